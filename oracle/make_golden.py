@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code in this container.
+
+    python oracle/make_golden.py            # needs /root/reference (read-only) -- build container only
+
+The reference modules (probabilistic_inference.py, inference_utils.py, modeling_utils.py) are
+imported where they lie via oracle/refimport.py (detectron2 calls served by oracle/refstub);
+nothing is copied.  A fake model object returns seeded synthetic head tensors
+(pod_compare_amd.synthetic), normal draws are served from a numpy-Philox stream by patching
+`torch.distributions.*._standard_normal`, and `topk` / `batched_nms` results are recorded so
+index sequences can be compared exactly.
+
+A fixture is DATA: the generator parameters (seeds, sizes), checksums of the regenerated
+inputs / eps stream, and the reference's outputs.  Small unit fixtures store their input
+arrays verbatim.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.refimport import load_reference  # noqa: E402
+from pod_compare_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(tensors) -> str:
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def head_checksum(ho) -> str:
+    ts = list(ho.cls) + list(ho.delta) + (ho.cls_var or []) + (ho.reg_var or [])
+    return sha(ts)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole-predictor cases
+# ---------------------------------------------------------------------------------------------
+
+CASES = {
+    # name: dict(mode, runs, heads, synth kwargs, cfg)
+    "cfg1_standard_nms_plain": dict(mode="standard_nms", runs=1, cls_var=False, reg_var=False, seeds=[11, 12]),
+    "cfg2_bayes_od_regclsvar": dict(mode="bayes_od", runs=1, cls_var=True, reg_var=True, seeds=[21, 22]),
+    "cfg3_bayes_od_mc10": dict(mode="bayes_od", runs=10, mc=True, cls_var=True, reg_var=True, seeds=[31, 32]),
+    "cfg4_anchor_stats_plain": dict(mode="anchor_statistics", runs=1, cls_var=False, reg_var=False, seeds=[41, 42]),
+    "cfg5_ensembles_pre_nms": dict(mode="ensembles", runs=5, ensemble=True, cls_var=True, reg_var=True, seeds=[51, 52]),
+    "anchor_stats_regclsvar": dict(mode="anchor_statistics", runs=1, cls_var=True, reg_var=True, seeds=[61]),
+    "bayes_od_ci_clsbayes": dict(mode="bayes_od", runs=1, cls_var=True, reg_var=True, seeds=[71],
+                                 box_merge="covariance_intersection", cls_merge="bayesian_inference"),
+    "mc_dropout_plain_pre_nms": dict(mode="mc_dropout_ensembles", runs=10, mc=True, cls_var=False, reg_var=False, seeds=[81]),
+    "standard_nms_regclsvar": dict(mode="standard_nms", runs=1, cls_var=True, reg_var=True, seeds=[91]),
+    "worst_topk_regclsvar": dict(mode="standard_nms", runs=1, cls_var=True, reg_var=True, seeds=[101], synth_mode="worst"),
+    "worst_bayes_od_mc4": dict(mode="bayes_od", runs=4, mc=True, cls_var=True, reg_var=True, seeds=[111], synth_mode="worst",
+                               topk=200),
+    "full_cov_standard_nms": dict(mode="standard_nms", runs=1, cls_var=True, reg_var=True, cov_dims=10, seeds=[121]),
+    "mc3_standard_nms_regclsvar": dict(mode="standard_nms", runs=3, mc=True, cls_var=True, reg_var=True, seeds=[131]),
+    "post_nms_ensembles": dict(mode="ensembles", runs=3, ensemble=True, post_nms=True, cls_var=True, reg_var=True, seeds=[141]),
+    "post_nms_mc_dropout": dict(mode="mc_dropout_ensembles", runs=3, mc=True, post_nms=True, cls_var=True, reg_var=True,
+                                seeds=[151]),
+    "empty_plain": dict(mode="standard_nms", runs=1, cls_var=False, reg_var=False, seeds=[161], num_boxes=0),
+    # BASELINE configs[2] at full size: 1280x720 frame -> 750x1333 network input -> 768x1344 padded, R = 193374
+    "full_cfg3_bayes_od_mc10": dict(mode="bayes_od", runs=10, mc=True, cls_var=True, reg_var=True, seeds=[1001],
+                                    image=(750, 1333), out=(720, 1280), num_boxes=24),
+    "full_cfg4_anchor_stats_plain": dict(mode="anchor_statistics", runs=1, cls_var=False, reg_var=False, seeds=[1002],
+                                         image=(750, 1333), out=(720, 1280), num_boxes=24),
+}
+SMALL_IMAGE, SMALL_OUT = (180, 250), (173, 240)
+
+
+class FakeModel:
+    """Stands in for ProbabilisticRetinaNet (attributes of SURVEY 8b; outputs of PR:352-361)."""
+
+    def __init__(self, ho, run_ids, topk=1000):
+        from detectron2.modeling.box_regression import Box2BoxTransform
+        from detectron2.structures import Boxes
+        self.ho, self.run_ids = ho, run_ids
+        self.in_features = ["p3", "p4", "p5", "p6", "p7"]
+        self.cls_var_num_samples = 10
+        self.test_topk_candidates = topk
+        self.test_score_thresh = 0.05
+        self.test_nms_thresh = 0.5
+        self.max_detections_per_image = 100
+        self.box2box_transform = Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0))
+        self.device = torch.device("cpu")
+        self._Boxes = Boxes
+
+    def _one(self, run):
+        d = synthetic.to_reference_layout(self.ho, run)
+        d = {k: (None if v is None else [t.clone() for t in v]) for k, v in d.items()}
+        d["anchors"] = [self._Boxes(a.clone()) for a in self.ho.anchors]
+        return d
+
+    def __call__(self, input_im, return_anchorwise_output=True, num_mc_dropout_runs=-1):
+        if num_mc_dropout_runs > 1:
+            outs = [self._one(r) for r in self.run_ids[:num_mc_dropout_runs]]
+            return {k: (None if outs[0][k] is None else sum((o[k] for o in outs), [])) for k in outs[0]}
+        return self._one(self.run_ids[0])
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def run_case(pi, iu, name, spec, seed):
+    image = spec.get("image", SMALL_IMAGE)
+    out = spec.get("out", SMALL_OUT)
+    from pod_compare_amd.anchors import padded_size
+    padded = padded_size(*image)
+    runs = spec["runs"]
+    ho = synthetic.planted_head_outputs(padded, runs, seed=seed, num_boxes=spec.get("num_boxes", 8),
+                                        with_cls_var=spec["cls_var"], with_reg_var=spec["reg_var"],
+                                        cov_dims=spec.get("cov_dims", 4), mode=spec.get("synth_mode", "planted"))
+    topk = spec.get("topk", 1000)
+    pred = object.__new__(pi.RetinaNetProbabilisticPredictor)
+    post_nms = spec.get("post_nms", False)
+    pred.cfg = ns(PROBABILISTIC_INFERENCE=ns(
+        AFFINITY_THRESHOLD=0.9,
+        BAYES_OD=ns(BOX_MERGE_MODE=spec.get("box_merge", "bayesian_inference"), CLS_MERGE_MODE=spec.get("cls_merge", "max_score")),
+        ENSEMBLES=ns(BOX_MERGE_MODE="post_nms" if post_nms else "pre_nms"),
+        ENSEMBLES_DROPOUT=ns(BOX_MERGE_MODE="post_nms" if post_nms else "pre_nms")))
+    pred.inference_mode = spec["mode"]
+    pred.mc_dropout_enabled = bool(spec.get("mc", False))
+    pred.num_mc_dropout_runs = runs if spec.get("mc", False) else 1
+    pred.sample_box2box_transform = iu.SampleBox2BoxTransform((1.0, 1.0, 1.0, 1.0))
+    if spec.get("ensemble", False):
+        pred.model_list = [FakeModel(ho, [r], topk) for r in range(runs)]
+        pred.model = pred.model_list[0]
+    else:
+        pred.model_list = []
+        pred.model = FakeModel(ho, list(range(runs)), topk)
+
+    # --- instrumentation: eps stream, top-k indices, NMS keeps, anchorwise outputs
+    eps_src = synthetic.SeededNormals(seed + 7_000_000)
+    eps_log, topk_log, keep_log, aw_log = [], [], [], []
+
+    def std_normal(shape, dtype, device):
+        t = eps_src(shape)
+        eps_log.append(t)
+        return t
+
+    import torch.distributions.multivariate_normal as mvn_mod
+    import torch.distributions.normal as normal_mod
+    orig_n, orig_m = normal_mod._standard_normal, mvn_mod._standard_normal
+    orig_topk = torch.Tensor.topk
+    orig_nms_pi, orig_nms_iu = pi.batched_nms, iu.batched_nms
+    orig_inf = pi.RetinaNetProbabilisticPredictor.retinanet_probabilistic_inference
+
+    def topk_spy(self, *a, **k):
+        r = orig_topk(self, *a, **k)
+        topk_log.append(r[1].clone())
+        return r
+
+    def nms_spy(*a, **k):
+        r = orig_nms_iu(*a, **k)
+        keep_log.append(r.clone())
+        return r
+
+    def inf_spy(self, *a, **k):
+        r = orig_inf(self, *a, **k)
+        aw_log.append(tuple(x.clone() if isinstance(x, torch.Tensor) else x for x in r))
+        return r
+
+    normal_mod._standard_normal = mvn_mod._standard_normal = std_normal
+    torch.Tensor.topk = topk_spy
+    pi.batched_nms = iu.batched_nms = nms_spy
+    pi.RetinaNetProbabilisticPredictor.retinanet_probabilistic_inference = inf_spy
+    try:
+        input_im = [{"image": torch.zeros((3,) + tuple(image)), "height": out[0], "width": out[1], "image_id": seed}]
+        with torch.no_grad():
+            res = pred(input_im)
+    finally:
+        normal_mod._standard_normal, mvn_mod._standard_normal = orig_n, orig_m
+        torch.Tensor.topk = orig_topk
+        pi.batched_nms, iu.batched_nms = orig_nms_pi, orig_nms_iu
+        pi.RetinaNetProbabilisticPredictor.retinanet_probabilistic_inference = orig_inf
+
+    cat_map = {i: i + 1 for i in range(7)}
+    js = iu.instances_to_json(res, seed, cat_map)
+    fx = {
+        "meta": json.dumps(dict(name=name, seed=seed, spec={k: v for k, v in spec.items() if k != "seeds"},
+                                image=list(image), out=list(out), padded=list(padded), eps_seed=seed + 7_000_000,
+                                topk=topk, input_sha=head_checksum(ho), eps_sha=sha(eps_log),
+                                eps_shapes=[list(t.shape) for t in eps_log], n_anchorwise_calls=len(aw_log))),
+        "pred_boxes": res.pred_boxes.tensor.numpy(), "scores": res.scores.numpy(),
+        "pred_classes": res.pred_classes.numpy(), "pred_cls_probs": res.pred_cls_probs.numpy(),
+        "pred_boxes_covariance": res.pred_boxes_covariance.numpy(),
+        "json": json.dumps(js),
+    }
+    for i, t in enumerate(topk_log):
+        fx["topk_%d" % i] = t.numpy()
+    for i, t in enumerate(keep_log):
+        fx["nms_keep_%d" % i] = t.numpy()
+    for i, aw in enumerate(aw_log):
+        boxes, cov, prob, cls, pvec = aw
+        fx["aw%d_boxes" % i] = boxes.numpy()
+        fx["aw%d_cov" % i] = cov.numpy() if isinstance(cov, torch.Tensor) else np.zeros((0,), np.float32)
+        fx["aw%d_prob" % i] = prob.numpy()
+        fx["aw%d_cls" % i] = cls.numpy()
+        fx["aw%d_pvec" % i] = pvec.numpy()
+    return fx
+
+
+# ---------------------------------------------------------------------------------------------
+# unit fixtures (separately callable reference functions); inputs stored verbatim
+# ---------------------------------------------------------------------------------------------
+
+def unit_fixtures(pi, iu, mu):
+    from detectron2.structures import Boxes, Instances
+    rng = synthetic.SeededNormals(4242)
+    fx = {}
+    # MU:4-22
+    rv4, rv10 = rng.randn(9, 4) - 4.0, torch.cat((rng.randn(9, 4) - 4.0, 0.05 * rng.randn(9, 6)), 1)
+    fx.update(chol_in4=rv4, chol_out4=mu.covariance_output_to_cholesky(rv4), chol_in10=rv10,
+              chol_out10=mu.covariance_output_to_cholesky(rv10))
+    # IU:337-371 tensor form and list form
+    smp = 50.0 + 3.0 * rng.randn(6, 4, 200)
+    m, c = iu.compute_mean_covariance_torch(smp)
+    fx.update(mc_samples=smp, mc_mean=m, mc_cov=c)
+    lst = [20.0 + rng.randn(5, 4) for _ in range(10)]
+    m, c = iu.compute_mean_covariance_torch(lst)
+    fx.update(mcl_samples=torch.stack(lst, 0), mcl_mean=m, mcl_cov=c)
+    # IU:510-547
+    d = 0.3 * rng.randn(7, 4, 33)
+    d[0, 2, 0] = 9.0  # exercises the dw clamp
+    a0 = torch.tensor([[10., 20., 60., 90.]]).repeat(7, 1) + 5 * rng.rand(7, 4)
+    a = torch.repeat_interleave(a0.unsqueeze(2), 33, dim=2)
+    fx.update(sd_deltas=d, sd_anchors=a, sd_out=iu.SampleBox2BoxTransform((1., 1., 1., 1.)).apply_samples_deltas(d, a))
+    # IU:292-334 both merge modes
+    base = torch.tensor([100., 120., 180., 240.])
+    means = (base + 2.0 * rng.randn(6, 4)).numpy()
+    l = 0.5 * rng.randn(6, 4, 4)
+    covs = (torch.matmul(l, l.transpose(1, 2)) + 2.0 * torch.eye(4)).numpy()
+    for mode in ("bayesian_inference", "covariance_intersection"):
+        fm, fc = iu.bounding_box_bayesian_inference(means, covs, mode)
+        fx["bf_mean_" + mode], fx["bf_cov_" + mode] = np.squeeze(fm), fc
+    fx.update(bf_means=means, bf_covs=covs)
+    # IU:374-425 + IU:428-451 + IU:454-502
+    inst = Instances((180, 250))
+    bx = torch.tensor([[10., 10., 60., 80.], [-5., 20., 30., 60.], [100., 100., 400., 300.], [240., 10., 249., 12.],
+                       [260., 5., 300., 50.]])
+    inst.pred_boxes = Boxes(bx.clone())
+    inst.scores = torch.tensor([0.9, 0.8, 0.7, 0.6, 0.5])
+    inst.pred_classes = torch.tensor([0, 3, 6, 2, 1])
+    inst.pred_cls_probs = rng.rand(5, 7)
+    l = rng.randn(5, 4, 4)
+    inst.pred_boxes_covariance = torch.matmul(l, l.transpose(1, 2))
+    fx.update(pp_boxes=bx, pp_scores=inst.scores, pp_classes=inst.pred_classes, pp_probs=inst.pred_cls_probs,
+              pp_cov=inst.pred_boxes_covariance)
+    res = iu.probabilistic_detector_postprocess(inst, 173, 240)
+    fx.update(pp_out_boxes=res.pred_boxes.tensor, pp_out_scores=res.scores, pp_out_classes=res.pred_classes,
+              pp_out_probs=res.pred_cls_probs, pp_out_cov=res.pred_boxes_covariance,
+              pp_xywh_cov=iu.covar_xyxy_to_xywh(res.pred_boxes_covariance))
+    fx["pp_json"] = json.dumps(iu.instances_to_json(res, 77, {i: i + 1 for i in range(6)}))  # class 6 unmapped -> dropped
+    return {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in fx.items()}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    pi, iu, mu = load_reference()
+    np.savez_compressed(os.path.join(OUT, "unit_functions.npz"), **unit_fixtures(pi, iu, mu))
+    only = sys.argv[1:] or list(CASES)
+    for name in only:
+        spec = CASES[name]
+        for seed in spec["seeds"]:
+            fx = run_case(pi, iu, name, spec, seed)
+            path = os.path.join(OUT, "%s_s%d.npz" % (name, seed))
+            np.savez_compressed(path, **fx)
+            print("%-34s seed %5d  M=%3d  n=%s  %6.1f KB" % (name, seed, fx["pred_boxes"].shape[0],
+                                                            fx["aw0_boxes"].shape[0] if "aw0_boxes" in fx else "-",
+                                                            os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()
