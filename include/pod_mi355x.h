@@ -1,0 +1,211 @@
+/*
+ * pod_mi355x.h -- C ABI of the MI355X-native probabilistic-inference hot path.
+ *
+ * Drop-in boundary for asharakeh/pod_compare's `probabilistic_inference` plugin
+ * (reference files, relative to /root/reference/src):
+ *   PI = probabilistic_inference/probabilistic_inference.py
+ *   IU = probabilistic_inference/inference_utils.py
+ *   MU = probabilistic_modeling/modeling_utils.py
+ *   PR = probabilistic_modeling/probabilistic_retinanet.py
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a DEVICE pointer (HBM); everything else is host memory;
+ *   - all floating point is fp32, anchor indices int32, class ids int32 (the Python
+ *     boundary widens them to the reference's int64);
+ *   - outputs and scratch are caller-allocated; the library never allocates device memory,
+ *     never synchronises the device and holds no global state; distinct streams may be used
+ *     concurrently from distinct threads;
+ *   - every entry point takes the `hipStream_t` to launch on (passed as `void*` so that this
+ *     header needs no HIP include), is asynchronous and hipGraph-capturable, and returns
+ *     0 on success or a negative POD_E_* code (it never throws across the ABI);
+ *   - counts that are only known on the device (number of candidates, detections ...) live in
+ *     device int32 words; kernels are launched for the worst case and exit early.
+ *
+ * HBM data layout
+ *   dense head tensors, per FPN level l (what the conv head writes, NCHW, PR:486-537):
+ *       cls, cls_var : (n_runs, A*K, H_l, W_l)      delta : (n_runs, A*4, H_l, W_l)
+ *       reg_var      : (n_runs, A*D, H_l, W_l), D = 4 (diagonal) or 10 (full), MU:4-22
+ *     run r of a tensor starts `run_stride` elements after run r-1 (MC-dropout runs batched
+ *     on the batch dim, or ensemble members stacked / gathered over RCCL).
+ *   reference anchor index inside a level (permute_to_N_HWA_K, PR:343-349):
+ *       r = (h*W + w)*A + a,   channel of class k = a*K + k.
+ *   "plane layout" outputs keep the input's (A*C, H, W) order (coalesced, no transpose).
+ */
+#ifndef POD_MI355X_H
+#define POD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POD_ABI_VERSION 1
+#define POD_MAX_LEVELS 8
+#define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
+#define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
+#define POD_MAX_TOPK 2048        /* model.test_topk_candidates (detectron2 default 1000, PI:300) */
+#define POD_MAX_PROP_SAMPLES 1024 /* PI:355 hard-codes 1000 */
+#define POD_MAX_CLS_SAMPLES 64   /* CLS_VAR_LOSS.NUM_SAMPLES (10 in the reg_cls_var yamls) */
+#define POD_MAX_CANDIDATES 8192  /* n = sum over levels of kept top-k; 5 x 1000 at BASELINE */
+#define POD_MAX_DETECTIONS 128   /* model.max_detections_per_image (100) */
+
+#define POD_OK 0
+#define POD_E_INVALID (-1)       /* bad argument / unsupported size */
+#define POD_E_LAUNCH (-2)        /* HIP launch error (see hipGetLastError) */
+
+typedef void* pod_stream_t;      /* hipStream_t */
+
+/* One FPN level of the dense head output (device pointers, NCHW). */
+typedef struct PodLevel {
+    const float* cls;            /* dev (n_runs, A*K, H, W) logits               PR:352-361 'box_cls'     */
+    const float* cls_var;        /* dev (n_runs, A*K, H, W) log-variances or NULL            'box_cls_var' */
+    const float* delta;          /* dev (n_runs, A*4, H, W)                                   'box_delta'   */
+    const float* reg_var;        /* dev (n_runs, A*D, H, W) or NULL                           'box_reg_var' */
+    const float* eps_cls;        /* dev (cls_samples, H*W*A, K) replayed normals in REFERENCE layout, or NULL
+                                    (NULL = in-kernel Philox4x32-10; replay is the parity mode)            */
+    int64_t run_stride_cls;      /* elements between consecutive runs of cls / cls_var */
+    int64_t run_stride_delta;
+    int64_t run_stride_reg;
+    int32_t H, W;
+    int32_t anchor_base;         /* index of this level's first anchor in the level-concatenated order */
+    int32_t reserved;
+} PodLevel;
+
+/* Static description of the path (model attributes + config keys). */
+typedef struct PodConfig {
+    int32_t n_levels;            /* <= POD_MAX_LEVELS */
+    int32_t n_runs;              /* N >= 1; > 1 merges runs (PI:211-270) and adds epistemic covariance */
+    int32_t num_anchors;         /* A (9) */
+    int32_t num_classes;         /* K (7) */
+    int32_t cov_dims;            /* D: 0 (no reg_var head), 4 or 10 */
+    int32_t has_cls_var;         /* 0/1 */
+    int32_t merge_quirk;         /* 1 = reference behaviour (2*x0+x1+..+x_{n-2})/n, PI:216-222; 0 = true mean */
+    int32_t cls_samples;         /* model.cls_var_num_samples, PI:294 */
+    int32_t prop_samples;        /* 1000, PI:355 */
+    int32_t topk;                /* model.test_topk_candidates, PI:300 */
+    int32_t max_detections;      /* model.max_detections_per_image */
+    float score_thresh;          /* model.test_score_thresh, PI:304 */
+    float nms_thresh;            /* model.test_nms_thresh */
+    float affinity_thresh;       /* PROBABILISTIC_INFERENCE.AFFINITY_THRESHOLD */
+    float box_weights[4];        /* Box2BoxTransform weights (cfg.MODEL.RPN.BBOX_REG_WEIGHTS, PI:175-176) */
+    uint64_t philox_seed;        /* native-RNG mode only */
+} PodConfig;
+
+int pod_abi_version(void);
+
+/* ---- K1  mc_merge_score -------------------------------------------------------------------
+ * Replaces: the dense MC-dropout / ensemble merge PI:211-270, the classification sampling
+ * PI:289-297 and the max-over-classes + score-threshold test PI:301-304.
+ * Streams every run of every level once (coalesced 16-byte loads along W), writes the merged
+ * tensors in plane layout (skipped when n_runs == 1 or the pointer is NULL) and appends one
+ * 64-bit key per anchor whose score exceeds `score_thresh` to its level's candidate list:
+ *     key = (float_bits(score) << 32) | (0xFFFFFFFF - r)      (descending key = score desc, r asc)
+ * mean_* : dev, level-concatenated plane layout: level l starts at anchor_base_l * C elements.
+ * cand_keys : dev uint64[R_total], level l's list starts at anchor_base_l.
+ * cand_count: dev int32[n_levels], MUST be zero on entry (pod_reset_counters).
+ * HBM-bound; algorithmic bytes per image = 4 * R * (2K + 4 + D) * (N + 1)  (SURVEY 8d). */
+int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
+                       float* mean_cls, float* mean_cls_var, float* mean_delta, float* mean_reg_var,
+                       uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream);
+
+/* Zeroes `n` int32 device words on the stream (graph-capturable memset node). */
+int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
+
+/* ---- K2  level_topk ------------------------------------------------------------------------
+ * Replaces: `predicted_prob.topk(num_topk)` + `> test_score_thresh` filter PI:300-308, per level.
+ * Exact top-`topk` of each level's candidate list, sorted by descending key (ties: lower anchor
+ * index first).  One workgroup per level: LDS bitonic sort, preceded by an 8-pass radix select
+ * when a level has more than POD_MAX_TOPK candidates.
+ * sel_keys : dev uint64[n_levels * topk];  sel_count : dev int32[n_levels] (written). */
+int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
+                   const int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream);
+
+/* ---- K2b gather_candidates -----------------------------------------------------------------
+ * Replaces: the index gathers PI:305-338 and the level concatenation PI:341-342, 387-388.
+ * Candidate i of the level-concatenated list gets: anchor index inside its level, level id,
+ * score, class, K probabilities (recomputed bit-identically to K1), merged delta, merged
+ * reg_var (D values), its anchor box and every run's raw delta (for the epistemic term).
+ * anchors : dev (R_total, 4) level-concatenated XYXY anchors (PR:101).
+ * n_total : dev int32 (written) = number of candidates n. */
+int pod_gather_candidates(const PodConfig* cfg, const PodLevel* levels, const float* anchors,
+                          const uint64_t* sel_keys, const int32_t* sel_count,
+                          int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score, int32_t* cand_class,
+                          float* cand_probs, float* cand_delta, float* cand_reg_var, float* cand_anchor,
+                          float* cand_run_delta /* (n, n_runs, 4) or NULL when n_runs == 1 */,
+                          int32_t* n_total, pod_stream_t stream);
+
+/* ---- K3  decode_cov ------------------------------------------------------------------------
+ * Replaces: covariance_output_to_cholesky MU:4-22, the 1000-sample propagation PI:344-368
+ * (MVN rsample, SampleBox2BoxTransform.apply_samples_deltas IU:510-547,
+ * compute_mean_covariance_torch IU:337-371), the epistemic covariance PI:323-331 (+= PI:369-374)
+ * and the deterministic decode PI:375-385.  One wavefront per candidate; samples live in
+ * registers; two-pass moments with the CPU reference's 16-row block summation order.
+ * eps_prop : dev (prop_samples, n_replay, 4) replayed normals (reference layout) or NULL (Philox).
+ * boxes : dev (n,4)   cov : dev (n,4,4) (zeros when the model has neither reg_var nor runs). */
+int pod_decode_cov(const PodConfig* cfg, const PodLevel* levels, const int32_t* n_total, int32_t n_capacity,
+                   const float* cand_delta, const float* cand_reg_var, const float* cand_anchor,
+                   const float* cand_run_delta, const int32_t* cand_anchor_idx, const int32_t* cand_level,
+                   const float* eps_prop, int32_t n_replay,
+                   float* boxes, float* cov, pod_stream_t stream);
+
+/* ---- K4  nms_cluster -----------------------------------------------------------------------
+ * Replaces: detectron2 batched_nms -> torchvision coordinate-trick NMS (call sites PI:554-560,
+ * IU:31-36, IU:83-89): boxes + class*(max_coord+1), stable descending-score order, suppress
+ * iff IoU > nms_thresh, first `max_detections` survivors.
+ * keep : dev int32[max_detections] candidate indices in keep order;  n_keep : dev int32 (written).
+ * scratch : dev, pod_nms_scratch_bytes(n_capacity) bytes. */
+size_t pod_nms_scratch_bytes(int32_t n_capacity);
+int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capacity,
+                    const float* boxes, const float* scores, const int32_t* classes,
+                    int32_t* keep, int32_t* n_keep, void* scratch, pod_stream_t stream);
+
+/* ---- K5  bayes_fuse ------------------------------------------------------------------------
+ * Replaces: post_processing_bayes_od PI:562-636 + bounding_box_bayesian_inference IU:292-334.
+ * One workgroup per kept centre: members = {j : IoU(centre, j) > affinity (pairwise_iou, Q8:
+ * only the <=100 needed rows) and argmax(probs_j) == argmax(probs_centre)}; 4x4 SPD inverses
+ * in fp64 registers, wavefront reductions of the precisions.
+ * box_mode: 0 = bayesian_inference, 1 = covariance_intersection;
+ * cls_mode: 0 = max_score (centre's score/class/probs), 1 = bayesian_inference (mean of member probs).
+ * Degenerate cluster (no member, Q12): falls back to the centre's box/covariance.
+ * out_* : dev, max_detections rows. */
+int pod_bayes_fuse(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
+                   const float* boxes, const float* cov, const float* scores, const int32_t* classes,
+                   const float* probs, int32_t box_mode, int32_t cls_mode,
+                   float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,
+                   pod_stream_t stream);
+
+/* ---- K6  anchor_stats_merge ----------------------------------------------------------------
+ * Replaces: general_anchor_statistics_postprocessing IU:91-154 (cluster mean, residual outer
+ * products / max(m-1,1), + mean member covariance when the net provides one, mean prob vector,
+ * singleton rule IU:127-133, score/class re-derived from the merged prob vector IU:146-152).
+ * cov may be NULL (no network covariance). */
+int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
+                           const float* boxes, const float* cov, const int32_t* classes, const float* probs,
+                           float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,
+                           pod_stream_t stream);
+
+/* ---- K7  finalize --------------------------------------------------------------------------
+ * Replaces: the keep-gather of general_standard_nms_postprocessing IU:42-53 (when `keep` is
+ * non-NULL rows are gathered through it; cov == NULL gives the zeros of IU:52-53) and
+ * probabilistic_detector_postprocess IU:374-425 (scale, clip, drop empty boxes, cov + 1e-4 I,
+ * S cov S^T).  Also emits, per detection, the XYWH box and T cov T^T of instances_to_json /
+ * covar_xyxy_to_xywh IU:428-502 as a fixed-stride record:
+ *     records[i] = { x, y, w, h, score, class, probs[K], cov_xywh[16] }   (6 + K + 16 floats)
+ * det_* : dev, max_detections rows;  n_det : dev int32 (written). */
+int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_rows,
+                 const float* boxes, const float* cov, const float* scores, const int32_t* classes,
+                 const float* probs, float scale_x, float scale_y, float out_h, float out_w,
+                 float* det_boxes, float* det_cov, float* det_scores, int32_t* det_classes, float* det_probs,
+                 float* records, int32_t* n_det, pod_stream_t stream);
+
+/* ---- NLL scoring rule ----------------------------------------------------------------------
+ * Replaces: compute_reg_scores core/evaluation_tools/scoring_rules.py:68-74
+ * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */
+int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t n, float* nll, pod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POD_MI355X_H */

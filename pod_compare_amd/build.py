@@ -1,0 +1,55 @@
+"""Builds the gfx950 HIP library of the hot path in-tree (pod_compare_amd/lib/libpod_mi355x.so).
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  `python -m pod_compare_amd.build [--force]`.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libpod_mi355x.so")
+SOURCES = ["k1_mc_merge_score.hip", "k2_topk_gather.hip", "k3_decode_cov.hip", "k4_nms.hip", "k5_cluster_merge.hip"]
+HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(os.path.dirname(HERE), "include", "pod_mi355x.h")]
+# -ffp-contract=off: the CPU reference rounds after every op; index parity needs the same fp32 values.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,230 @@
+// K2 level_topk + K2b gather_candidates.
+//
+// Replaces (probabilistic_inference.py): `predicted_prob.topk(num_topk)` and the
+// `> test_score_thresh` filter :300-308 (K1 already applied the threshold, which commutes with
+// top-k), the per-level gathers :305-338 and the level concatenation :341-342 / :387-388.
+//
+// K2: one 1024-thread workgroup per FPN level.  Keys are 64-bit (score bits, ~anchor index), all
+// distinct, so "top-k, ties to the lower index" is a plain descending sort.  Up to 2048
+// candidates are sorted directly in LDS (bitonic network); a level with more candidates first runs
+// an 8-pass MSB radix select (LDS histograms) to find the k-th largest key, then compacts.
+// K2b: one thread per selected candidate re-derives the class probabilities with K1's own device
+// function (bit-identical), and gathers merged deltas / log-variances, the anchor and every run's
+// raw delta into the level-concatenated candidate arrays.
+#include "pod_device.h"
+
+namespace pod {
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int SORT_CAP = POD_MAX_TOPK;   // 2048 keys = 16 KiB LDS
+
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n_pow2, int tid, int nthreads) {
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct K2Params {
+    int32_t anchor_base[POD_MAX_LEVELS];
+    int32_t topk;
+    const uint64_t* cand_keys;
+    const int32_t* cand_count;
+    uint64_t* sel_keys;
+    int32_t* sel_count;
+};
+
+__global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) {
+    __shared__ uint64_t s_keys[SORT_CAP];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint64_t s_prefix;
+    __shared__ int32_t s_remaining, s_fill;
+    const int l = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint64_t* keys = P.cand_keys + P.anchor_base[l];
+    const int C = P.cand_count[l];
+    const int k = min(P.topk, C);
+    int n_sort;
+    if (C <= SORT_CAP) {
+        n_sort = 1;
+        while (n_sort < C) n_sort <<= 1;
+        for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = (i < C) ? keys[i] : 0ull;
+        __syncthreads();
+    } else {
+        // radix select: k-th largest of C distinct 64-bit keys, 8 bits per pass from the top
+        if (tid == 0) {
+            s_prefix = 0ull;
+            s_remaining = k;
+        }
+        __syncthreads();
+        for (int pass = 7; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            if (tid < 256) s_hist[tid] = 0u;
+            __syncthreads();
+            const uint64_t prefix = s_prefix;
+            const uint64_t himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
+            for (int i = tid; i < C; i += TOPK_THREADS) {
+                const uint64_t key = keys[i];
+                if ((key & himask) == prefix) atomicAdd(&s_hist[(uint32_t)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining;
+                int d = 255;
+                for (; d > 0; --d) {
+                    const int c = (int)s_hist[d];
+                    if (c >= rem) break;
+                    rem -= c;
+                }
+                s_remaining = rem;
+                s_prefix = prefix | ((uint64_t)d << shift);
+            }
+            __syncthreads();
+        }
+        const uint64_t thr = s_prefix;   // exactly k keys are >= thr
+        if (tid == 0) s_fill = 0;
+        n_sort = 1;
+        while (n_sort < k) n_sort <<= 1;
+        for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < C; i += TOPK_THREADS) {
+            const uint64_t key = keys[i];
+            if (key >= thr) s_keys[atomicAdd(&s_fill, 1)] = key;
+        }
+        __syncthreads();
+    }
+    bitonic_sort_desc(s_keys, n_sort, tid, TOPK_THREADS);
+    uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
+    for (int i = tid; i < k; i += TOPK_THREADS) out[i] = s_keys[i];
+    if (tid == 0) P.sel_count[l] = k;
+}
+
+struct K2bParams {
+    PodLevel lv[POD_MAX_LEVELS];
+    int32_t n_levels, n_runs, A, K, D, has_cls_var, quirk, cls_samples, topk;
+    uint64_t seed;
+    const float* anchors;
+    const uint64_t* sel_keys;
+    const int32_t* sel_count;
+    int32_t* cand_anchor_idx;
+    int32_t* cand_level;
+    float* cand_score;
+    int32_t* cand_class;
+    float* cand_probs;
+    float* cand_delta;
+    float* cand_reg_var;
+    float* cand_anchor;
+    float* cand_run_delta;
+    int32_t* n_total;
+};
+
+// merged value of one element (plane-layout offset `e` inside a run) in the reference order
+__device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int64_t e, int n_runs, int quirk) {
+    float acc = base[e];
+    if (n_runs == 1) return acc;
+    for (int t = 1; t < n_runs; ++t) acc = acc + base[(int64_t)merge_term_run(t, quirk) * rs + e];
+    return __fdiv_rn(acc, (float)n_runs);
+}
+
+__global__ void __launch_bounds__(256) k2b_gather(const K2bParams P) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = P.n_levels;
+    int total = 0;
+    for (int i = 0; i < L; ++i) total += P.sel_count[i];
+    if (slot == 0) *P.n_total = total;
+    const int l = slot / P.topk;
+    const int j = slot - l * P.topk;
+    if (l >= L || j >= P.sel_count[l]) return;
+    int dst = j;
+    for (int i = 0; i < l; ++i) dst += P.sel_count[i];
+    const PodLevel& lv = P.lv[l];
+    const uint64_t key = P.sel_keys[(int64_t)l * P.topk + j];
+    const int r = key_index(key);
+    const int A = P.A, K = P.K, D = P.D;
+    const int hw = r / A;
+    const int a = r - hw * A;
+    const int64_t HW = (int64_t)lv.H * lv.W;
+    const bool has_var = P.has_cls_var != 0;
+    // class probabilities, identical code path to K1
+    float best = 0.0f;
+    int best_k = 0;
+    for (int k = 0; k < K; ++k) {
+        const int64_t e = (int64_t)(a * K + k) * HW + hw;
+        const float logit = merge_scalar(lv.cls, lv.run_stride_cls, e, P.n_runs, P.quirk);
+        const float lvar = has_var ? merge_scalar(lv.cls_var, lv.run_stride_cls, e, P.n_runs, P.quirk) : 0.0f;
+        ClsEps eps(lv.eps_cls, HW * A, K, r, k, P.seed, (uint32_t)(lv.anchor_base + r));
+        const float p = class_prob(logit, lvar, has_var, P.cls_samples, eps);
+        P.cand_probs[(int64_t)dst * K + k] = p;
+        if (k == 0 || p > best) {
+            best = p;
+            best_k = k;
+        }
+    }
+    P.cand_score[dst] = best;            // == key_score(key) by construction
+    P.cand_class[dst] = best_k;
+    P.cand_anchor_idx[dst] = r;
+    P.cand_level[dst] = l;
+    for (int c = 0; c < 4; ++c) {
+        const int64_t e = (int64_t)(a * 4 + c) * HW + hw;
+        P.cand_delta[(int64_t)dst * 4 + c] = merge_scalar(lv.delta, lv.run_stride_delta, e, P.n_runs, P.quirk);
+        if (P.cand_run_delta)
+            for (int run = 0; run < P.n_runs; ++run)
+                P.cand_run_delta[((int64_t)dst * P.n_runs + run) * 4 + c] = lv.delta[(int64_t)run * lv.run_stride_delta + e];
+    }
+    for (int c = 0; c < D; ++c) {
+        const int64_t e = (int64_t)(a * D + c) * HW + hw;
+        P.cand_reg_var[(int64_t)dst * D + c] = merge_scalar(lv.reg_var, lv.run_stride_reg, e, P.n_runs, P.quirk);
+    }
+    const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
+    *reinterpret_cast<float4*>(P.cand_anchor + (int64_t)dst * 4) = anc;
+}
+
+}  // namespace pod
+
+extern "C" int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
+                              const int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream) {
+    if (!cfg || !levels || !cand_keys || !cand_count || !sel_keys || !sel_count) return POD_E_INVALID;
+    if (cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS || cfg->topk < 1 || cfg->topk > POD_MAX_TOPK) return POD_E_INVALID;
+    pod::K2Params P;
+    for (int l = 0; l < cfg->n_levels; ++l) P.anchor_base[l] = levels[l].anchor_base;
+    P.topk = cfg->topk; P.cand_keys = cand_keys; P.cand_count = cand_count; P.sel_keys = sel_keys; P.sel_count = sel_count;
+    hipLaunchKernelGGL(pod::k2_level_topk, dim3(cfg->n_levels), dim3(pod::TOPK_THREADS), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_gather_candidates(const PodConfig* cfg, const PodLevel* levels, const float* anchors,
+                                     const uint64_t* sel_keys, const int32_t* sel_count, int32_t* cand_anchor_idx,
+                                     int32_t* cand_level, float* cand_score, int32_t* cand_class, float* cand_probs,
+                                     float* cand_delta, float* cand_reg_var, float* cand_anchor, float* cand_run_delta,
+                                     int32_t* n_total, pod_stream_t stream) {
+    if (!cfg || !levels || !anchors || !sel_keys || !sel_count || !cand_anchor_idx || !cand_level || !cand_score ||
+        !cand_class || !cand_probs || !cand_delta || !cand_anchor || !n_total)
+        return POD_E_INVALID;
+    if (cfg->cov_dims > 0 && !cand_reg_var) return POD_E_INVALID;
+    if (cfg->n_levels * cfg->topk > POD_MAX_CANDIDATES * 4) return POD_E_INVALID;
+    pod::K2bParams P;
+    for (int l = 0; l < cfg->n_levels; ++l) P.lv[l] = levels[l];
+    P.n_levels = cfg->n_levels; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = cfg->num_classes; P.D = cfg->cov_dims;
+    P.has_cls_var = cfg->has_cls_var; P.quirk = cfg->merge_quirk; P.cls_samples = cfg->cls_samples; P.topk = cfg->topk;
+    P.seed = cfg->philox_seed; P.anchors = anchors; P.sel_keys = sel_keys; P.sel_count = sel_count;
+    P.cand_anchor_idx = cand_anchor_idx; P.cand_level = cand_level; P.cand_score = cand_score; P.cand_class = cand_class;
+    P.cand_probs = cand_probs; P.cand_delta = cand_delta; P.cand_reg_var = cand_reg_var; P.cand_anchor = cand_anchor;
+    P.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr; P.n_total = n_total;
+    const int slots = cfg->n_levels * cfg->topk;
+    hipLaunchKernelGGL(pod::k2b_gather, dim3((slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}

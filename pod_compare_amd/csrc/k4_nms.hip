@@ -1,0 +1,160 @@
+// K4 nms_cluster -- class-aware NMS of the candidate list.
+//
+// Replaces: detectron2.layers.batched_nms -> torchvision.ops.batched_nms (coordinate trick) ->
+// torchvision nms, at the reference call sites probabilistic_inference.py:554-560,
+// inference_utils.py:31-36, :83-89 (and :269-274 for the post-NMS ensemble merge):
+//     boxes_for_nms = boxes + class * (boxes.max() + 1)        (fp32, rounds the shifted coordinates)
+//     visit in stable descending-score order; area = (x2-x1)*(y2-y1);
+//     suppress j iff inter / (area_i + area_j - inter) > thr   (strict)
+//     keep[: max_detections]
+//
+// One 1024-thread workgroup: (1) max-reduce the coordinates, (2) LDS bitonic sort of 64-bit
+// (score, ~index) keys, (3) sorted, shifted boxes to scratch, (4) greedy sweep with an LDS
+// "removed" bitmap: thread 0 finds the next survivor with ffs on 64-bit words, all threads then
+// test it against the remaining boxes.  The sweep stops at max_detections survivors (Q8: only
+// those rows are ever needed), so worst-case work is max_det x n IoUs, not n^2.
+#include "pod_device.h"
+
+namespace pod {
+
+constexpr int NMS_THREADS = 1024;
+
+struct K4Params {
+    const int32_t* n_total;
+    int32_t n_capacity, max_det;
+    float thr;
+    const float* boxes;
+    const float* scores;
+    const int32_t* classes;
+    int32_t* keep;
+    int32_t* n_keep;
+    float4* sbox;      // scratch: sorted + shifted boxes
+    float* sarea;      // scratch
+    int32_t* order;    // scratch: sorted position -> candidate index
+};
+
+__global__ void __launch_bounds__(NMS_THREADS) k4_nms(const K4Params P) {
+    __shared__ uint64_t s_keys[POD_MAX_CANDIDATES];          // 64 KiB
+    __shared__ unsigned long long s_removed[POD_MAX_CANDIDATES / 64];
+    __shared__ float s_red[NMS_THREADS / 64];
+    __shared__ int s_cur, s_kept;
+    const int tid = threadIdx.x;
+    const int n = min(*P.n_total, P.n_capacity);
+    if (n <= 0) {
+        if (tid == 0) *P.n_keep = 0;
+        return;
+    }
+    // (1) max coordinate
+    float m = -INFINITY;
+    for (int i = tid; i < n * 4; i += NMS_THREADS) m = fmaxf(m, P.boxes[i]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    __syncthreads();
+    m = s_red[0];
+    for (int w = 1; w < NMS_THREADS / 64; ++w) m = fmaxf(m, s_red[w]);
+    const float shift_unit = m + 1.0f;
+    // (2) sort by (score desc, index asc)
+    int n_sort = 1;
+    while (n_sort < n) n_sort <<= 1;
+    for (int i = tid; i < n_sort; i += NMS_THREADS) s_keys[i] = (i < n) ? make_key(P.scores[i], i) : 0ull;
+    for (int i = tid; i < POD_MAX_CANDIDATES / 64; i += NMS_THREADS) s_removed[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= n_sort; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_sort; i += NMS_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s_keys[i], b = s_keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s_keys[i] = b;
+                        s_keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // (3) sorted, shifted boxes
+    for (int p = tid; p < n; p += NMS_THREADS) {
+        const int idx = key_index(s_keys[p]);
+        const float4 b = *reinterpret_cast<const float4*>(P.boxes + (size_t)idx * 4);
+        const float off = (float)P.classes[idx] * shift_unit;
+        const float4 sb = float4{b.x + off, b.y + off, b.z + off, b.w + off};
+        P.sbox[p] = sb;
+        P.sarea[p] = (sb.z - sb.x) * (sb.w - sb.y);
+        P.order[p] = idx;
+    }
+    if (tid == 0) {
+        s_cur = -1;
+        s_kept = 0;
+    }
+    __syncthreads();   // workgroup-scope visibility of this block's own global writes
+    // (4) greedy sweep
+    const int nwords = (n + 63) >> 6;
+    while (true) {
+        if (tid == 0) {
+            int next = -1;
+            int start = s_cur + 1;
+            for (int w = start >> 6; w < nwords && next < 0; ++w) {
+                unsigned long long live = ~s_removed[w];
+                if (w == (start >> 6)) live &= ~0ull << (start & 63);
+                if (live) {
+                    const int cand = (w << 6) + __ffsll((long long)live) - 1;
+                    if (cand < n) next = cand;
+                    break;
+                }
+            }
+            if (next >= 0 && s_kept < P.max_det) {
+                P.keep[s_kept] = P.order[next];
+                s_kept = s_kept + 1;
+                s_cur = next;
+            } else {
+                s_cur = -1;
+            }
+        }
+        __syncthreads();
+        const int i = s_cur;
+        const int kept = s_kept;
+        if (i < 0) break;
+        if (kept >= P.max_det) break;   // survivor list full: the rest of the sweep cannot change keep[:max_det]
+        const float4 bi = P.sbox[i];
+        const float ai = P.sarea[i];
+        for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
+            const float4 bj = P.sbox[j];
+            const float w = fmaxf(0.0f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
+            const float h = fmaxf(0.0f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
+            const float inter = w * h;
+            const float ovr = __fdiv_rn(inter, (ai + P.sarea[j]) - inter);
+            if (ovr > P.thr) atomicOr(&s_removed[j >> 6], 1ull << (j & 63));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *P.n_keep = s_kept;
+}
+
+}  // namespace pod
+
+extern "C" size_t pod_nms_scratch_bytes(int32_t n_capacity) {
+    if (n_capacity < 1) return 0;
+    const size_t n = (size_t)n_capacity;
+    return n * sizeof(float4) + n * sizeof(float) + n * sizeof(int32_t) + 64;
+}
+
+extern "C" int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capacity, const float* boxes,
+                               const float* scores, const int32_t* classes, int32_t* keep, int32_t* n_keep, void* scratch,
+                               pod_stream_t stream) {
+    if (!cfg || !n_total || !boxes || !scores || !classes || !keep || !n_keep || !scratch) return POD_E_INVALID;
+    if (n_capacity < 1 || n_capacity > POD_MAX_CANDIDATES) return POD_E_INVALID;
+    if (cfg->max_detections < 1 || cfg->max_detections > POD_MAX_DETECTIONS) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(scratch) & 15u) != 0) return POD_E_INVALID;
+    pod::K4Params P;
+    P.n_total = n_total; P.n_capacity = n_capacity; P.max_det = cfg->max_detections; P.thr = cfg->nms_thresh;
+    P.boxes = boxes; P.scores = scores; P.classes = classes; P.keep = keep; P.n_keep = n_keep;
+    char* s = static_cast<char*>(scratch);
+    P.sbox = reinterpret_cast<float4*>(s);
+    P.sarea = reinterpret_cast<float*>(s + (size_t)n_capacity * sizeof(float4));
+    P.order = reinterpret_cast<int32_t*>(s + (size_t)n_capacity * (sizeof(float4) + sizeof(float)));
+    hipLaunchKernelGGL(pod::k4_nms, dim3(1), dim3(pod::NMS_THREADS), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}

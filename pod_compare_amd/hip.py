@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI declared in include/pod_mi355x.h.
+
+The product path has NO CPU fallback: if the HIP library is missing or a kernel entry point
+returns an error, a RuntimeError is raised.  Tensors are passed as raw device pointers
+(`tensor.data_ptr()`), the stream as the current torch HIP stream handle -- torch is plumbing
+(device memory + streams), the kernels are ours.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from typing import Optional
+
+import torch
+
+from .build import LIB
+
+POD_ABI_VERSION = 1
+POD_MAX_LEVELS = 8
+POD_MAX_CLASSES = 16
+POD_MAX_RUNS = 64
+POD_MAX_TOPK = 2048
+POD_MAX_PROP_SAMPLES = 1024
+POD_MAX_CLS_SAMPLES = 64
+POD_MAX_CANDIDATES = 8192
+POD_MAX_DETECTIONS = 128
+
+EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
+           "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
+           "pod_finalize", "pod_reg_nll")
+
+
+class PodLevel(Structure):
+    _fields_ = [("cls", c_void_p), ("cls_var", c_void_p), ("delta", c_void_p), ("reg_var", c_void_p), ("eps_cls", c_void_p),
+                ("run_stride_cls", c_int64), ("run_stride_delta", c_int64), ("run_stride_reg", c_int64),
+                ("H", c_int32), ("W", c_int32), ("anchor_base", c_int32), ("reserved", c_int32)]
+
+
+class PodConfig(Structure):
+    _fields_ = [("n_levels", c_int32), ("n_runs", c_int32), ("num_anchors", c_int32), ("num_classes", c_int32),
+                ("cov_dims", c_int32), ("has_cls_var", c_int32), ("merge_quirk", c_int32), ("cls_samples", c_int32),
+                ("prop_samples", c_int32), ("topk", c_int32), ("max_detections", c_int32),
+                ("score_thresh", c_float), ("nms_thresh", c_float), ("affinity_thresh", c_float),
+                ("box_weights", c_float * 4), ("philox_seed", c_uint64)]
+
+
+class PodError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.environ.get("POD_MI355X_LIB", LIB)
+
+
+def load() -> ctypes.CDLL:
+    """Loads libpod_mi355x.so (built by `python -m pod_compare_amd.build`); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PodError("HIP library {} not found: run `python -m pod_compare_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback for the hot path.".format(path))
+    lib = ctypes.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise PodError("{} does not export {}".format(path, name))
+    P = c_void_p
+    lib.pod_abi_version.restype = ctypes.c_int
+    lib.pod_nms_scratch_bytes.restype = c_size_t
+    lib.pod_nms_scratch_bytes.argtypes = [c_int32]
+    lib.pod_reset_counters.argtypes = [P, c_int32, P]
+    lib.pod_mc_merge_score.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P, P]
+    lib.pod_level_topk.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P]
+    lib.pod_gather_candidates.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 14
+    lib.pod_decode_cov.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, c_int32, P, P, P, P, P, P, P, c_int32, P, P, P]
+    lib.pod_nms_cluster.argtypes = [POINTER(PodConfig), P, c_int32, P, P, P, P, P, P, P]
+    lib.pod_bayes_fuse.argtypes = [POINTER(PodConfig), P, P, P, P, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P]
+    lib.pod_anchor_stats_merge.argtypes = [POINTER(PodConfig), P, P, P, P, P, P, P, P, P, P, P, P, P]
+    lib.pod_finalize.argtypes = [POINTER(PodConfig)] + [P] * 7 + [c_float] * 4 + [P] * 7 + [P]
+    lib.pod_reg_nll.argtypes = [P, P, P, c_int32, P, P]
+    for name in EXPORTS:
+        if name not in ("pod_abi_version", "pod_nms_scratch_bytes"):
+            getattr(lib, name).restype = ctypes.c_int
+    if lib.pod_abi_version() != POD_ABI_VERSION:
+        raise PodError("ABI version mismatch: library {} vs binding {}".format(lib.pod_abi_version(), POD_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "pod_mi355x kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise PodError("{} failed with code {} ({})".format(what, rc, {-1: "invalid argument", -2: "HIP launch error"}.get(rc, "?")))

@@ -1,0 +1,258 @@
+"""Host side of the MI355X hot path: owns the HBM workspace of one image geometry and enqueues
+the kernel chain K1..K7 (include/pod_mi355x.h) on the current HIP stream.
+
+Nothing here computes on the CPU and nothing synchronises in native-RNG mode: counts stay in
+device words, all buffers are sized for the worst case once (288 GB of HBM: the workspace of the
+BASELINE geometry is ~25 MB), so the whole chain is hipGraph-capturable (`HotPath.capture`).
+The eps-replay parity mode needs one host sync to learn the candidate count n before the
+(1000, n, 4) normal tensor can be drawn -- exactly where the reference draws it
+(probabilistic_inference.py:351-356).
+"""
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+
+MODES = ("standard_nms", "mc_dropout_ensembles", "anchor_statistics", "ensembles", "bayes_od")
+
+
+@dataclass
+class PathParams:
+    """Model attributes / config keys the path reads (defaults of core/setup.py:90-133
+    and detectron2's RetinaNet defaults)."""
+    num_classes: int = 7
+    num_anchors: int = 9
+    topk_candidates: int = 1000          # model.test_topk_candidates (PI:300)
+    score_thresh: float = 0.05           # model.test_score_thresh (PI:304)
+    nms_thresh: float = 0.5              # model.test_nms_thresh
+    max_detections: int = 100            # model.max_detections_per_image
+    cls_var_num_samples: int = 10        # model.cls_var_num_samples (PI:294)
+    prop_num_samples: int = 1000         # hard-coded at PI:355
+    affinity_thresh: float = 0.9         # PROBABILISTIC_INFERENCE.AFFINITY_THRESHOLD
+    merge_quirk: bool = True             # PI:216-222; False = true mean over runs
+    box_weights: Tuple[float, float, float, float] = (1.0, 1.0, 1.0, 1.0)
+    philox_seed: int = 0x5EED
+
+
+@dataclass
+class DeviceDetections:
+    """Fixed-capacity detection buffers in HBM + device count (no host sync until `.count()`)."""
+    image_size: Tuple[int, int]
+    boxes: torch.Tensor          # (max_det, 4) fp32 XYXY in output pixels
+    cov: torch.Tensor            # (max_det, 4, 4)
+    scores: torch.Tensor         # (max_det,)
+    classes: torch.Tensor        # (max_det,) int32
+    probs: torch.Tensor          # (max_det, K)
+    records: torch.Tensor        # (max_det, 6 + K + 16) fixed-stride JSON payload (XYWH box, T cov T^T)
+    n_det: torch.Tensor          # () int32 on device
+    _n: Optional[int] = None
+
+    def count(self) -> int:
+        if self._n is None:
+            self._n = int(self.n_det.item())   # the one device->host sync of an image
+        return self._n
+
+
+class HotPath:
+    """Workspace + launcher for one (level geometry, head configuration)."""
+
+    def __init__(self, shapes: Sequence[Tuple[int, int]], anchors: Sequence[torch.Tensor], params: PathParams,
+                 n_runs: int = 1, has_cls_var: bool = False, cov_dims: int = 0, device="cuda"):
+        self.lib = hip.load()
+        self.p = params
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.shapes = [tuple(s) for s in shapes]
+        self.L = len(self.shapes)
+        self.n_runs, self.has_cls_var, self.cov_dims = int(n_runs), bool(has_cls_var), int(cov_dims)
+        A, K = params.num_anchors, params.num_classes
+        if self.L > hip.POD_MAX_LEVELS or K > hip.POD_MAX_CLASSES - 1 or self.n_runs > hip.POD_MAX_RUNS:
+            raise hip.PodError("unsupported geometry: levels={} classes={} runs={}".format(self.L, K, self.n_runs))
+        self.level_R = [h * w * A for h, w in self.shapes]
+        self.anchor_base = [0]
+        for r in self.level_R[:-1]:
+            self.anchor_base.append(self.anchor_base[-1] + r)
+        self.R = sum(self.level_R)
+        self.n_cap = self.L * params.topk_candidates
+        if params.topk_candidates > hip.POD_MAX_TOPK or self.n_cap > hip.POD_MAX_CANDIDATES:
+            raise hip.PodError("topk_candidates={} x {} levels exceeds the kernel capacity".format(params.topk_candidates, self.L))
+        dev = self.device
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        self.anchors = torch.cat([a.to(dev, torch.float32) for a in anchors]).contiguous()
+        assert self.anchors.shape == (self.R, 4)
+        D = self.cov_dims
+        # K1 outputs
+        merged = self.n_runs > 1
+        self.mean_cls = f32(self.R * K) if merged else None
+        self.mean_cls_var = f32(self.R * K) if merged and has_cls_var else None
+        self.mean_delta = f32(self.R * 4) if merged else None
+        self.mean_reg_var = f32(self.R * D) if merged and D > 0 else None
+        self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
+        self.counters = torch.zeros(hip.POD_MAX_LEVELS + 8, dtype=torch.int32, device=dev)   # [0:L] cand_count
+        self.cand_count = self.counters[: self.L]
+        # K2 outputs
+        self.sel_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)
+        self.sel_count = i32(self.L)
+        n = self.n_cap
+        self.n_total = i32(1)
+        self.cand_anchor_idx, self.cand_level, self.cand_class = i32(n), i32(n), i32(n)
+        self.cand_score, self.cand_probs = f32(n), f32(n, K)
+        self.cand_delta, self.cand_anchor = f32(n, 4), f32(n, 4)
+        self.cand_reg_var = f32(n, max(D, 1))
+        self.cand_run_delta = f32(n, self.n_runs, 4) if merged else None
+        # K3 outputs
+        self.boxes, self.cov = f32(n, 4), f32(n, 4, 4)
+        # K4
+        self.keep, self.n_keep = i32(hip.POD_MAX_DETECTIONS), i32(1)
+        self.nms_scratch = torch.empty(self.lib.pod_nms_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        # K5/K6 outputs
+        md = hip.POD_MAX_DETECTIONS
+        self.m_boxes, self.m_cov, self.m_scores = f32(md, 4), f32(md, 4, 4), f32(md)
+        self.m_classes, self.m_probs = i32(md), f32(md, K)
+        self.cfg = self._make_cfg()
+        self._levels_t = hip.PodLevel * self.L
+
+    # ------------------------------------------------------------------------------------------
+    def _make_cfg(self) -> hip.PodConfig:
+        p = self.p
+        c = hip.PodConfig()
+        c.n_levels, c.n_runs, c.num_anchors, c.num_classes = self.L, self.n_runs, p.num_anchors, p.num_classes
+        c.cov_dims, c.has_cls_var, c.merge_quirk = self.cov_dims, int(self.has_cls_var), int(p.merge_quirk)
+        c.cls_samples, c.prop_samples, c.topk, c.max_detections = p.cls_var_num_samples, p.prop_num_samples, p.topk_candidates, p.max_detections
+        c.score_thresh, c.nms_thresh, c.affinity_thresh = p.score_thresh, p.nms_thresh, p.affinity_thresh
+        for i in range(4):
+            c.box_weights[i] = p.box_weights[i]
+        c.philox_seed = p.philox_seed
+        return c
+
+    def _levels(self, cls, delta, cls_var, reg_var, eps_cls):
+        A, K, D = self.p.num_anchors, self.p.num_classes, self.cov_dims
+        arr = self._levels_t()
+        for l, (h, w) in enumerate(self.shapes):
+            for name, t, c in (("cls", cls[l], K), ("delta", delta[l], 4)):
+                assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n_runs, A * c, h, w), \
+                    "{}[{}]: expected contiguous fp32 {}, got {} {}".format(name, l, (self.n_runs, A * c, h, w), t.dtype, tuple(t.shape))
+            lv = arr[l]
+            lv.cls, lv.delta = cls[l].data_ptr(), delta[l].data_ptr()
+            lv.run_stride_cls, lv.run_stride_delta = A * K * h * w, A * 4 * h * w
+            lv.cls_var = lv.reg_var = lv.eps_cls = None
+            lv.run_stride_reg = 0
+            if self.has_cls_var:
+                assert tuple(cls_var[l].shape) == (self.n_runs, A * K, h, w) and cls_var[l].is_contiguous()
+                lv.cls_var = cls_var[l].data_ptr()
+            if D > 0:
+                assert tuple(reg_var[l].shape) == (self.n_runs, A * D, h, w) and reg_var[l].is_contiguous()
+                lv.reg_var = reg_var[l].data_ptr()
+                lv.run_stride_reg = A * D * h * w
+            if eps_cls is not None:
+                e = eps_cls[l]
+                assert tuple(e.shape) == (self.p.cls_var_num_samples, h * w * A, K) and e.is_contiguous() and e.device == self.device
+                lv.eps_cls = e.data_ptr()
+            lv.H, lv.W, lv.anchor_base = h, w, self.anchor_base[l]
+        return arr
+
+    # ------------------------------------------------------------------------------------------
+    def candidates(self, cls, delta, cls_var=None, reg_var=None, eps_cls=None, write_merged: bool = True):
+        """K1 + K2 + K2b: dense tensors -> level-concatenated candidate arrays (device-resident)."""
+        lib, cfg, st = self.lib, self.cfg, hip.current_stream()
+        lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
+        self._lv_keepalive = (lv, eps_cls)
+        P = hip.ptr
+        hip.check(lib.pod_reset_counters(P(self.counters), self.L, st), "pod_reset_counters")
+        wm = write_merged and self.n_runs > 1
+        hip.check(lib.pod_mc_merge_score(cfg, lv, P(self.mean_cls) if wm else None, P(self.mean_cls_var) if wm else None,
+                                         P(self.mean_delta) if wm else None, P(self.mean_reg_var) if wm else None,
+                                         P(self.cand_keys), P(self.counters), st), "pod_mc_merge_score")
+        hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.counters), P(self.sel_keys), P(self.sel_count), st),
+                  "pod_level_topk")
+        hip.check(lib.pod_gather_candidates(cfg, lv, P(self.anchors), P(self.sel_keys), P(self.sel_count),
+                                            P(self.cand_anchor_idx), P(self.cand_level), P(self.cand_score), P(self.cand_class),
+                                            P(self.cand_probs), P(self.cand_delta), P(self.cand_reg_var) if self.cov_dims else None,
+                                            P(self.cand_anchor), P(self.cand_run_delta), P(self.n_total), st),
+                  "pod_gather_candidates")
+        return lv
+
+    def decode(self, lv, eps_prop: Optional[torch.Tensor] = None):
+        """K3: candidate boxes + covariances."""
+        P = hip.ptr
+        n_replay = 0
+        if eps_prop is not None:
+            assert eps_prop.dim() == 3 and eps_prop.shape[0] == self.p.prop_num_samples and eps_prop.shape[2] == 4
+            assert eps_prop.is_contiguous() and eps_prop.device == self.device
+            n_replay = int(eps_prop.shape[1])
+            self._eps_keepalive = eps_prop
+        hip.check(self.lib.pod_decode_cov(self.cfg, lv, P(self.n_total), self.n_cap, P(self.cand_delta),
+                                          P(self.cand_reg_var) if self.cov_dims else None, P(self.cand_anchor),
+                                          P(self.cand_run_delta), P(self.cand_anchor_idx), P(self.cand_level),
+                                          P(eps_prop), n_replay, P(self.boxes), P(self.cov), hip.current_stream()),
+                  "pod_decode_cov")
+
+    @property
+    def has_covariance(self) -> bool:
+        """False reproduces the reference's `all_predicted_boxes_covariance = []` (PI:381)."""
+        return self.cov_dims > 0 or self.n_runs > 1
+
+    def postprocess(self, mode: str, image_size, out_size, box_merge_mode: str = "bayesian_inference",
+                    cls_merge_mode: str = "max_score") -> DeviceDetections:
+        """K4 (+K5/K6) + K7."""
+        if mode not in MODES:
+            raise ValueError("Invalid inference mode {}.".format(mode))   # PI:100-103
+        lib, cfg, st, P = self.lib, self.cfg, hip.current_stream(), hip.ptr
+        K, md = self.p.num_classes, hip.POD_MAX_DETECTIONS
+        dev = self.device
+        hip.check(lib.pod_nms_cluster(cfg, P(self.n_total), self.n_cap, P(self.boxes), P(self.cand_score), P(self.cand_class),
+                                      P(self.keep), P(self.n_keep), P(self.nms_scratch), st), "pod_nms_cluster")
+        cov_in = self.cov if self.has_covariance else None
+        if mode == "bayes_od":
+            if cov_in is None:
+                raise hip.PodError("bayes_od needs box covariances (a reg_var head or MC runs)")
+            bm = {"bayesian_inference": 0, "covariance_intersection": 1}[box_merge_mode]
+            cm = {"max_score": 0, "bayesian_inference": 1}[cls_merge_mode]
+            hip.check(lib.pod_bayes_fuse(cfg, P(self.n_total), P(self.keep), P(self.n_keep), P(self.boxes), P(self.cov),
+                                         P(self.cand_score), P(self.cand_class), P(self.cand_probs), bm, cm, P(self.m_boxes),
+                                         P(self.m_cov), P(self.m_scores), P(self.m_classes), P(self.m_probs), st), "pod_bayes_fuse")
+            src = (None, self.m_boxes, self.m_cov, self.m_scores, self.m_classes, self.m_probs)
+        elif mode == "anchor_statistics":
+            hip.check(lib.pod_anchor_stats_merge(cfg, P(self.n_total), P(self.keep), P(self.n_keep), P(self.boxes), P(cov_in),
+                                                 P(self.cand_class), P(self.cand_probs), P(self.m_boxes), P(self.m_cov),
+                                                 P(self.m_scores), P(self.m_classes), P(self.m_probs), st), "pod_anchor_stats_merge")
+            src = (None, self.m_boxes, self.m_cov, self.m_scores, self.m_classes, self.m_probs)
+        else:   # standard NMS (also the pre-NMS MC-dropout / ensemble modes): gather through keep
+            src = (self.keep, self.boxes, cov_in, self.cand_score, self.cand_class, self.cand_probs)
+        keep, b, c, s, cl, pr = src
+        out = DeviceDetections(
+            (int(out_size[0]), int(out_size[1])),
+            torch.empty((md, 4), dtype=torch.float32, device=dev), torch.empty((md, 4, 4), dtype=torch.float32, device=dev),
+            torch.empty((md,), dtype=torch.float32, device=dev), torch.empty((md,), dtype=torch.int32, device=dev),
+            torch.empty((md, K), dtype=torch.float32, device=dev), torch.empty((md, 6 + K + 16), dtype=torch.float32, device=dev),
+            torch.empty((), dtype=torch.int32, device=dev))
+        sx, sy = out_size[1] / image_size[1], out_size[0] / image_size[0]   # IU:394-396
+        hip.check(lib.pod_finalize(cfg, P(keep), P(self.n_keep), P(b), P(c), P(s), P(cl), P(pr), sx, sy,
+                                   float(out_size[0]), float(out_size[1]), P(out.boxes), P(out.cov), P(out.scores),
+                                   P(out.classes), P(out.probs), P(out.records), P(out.n_det), st), "pod_finalize")
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def run(self, mode: str, cls, delta, cls_var=None, reg_var=None, *, image_size, out_size,
+            eps_fn: Optional[Callable] = None, box_merge_mode: str = "bayesian_inference",
+            cls_merge_mode: str = "max_score", write_merged: bool = True) -> DeviceDetections:
+        """predictor(input_im) minus the conv net: dense head tensors -> detections.
+
+        eps_fn=None  : native mode, in-kernel Philox4x32-10, fully asynchronous.
+        eps_fn=callable(shape)->CPU tensor : eps-replay parity mode; draws are requested in the
+          reference's order (one (S_cls, R_l, K) tensor per level, then one (1000, n, 4))."""
+        eps_cls = eps_prop = None
+        if eps_fn is not None and self.has_cls_var:
+            A, K = self.p.num_anchors, self.p.num_classes
+            eps_cls = [eps_fn((self.p.cls_var_num_samples, h * w * A, K)).to(self.device).contiguous() for h, w in self.shapes]
+        lv = self.candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged)
+        if eps_fn is not None and self.cov_dims > 0:
+            n = int(self.n_total.item())
+            if n > 0:
+                eps_prop = eps_fn((self.p.prop_num_samples, n, 4)).to(self.device).contiguous()
+        self.decode(lv, eps_prop)
+        return self.postprocess(mode, image_size, out_size, box_merge_mode, cls_merge_mode)

@@ -113,6 +113,20 @@ class SeededNormals:
         return self.randn(*tuple(shape))
 
 
+def _exp(x: torch.Tensor) -> torch.Tensor:
+    """exp/log through float64 numpy on the CPU: torch's fp32 SIMD exp/log (Sleef) differ in the last
+    bit between AVX2 and AVX-512 hosts, which would break seed-only golden fixtures."""
+    if x.device.type != "cpu":
+        return torch.exp(x)
+    return torch.from_numpy(np.exp(x.double().numpy())).float()
+
+
+def _log(x: torch.Tensor) -> torch.Tensor:
+    if x.device.type != "cpu":
+        return torch.log(x)
+    return torch.from_numpy(np.log(x.double().numpy())).float()
+
+
 def _iou_rows(boxes: torch.Tensor, anchors: torch.Tensor) -> torch.Tensor:
     wh = torch.min(boxes[:, None, 2:], anchors[:, 2:]) - torch.max(boxes[:, None, :2], anchors[:, :2])
     inter = wh.clamp_(min=0).prod(dim=2)
@@ -126,7 +140,7 @@ def _deltas(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
     tw, th = dst[:, 2] - dst[:, 0], dst[:, 3] - dst[:, 1]
     tx, ty = dst[:, 0] + 0.5 * tw, dst[:, 1] + 0.5 * th
-    return torch.stack(((tx - sx) / sw, (ty - sy) / sh, torch.log(tw / sw), torch.log(th / sh)), dim=1)
+    return torch.stack(((tx - sx) / sw, (ty - sy) / sh, _log(tw / sw), _log(th / sh)), dim=1)
 
 
 def planted_head_outputs(image_size: Tuple[int, int], num_runs: int = 1, *, seed: int = 0, num_boxes: int = 24,
@@ -154,8 +168,8 @@ def planted_head_outputs(image_size: Tuple[int, int], num_runs: int = 1, *, seed
     boxes = classes = None
     if mode == "planted" and num_boxes > 0:
         side_lo, side_hi = math.log(24.0), math.log(min(400.0, 0.9 * min(H, W)))
-        bw = torch.exp(side_lo + (side_hi - side_lo) * rand(num_boxes))
-        bh = torch.exp(side_lo + (side_hi - side_lo) * rand(num_boxes))
+        bw = _exp(side_lo + (side_hi - side_lo) * rand(num_boxes))
+        bh = _exp(side_lo + (side_hi - side_lo) * rand(num_boxes))
         bx = rand(num_boxes) * (W - bw)
         by = rand(num_boxes) * (H - bh)
         boxes = torch.stack((bx, by, bx + bw, by + bh), dim=1)

@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/pod_mi355x.h declares; the ctypes mirrors have the C layout.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from pod_compare_amd import build, hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pod_mi355x.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(pod_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    return build.build_library()
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(hip.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.pod_abi_version() == hip.POD_ABI_VERSION
+
+
+def test_binding_loads(lib_path):
+    lib = hip.load()
+    assert lib.pod_nms_scratch_bytes(5000) >= 5000 * 24
+    assert lib.pod_nms_scratch_bytes(0) == 0
+
+
+def test_struct_layout_matches_c(lib_path, tmp_path):
+    """sizeof/offsetof of the ctypes mirrors against the C header (compiled with gcc)."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pod_mi355x.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PodLevel), offsetof(PodLevel, run_stride_cls),'
+                   ' offsetof(PodLevel, H), sizeof(PodConfig), offsetof(PodConfig, score_thresh), offsetof(PodConfig, box_weights),'
+                   ' offsetof(PodConfig, philox_seed)); return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(hip.PodLevel), hip.PodLevel.run_stride_cls.offset, hip.PodLevel.H.offset, ctypes.sizeof(hip.PodConfig),
+            hip.PodConfig.score_thresh.offset, hip.PodConfig.box_weights.offset, hip.PodConfig.philox_seed.offset]
+    assert got == want
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
+    """Argument validation happens on the host before any launch: safe to exercise on CPU."""
+    lib = hip.load()
+    cfg = hip.PodConfig()
+    assert lib.pod_reset_counters(None, 4, None) == -1
+    assert lib.pod_level_topk(cfg, None, None, None, None, None, None) == -1
+    assert lib.pod_reg_nll(None, None, None, 3, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setenv("POD_MI355X_LIB", "/nonexistent/libpod_mi355x.so")
+    monkeypatch.setattr(hip, "_lib", None)
+    with pytest.raises(hip.PodError):
+        hip.load()
