@@ -1,0 +1,261 @@
+"""ResNet-50-FPN + probabilistic RetinaNet head on PyTorch-ROCm (row a1 of SURVEY 8a).
+
+The reference model (probabilistic_modeling/probabilistic_retinanet.py) subclasses detectron2's
+RetinaNet, which is not installed; this is a from-scratch statement of the same architecture in
+plain torch (convolutions run in MIOpen -- they are not part of the hand-written hot path):
+
+  backbone  detectron2 `build_retinanet_resnet_fpn_backbone`: ResNet-50 (FrozenBN, stride in the
+            1x1 conv of each bottleneck), FPN on res3..res5 (256 ch) + LastLevelP6P7 from res5
+            (Base-RetinaNet.yaml:3-10).
+  head      ProbabilisticRetinaNetHead, PR:370-537: two 4 x (conv3x3 256->256, ReLU, Dropout p)
+            subnets; cls_score 256->A*K (bias -log(99), PR:454-455), bbox_pred 256->A*4,
+            cls_var 256->A*K (bias -10, PR:458-470), bbox_cov 256->A*D (std 1e-4, PR:473-484).
+
+MI355X-first differences from the reference's forward (PR:95-108, PR:486-537), numerically neutral:
+  * MC-dropout runs are batched along the batch dimension instead of replicating python lists of
+    feature maps N times (PR:104-106); outputs stay NCHW `(N, A*C, H, W)` -- exactly the layout
+    kernel K1 streams -- so `permute_to_N_HWA_K` (PR:343-349) never runs;
+  * the first conv+ReLU of each subnet sees the same input in every run (dropout only follows it),
+    so it is evaluated once and broadcast;
+  * in MC mode the mean and variance branches still use independent dropout draws (SURVEY Q2:
+    the reference evaluates each subnet twice, PR:518-523); without dropout the two evaluations are
+    identical and the trunk is shared (SURVEY f-4);
+  * dropout is enabled by a flag instead of `model.train()` (PI:53-56).
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import anchors as _anchors
+from .synthetic import HeadOutputs
+
+PIXEL_MEAN_BGR = (103.530, 116.280, 123.675)   # detectron2 defaults used by the BDD configs
+PIXEL_STD = (1.0, 1.0, 1.0)
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm with fixed statistics and affine terms (detectron2 FrozenBatchNorm2d)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+def _conv_bn(cin, cout, k, stride=1, padding=0):
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
+    nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill
+    return nn.Sequential(conv, FrozenBatchNorm2d(cout))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cout, mid, stride):
+        super().__init__()
+        self.shortcut = _conv_bn(cin, cout, 1, stride) if cin != cout else None
+        self.conv1 = _conv_bn(cin, mid, 1, stride)          # STRIDE_IN_1X1 = True (MSRA R-50)
+        self.conv2 = _conv_bn(mid, mid, 3, 1, 1)
+        self.conv3 = _conv_bn(mid, cout, 1)
+
+    def forward(self, x):
+        out = F.relu_(self.conv1(x))
+        out = F.relu_(self.conv2(out))
+        out = self.conv3(out)
+        sc = x if self.shortcut is None else self.shortcut(x)
+        return F.relu_(out + sc)
+
+
+class ResNet50(nn.Module):
+    """res2..res5 of ResNet-50; returns res3, res4, res5 (strides 8, 16, 32)."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = _conv_bn(3, 64, 7, 2, 3)
+        cfg = ((3, 64, 256, 1), (4, 128, 512, 2), (6, 256, 1024, 2), (3, 512, 2048, 2))
+        stages, cin = [], 64
+        for blocks, mid, cout, stride in cfg:
+            layers = []
+            for b in range(blocks):
+                layers.append(Bottleneck(cin, cout, mid, stride if b == 0 else 1))
+                cin = cout
+            stages.append(nn.Sequential(*layers))
+        self.res2, self.res3, self.res4, self.res5 = stages
+
+    def forward(self, x):
+        x = F.relu_(self.stem(x))
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = self.res2(x)
+        c3 = self.res3(x)
+        c4 = self.res4(c3)
+        c5 = self.res5(c4)
+        return c3, c4, c5
+
+
+class FPN(nn.Module):
+    """detectron2 FPN (sum fusion, no norm) on res3..res5 + LastLevelP6P7(in_feature='res5')."""
+
+    def __init__(self, in_channels=(512, 1024, 2048), out_channels=256):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels)
+        self.output = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+        self.p6 = nn.Conv2d(in_channels[-1], out_channels, 3, stride=2, padding=1)
+        self.p7 = nn.Conv2d(out_channels, out_channels, 3, stride=2, padding=1)
+        for m in list(self.lateral) + list(self.output) + [self.p6, self.p7]:
+            nn.init.kaiming_uniform_(m.weight, a=1)      # c2_xavier_fill
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, feats):
+        c3, c4, c5 = feats
+        l5 = self.lateral[2](c5)
+        l4 = self.lateral[1](c4) + F.interpolate(l5, size=c4.shape[-2:], mode="nearest")
+        l3 = self.lateral[0](c3) + F.interpolate(l4, size=c3.shape[-2:], mode="nearest")
+        p3, p4, p5 = self.output[0](l3), self.output[1](l4), self.output[2](l5)
+        p6 = self.p6(c5)
+        p7 = self.p7(F.relu(p6))
+        return [p3, p4, p5, p6, p7]
+
+
+class ProbabilisticRetinaNetHead(nn.Module):
+    """PR:365-537."""
+
+    def __init__(self, in_channels=256, num_anchors=9, num_classes=7, num_convs=4, prior_prob=0.01,
+                 dropout_rate=0.0, compute_cls_var=False, compute_bbox_cov=False, bbox_cov_dims=4):
+        super().__init__()
+        self.num_anchors, self.num_classes = num_anchors, num_classes
+        self.dropout_rate = float(dropout_rate)
+        self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims = compute_cls_var, compute_bbox_cov, bbox_cov_dims
+        self.cls_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
+        self.bbox_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
+        self.cls_score = nn.Conv2d(in_channels, num_anchors * num_classes, 3, padding=1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, 3, padding=1)
+        for m in list(self.cls_subnet) + list(self.bbox_subnet) + [self.cls_score, self.bbox_pred]:
+            nn.init.normal_(m.weight, mean=0, std=0.01)
+            nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.cls_score.bias, -math.log((1 - prior_prob) / prior_prob))      # PR:454-455
+        self.cls_var = self.bbox_cov = None
+        if compute_cls_var:                                                                    # PR:458-470
+            self.cls_var = nn.Conv2d(in_channels, num_anchors * num_classes, 3, padding=1)
+            nn.init.normal_(self.cls_var.weight, mean=0, std=0.01)
+            nn.init.constant_(self.cls_var.bias, -10.0)
+        if compute_bbox_cov:                                                                   # PR:473-484
+            self.bbox_cov = nn.Conv2d(in_channels, num_anchors * bbox_cov_dims, 3, padding=1)
+            nn.init.normal_(self.bbox_cov.weight, mean=0, std=0.0001)
+            nn.init.constant_(self.bbox_cov.bias, 0)
+
+    def _trunk(self, convs, feature, copies: int, dropout: bool):
+        """`copies` independent evaluations of a subnet, batched on dim 0.  The first conv+ReLU is
+        identical across copies (dropout only follows it) and is computed once."""
+        x = F.relu(convs[0](feature))
+        if not dropout:
+            for conv in convs[1:]:
+                x = F.relu(conv(x))
+            return x                                  # batch 1; shared by every copy
+        x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
+        for conv in convs[1:]:
+            x = F.dropout(F.relu(conv(x)), self.dropout_rate, training=True)
+        return x
+
+    def forward(self, features: List[torch.Tensor], num_runs: int = 1, mc_dropout: bool = False):
+        """features: per-level (1, 256, H, W).  Returns per-level lists of (num_runs, A*C, H, W)."""
+        dropout = mc_dropout and self.dropout_rate > 0.0
+        n = num_runs
+        logits, deltas, logit_vars, delta_covs = [], [], [], []
+        for f in features:
+            cls_copies = n * (2 if self.compute_cls_var else 1)
+            box_copies = n * (2 if self.compute_bbox_cov else 1)
+            tc = self._trunk(self.cls_subnet, f, cls_copies, dropout)
+            tb = self._trunk(self.bbox_subnet, f, box_copies, dropout)
+            if dropout:
+                logits.append(self.cls_score(tc[:n]))
+                deltas.append(self.bbox_pred(tb[:n]))
+                if self.compute_cls_var:
+                    logit_vars.append(self.cls_var(tc[n:]))         # independent dropout draw (Q2)
+                if self.compute_bbox_cov:
+                    delta_covs.append(self.bbox_cov(tb[n:]))
+            else:
+                ex = (lambda t: t.expand(n, -1, -1, -1).contiguous()) if n > 1 else (lambda t: t)
+                logits.append(ex(self.cls_score(tc)))
+                deltas.append(ex(self.bbox_pred(tb)))
+                if self.compute_cls_var:
+                    logit_vars.append(ex(self.cls_var(tc)))
+                if self.compute_bbox_cov:
+                    delta_covs.append(ex(self.bbox_cov(tb)))
+        return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
+
+
+class ProbabilisticRetinaNet(nn.Module):
+    """PR:20-166 (inference side only; `losses` PR:168-333 is training and out of scope)."""
+
+    def __init__(self, num_classes=7, dropout_rate=0.0, cls_var_loss="none", cls_var_num_samples=3,
+                 bbox_cov_loss="none", bbox_cov_type="diagonal", test_score_thresh=0.05, test_topk_candidates=1000,
+                 test_nms_thresh=0.5, max_detections_per_image=100, min_size_test=800, max_size_test=1333):
+        super().__init__()
+        self.num_classes = num_classes
+        self.compute_cls_var = cls_var_loss != "none"                  # PR:29-30
+        self.cls_var_num_samples = cls_var_num_samples
+        self.compute_bbox_cov = bbox_cov_loss != "none"                # PR:33-34
+        self.bbox_cov_dims = 4 if bbox_cov_type == "diagonal" else 10  # PR:37-44
+        self.dropout_rate = dropout_rate
+        self.use_dropout = dropout_rate != 0.0
+        self.test_score_thresh, self.test_topk_candidates = test_score_thresh, test_topk_candidates
+        self.test_nms_thresh, self.max_detections_per_image = test_nms_thresh, max_detections_per_image
+        self.min_size_test, self.max_size_test = min_size_test, max_size_test
+        self.input_format = "BGR"
+        self.in_features = ["p3", "p4", "p5", "p6", "p7"]
+        self.num_anchors = len(_anchors.ANCHOR_SIZES[0]) * len(_anchors.ASPECT_RATIOS)
+        self.bottom_up = ResNet50()
+        self.fpn = FPN()
+        self.head = ProbabilisticRetinaNetHead(256, self.num_anchors, num_classes, 4, 0.01, dropout_rate,
+                                               self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims)
+        self.register_buffer("pixel_mean", torch.tensor(PIXEL_MEAN_BGR).view(3, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(3, 1, 1), persistent=False)
+        self._anchor_cache: Dict[Tuple[int, int], List[torch.Tensor]] = {}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, image: torch.Tensor) -> torch.Tensor:
+        """(3,H,W) BGR uint8/float -> normalised, zero-padded (1,3,H',W') with H',W' % 32 == 0 (PR:96)."""
+        x = (image.to(self.device, torch.float32) - self.pixel_mean) / self.pixel_std
+        h, w = x.shape[-2:]
+        ph, pw = _anchors.padded_size(h, w)
+        return F.pad(x, (0, pw - w, 0, ph - h)).unsqueeze(0)
+
+    def anchors_for(self, padded_hw: Tuple[int, int]) -> List[torch.Tensor]:
+        if padded_hw not in self._anchor_cache:
+            shapes = _anchors.level_shapes(*padded_hw)
+            self._anchor_cache[padded_hw] = _anchors.grid_anchors(shapes, device=self.device)
+        return self._anchor_cache[padded_hw]
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1) -> HeadOutputs:
+        """Raw anchor-wise output (`return_anchorwise_output=True`, PR:352-361) in NCHW plane layout.
+        num_mc_dropout_runs > 1 batches that many dropout-perturbed head evaluations (PR:103-108)."""
+        x = self.preprocess_image(image)
+        feats = self.fpn(self.bottom_up(x))
+        n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
+        cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=n > 1 and self.use_dropout)
+        padded = tuple(x.shape[-2:])
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        return HeadOutputs(cls, delta, cls_var, reg_var, self.anchors_for(padded), shapes, self.num_anchors,
+                           self.num_classes, tuple(image.shape[-2:]))
+
+
+def resize_test_image(image: torch.Tensor, min_size: int = 800, max_size: int = 1333) -> torch.Tensor:
+    """detectron2 ResizeShortestEdge test transform (apply_net.py:83), bilinear, on the device."""
+    h, w = image.shape[-2:]
+    nh, nw = _anchors.resize_shortest_edge(h, w, min_size, max_size)
+    if (nh, nw) == (h, w):
+        return image
+    return F.interpolate(image.unsqueeze(0).float(), size=(nh, nw), mode="bilinear", align_corners=False).squeeze(0)

@@ -24,20 +24,24 @@ def make_path(ho: synthetic.HeadOutputs, topk=1000, quirk=True) -> hotpath.HotPa
                            cov_dims=cov_dims, device="cuda")
 
 
-def canonical_tie_order(idx: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+def canonical_perm(idx: torch.Tensor, score: torch.Tensor, counts) -> torch.Tensor:
     """torch.topk leaves the order of EXACTLY equal fp32 scores unspecified; this build's
-    stated convention is lower anchor index first.  Re-order the reference sequence inside groups of
-    bit-equal scores accordingly; everything else must match position by position."""
-    idx = idx.clone()
-    i, n = 0, idx.numel()
-    while i < n:
-        j = i + 1
-        while j < n and score[j] == score[i]:
-            j += 1
-        if j - i > 1:
-            idx[i:j] = torch.sort(idx[i:j])[0]
-        i = j
-    return idx
+    stated convention is lower anchor index first.  Returns `perm` such that ref[perm] lists the
+    reference's candidates in that convention: a permutation inside groups of bit-equal scores of one
+    level, the identity everywhere else."""
+    perm = torch.arange(idx.numel())
+    off = 0
+    for cnt in counts:
+        i = off
+        while i < off + cnt:
+            j = i + 1
+            while j < off + cnt and score[j] == score[i]:
+                j += 1
+            if j - i > 1:
+                perm[i:j] = i + torch.sort(idx[i:j])[1]
+            i = j
+        off += cnt
+    return perm
 
 
 def run_hip(g: Golden):
@@ -73,22 +77,24 @@ def test_hip_indices_bit_exact(path):
     hp, det = run_hip(g)
     n = int(hp.n_total.item())
     counts = hp.sel_count.cpu().tolist()
-    idx = hp.cand_anchor_idx[:n].cpu().long()
-    off = 0
-    ref_score = g.t("aw0_prob")
-    for lvl, cnt in enumerate(counts):
-        ref_idx = canonical_tie_order(g.t("topk_%d" % lvl)[:cnt], ref_score[off:off + cnt])
-        assert torch.equal(idx[off:off + cnt], ref_idx), "level %d anchor indices" % lvl
-        off += cnt
     assert n == g.t("aw0_boxes").shape[0]
-    assert torch.equal(hp.cand_class[:n].cpu().long(), g.t("aw0_cls"))
-    assert_close(hp.cand_score[:n].cpu(), g.t("aw0_prob"), "cand scores", rtol=2e-6, atol=1e-7)
-    assert_close(hp.cand_probs[:n].cpu(), g.t("aw0_pvec"), "cand probs", rtol=2e-6, atol=1e-7)
-    assert_close(hp.boxes[:n].cpu(), g.t("aw0_boxes"), "candidate boxes")
+    ref_top = torch.cat([g.t("topk_%d" % lvl)[:cnt] for lvl, cnt in enumerate(counts)])
+    perm = canonical_perm(ref_top, g.t("aw0_prob"), counts)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    assert torch.equal(hp.cand_anchor_idx[:n].cpu().long(), ref_top[perm]), "top-k anchor index sequence"
+    assert torch.equal(hp.cand_class[:n].cpu().long(), g.t("aw0_cls")[perm])
+    assert_close(hp.cand_score[:n].cpu(), g.t("aw0_prob")[perm], "cand scores", rtol=2e-6, atol=1e-7)
+    assert_close(hp.cand_probs[:n].cpu(), g.t("aw0_pvec")[perm], "cand probs", rtol=2e-6, atol=1e-7)
+    # replayed eps columns belong to candidate POSITIONS, so members of a re-ordered tie group saw each
+    # other's normal draws: compare boxes/covariances on the positions the convention left in place
+    same = perm == torch.arange(n)
+    assert int(same.sum()) >= n - 16
+    assert_close(hp.boxes[:n].cpu()[same], g.t("aw0_boxes")[same], "candidate boxes")
     if g.t("aw0_cov").numel():
-        assert_close(hp.cov[:n].cpu(), g.t("aw0_cov"), "candidate cov")
+        assert_close(hp.cov[:n].cpu()[same], g.t("aw0_cov")[same], "candidate cov")
     nk = int(hp.n_keep.item())
-    ref_keep = g.t("nms_keep_0")[:100]
+    ref_keep = inv[g.t("nms_keep_0")[:100]]
     assert torch.equal(hp.keep[:nk].cpu().long(), ref_keep)
 
 
