@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--k1-traffic-bytes", type=float, default=None,
+                    help="HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): 2*FETCH_SIZE + WRITE_SIZE")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,25 +159,34 @@ def main():
     lib, P = hp.lib, hotpath.hip.ptr
     lvs = [hp._levels(h.cls, h.delta, h.cls_var, h.reg_var, None) for h in heads]
     st = hotpath.hip.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    prune = spec["cls_var"]   # native RNG + variance head: K1 runs in prune mode, exactly as in the timed steps
+
+    def k1_call(j):
+        hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta),
+                                                 P(hp.mean_reg_var), P(hp.cand_keys), P(hp.cand_count),
+                                                 P(hp.maybe_bits) if prune else None, st),
+                          "pod_mc_merge_score")
 
     def k1_launch(j):
-        lib.pod_reset_counters(P(hp.counters), hp.L, st)
-        hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta),
-                                                 P(hp.mean_reg_var), P(hp.cand_keys), P(hp.counters), st), "pod_mc_merge_score")
+        lib.pod_reset_counters(P(hp.counters), 8, st)
+        k1_call(j)
 
     for j in range(3):
         k1_launch(j)
     torch.cuda.synchronize()
-    k1_ms = []
+    # HIP events on the launch stream.  The host must stay AHEAD of the device, otherwise the start event
+    # fires before the kernel has even been enqueued and the pair measures host launch latency: park the
+    # stream behind a ~1 ms spin kernel, enqueue every (event, K1, event) triple, then synchronise once.
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k1_iters)]
+    torch.cuda._sleep(3_000_000)
     for j in range(k1_iters):
-        lib.pod_reset_counters(P(hp.counters), hp.L, st)
-        e0.record()
-        hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta),
-                                                 P(hp.mean_reg_var), P(hp.cand_keys), P(hp.counters), st), "pod_mc_merge_score")
-        e1.record()
-        e1.synchronize()
-        k1_ms.append(e0.elapsed_time(e1))
+        lib.pod_reset_counters(P(hp.counters), 8, st)
+        evs[j][0].record()
+        k1_call(j)
+        evs[j][1].record()
+    torch.cuda.synchronize()
+    k1_ms = [a.elapsed_time(b) for a, b in evs]
     k1_ms.sort()
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
     k1_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk)
@@ -191,7 +202,7 @@ def main():
                    "images_per_gpu_step": 1, "parallelism": "image-sharded dp%d" % world, "rng": "in-kernel Philox4x32-10"},
         "hot_path_ms_per_image": hp_ms, "mean_detections": n_det_mean,
         "roofline": {"kernel": "k1_mc_merge_score", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": k1_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": args.k1_traffic_bytes, "algorithmic_bytes": k1_bytes,
                      "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_ms[0],
                      "survey_bytes_4RC(N+1)": 4 * R * (params.num_classes * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)},
     }

@@ -19,6 +19,8 @@
 //   * "box" workgroups: flat element-wise merge of the delta / reg_var planes (pure streaming).
 // ~1.6k workgroups, ~11k waves at BASELINE size (R = 193374, N = 10): every CU holds several
 // waves with >= 16 loads in flight each.  No MFMA: element-wise + reductions.
+#include <stdlib.h>
+
 #include "pod_device.h"
 
 namespace pod {
@@ -32,6 +34,8 @@ struct K1Params {
     uint8_t vec_reg[POD_MAX_LEVELS];
     int32_t n_levels, n_runs, A, K, D, has_cls_var, quirk, cls_samples;
     float score_thresh;
+    float skip_logit;                            // native mode: logit + EPS_MAX*sigma <= skip_logit can never pass the threshold
+    int32_t n_cls_blocks, n_box_blocks, interleave, debug_roles, debug_bits;
     uint64_t seed;
     float* mean_cls;
     float* mean_cls_var;
@@ -39,10 +43,12 @@ struct K1Params {
     float* mean_reg_var;
     uint64_t* cand_keys;
     int32_t* cand_count;
+    uint64_t* maybe_bits;    // prune mode: bitmap of the anchors that MAY pass the threshold (exact superset); scored by K1b
 };
 
-__device__ __forceinline__ float4 ld4(const float* p, int64_t i, int64_t n, bool vec) {
-    if (vec) return *reinterpret_cast<const float4*>(p + i);
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i, int64_t n) {
+    if (VEC) return *reinterpret_cast<const float4*>(p + i);
     float4 v;
     v.x = (i + 0 < n) ? p[i + 0] : 0.0f;
     v.y = (i + 1 < n) ? p[i + 1] : 0.0f;
@@ -50,8 +56,9 @@ __device__ __forceinline__ float4 ld4(const float* p, int64_t i, int64_t n, bool
     v.w = (i + 3 < n) ? p[i + 3] : 0.0f;
     return v;
 }
-__device__ __forceinline__ void st4(float* p, int64_t i, int64_t n, bool vec, float4 v) {
-    if (vec) {
+template <bool VEC>
+__device__ __forceinline__ void st4(float* p, int64_t i, int64_t n, float4 v) {
+    if (VEC) {
         *reinterpret_cast<float4*>(p + i) = v;
         return;
     }
@@ -61,37 +68,141 @@ __device__ __forceinline__ void st4(float* p, int64_t i, int64_t n, bool vec, fl
     if (i + 3 < n) p[i + 3] = v.w;
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-
-// Merge N runs of 4 consecutive floats starting at element `i` of each run (run stride `rs`).
-// Loads are issued in batches of 8 independent 16-B loads; adds follow the reference order.
-__device__ __forceinline__ float4 merge_runs4(const float* base, int64_t rs, int64_t i, int64_t n, bool vec, int n_runs,
-                                             int quirk) {
-    float4 acc = ld4(base, i, n, vec);   // term 0 = run 0
-    if (n_runs == 1) return acc;
-    // remaining terms t = 1..N-1 read run (quirk ? t-1 : t); in quirk mode term 1 re-uses run 0.
-    int t = 1;
-    if (quirk) {
-        acc = add4(acc, acc);
-        t = 2;
-    }
-    for (; t < n_runs; t += 8) {
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int tt = t + j;
-            if (tt < n_runs) v[j] = ld4(base + (int64_t)merge_term_run(tt, quirk) * rs, i, n, vec);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (t + j < n_runs) acc = add4(acc, v[j]);
-    }
-    const float fn = (float)n_runs;
-    return float4{__fdiv_rn(acc.x, fn), __fdiv_rn(acc.y, fn), __fdiv_rn(acc.z, fn), __fdiv_rn(acc.w, fn)};
+__device__ __forceinline__ float4 div4(float4 a, float d) {
+    return float4{__fdiv_rn(a.x, d), __fdiv_rn(a.y, d), __fdiv_rn(a.z, d), __fdiv_rn(a.w, d)};
 }
 
+// CNT straight-line independent 16-B loads of runs run0..run0+CNT-1 of NT tensors (same index and run
+// stride), then the adds in the reference's order.  No branch between the loads: they are all in flight
+// together (CNT * NT * 16 B per lane), which is what keeps HBM busy with ~28 waves per CU.
+template <bool VEC, int NT, int CNT>
+__device__ __forceinline__ void merge_batch(float4* acc, const float* const* base, int64_t rs, int64_t i, int64_t n, int run0) {
+    float4 v[NT][CNT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) v[t][j] = ld4<VEC>(base[t] + (int64_t)(run0 + j) * rs, i, n);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) acc[t] = add4(acc[t], v[t][j]);
+}
+
+// PI:216-222 merge of the N runs of NT tensors at elements [i, i+4).
+//   quirk: acc = x0; acc += x0; acc += x1 .. x_{N-2}; acc /= N      true mean: acc = x0; acc += x1 .. x_{N-1}; acc /= N
+template <bool VEC, int NT, int BATCH>
+__device__ __forceinline__ void merge_runs4(float4* acc, const float* const* base, int64_t rs, int64_t i, int64_t n, int n_runs,
+                                            int quirk) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = ld4<VEC>(base[t], i, n);
+    if (n_runs == 1) return;
+    int r = 1, last = n_runs;          // runs [r, last) are still to be added
+    if (quirk) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = add4(acc[t], acc[t]);
+        last = n_runs - 1;
+    }
+    while (r + BATCH <= last) {
+        merge_batch<VEC, NT, BATCH>(acc, base, rs, i, n, r);
+        r += BATCH;
+    }
+    if (BATCH > 4 && r + 4 <= last) {
+        merge_batch<VEC, NT, 4>(acc, base, rs, i, n, r);
+        r += 4;
+    }
+    if (BATCH > 2 && r + 2 <= last) {
+        merge_batch<VEC, NT, 2>(acc, base, rs, i, n, r);
+        r += 2;
+    }
+    if (r + 1 <= last) {
+        merge_batch<VEC, NT, 1>(acc, base, rs, i, n, r);
+        r += 1;
+    }
+    if (BATCH <= 2 && r < last) merge_batch<VEC, NT, 1>(acc, base, rs, i, n, r);
+    const float fn = (float)n_runs;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = div4(acc[t], fn);
+}
+
+// ---- box role: element-wise merge of delta (role 1) or reg_var (role 2) ---------------------------------
+template <bool VEC, int BATCH>
+__device__ __forceinline__ void box_role(const K1Params& P, const PodLevel& lv, int l, int role, int local_b, int HW) {
+    const bool is_delta = role == 1;
+    const int C = is_delta ? 4 : P.D;
+    const float* src = is_delta ? lv.delta : lv.reg_var;
+    float* dst = (is_delta ? P.mean_delta : P.mean_reg_var);
+    if (dst == nullptr || P.n_runs == 1) return;
+    dst += (int64_t)lv.anchor_base * C;
+    const int64_t rs = is_delta ? lv.run_stride_delta : lv.run_stride_reg;
+    const int64_t n = (int64_t)P.A * C * HW;
+    const int64_t i = ((int64_t)local_b * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 acc[1];
+    const float* base[1] = {src};
+    merge_runs4<VEC, 1, BATCH>(acc, base, rs, i, n, P.n_runs, P.quirk);
+    st4<VEC>(dst, i, n, acc[0]);
+}
+
+// ---- cls role: merged logit / log-variance of class k (= wave id) for 4 cells per lane, then the 4 class
+// probabilities ------------------------------------------------------------------------------------------
+template <bool VEC, int BATCH>
+__device__ __forceinline__ float4 cls_role(const K1Params& P, const PodLevel& lv, int l, int a, int k, int hw0, int HW) {
+    const int K = P.K;
+    const bool has_var = P.has_cls_var != 0;
+    const int64_t plane = (int64_t)(a * K + k) * HW;
+    const int64_t n = plane + HW;   // bound for the scalar tail path
+    const int64_t i = plane + hw0;
+    float4 m[2];
+    m[1] = float4{0.f, 0.f, 0.f, 0.f};
+    const float* base[2] = {lv.cls, lv.cls_var};
+    if (has_var) merge_runs4<VEC, 2, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
+    else merge_runs4<VEC, 1, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
+    if (P.n_runs > 1 && !(P.debug_bits & 2)) {
+        const int64_t off = (int64_t)lv.anchor_base * K;
+        if (P.mean_cls) st4<VEC>(P.mean_cls + off, i, n, m[0]);
+        if (has_var && P.mean_cls_var) st4<VEC>(P.mean_cls_var + off, i, n, m[1]);
+    }
+    const float lg[4] = {m[0].x, m[0].y, m[0].z, m[0].w};
+    const float vr[4] = {m[1].x, m[1].y, m[1].z, m[1].w};
+    float pr[4];
+    if (P.maybe_bits != nullptr) {
+        // Prune mode (native RNG, variance head).  box_muller16() bounds every draw by |eps| < POD_EPS_MAX, so
+        // mean_s sigmoid(logit + eps_s*sigma) <= sigmoid(logit + POD_EPS_MAX*sigma): an (anchor, class) with
+        // logit + POD_EPS_MAX*sigma <= logit(score_thresh) can never become a candidate.  The dense pass only
+        // flags the (few) anchors that may pass; K1b draws the samples for those.  No Philox work here.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool may = (hw0 + j < HW) && !(P.debug_bits & 4) &&
+                             fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit;
+            pr[j] = may ? 1.0f : 0.0f;
+        }
+        return float4{pr[0], pr[1], pr[2], pr[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool live = hw0 + j < HW && !(P.debug_bits & 4);
+        pr[j] = live ? class_prob_cell(lg[j], vr[j], has_var, P.cls_samples, lv.eps_cls, (int64_t)HW * P.A, K, P.A, l, hw0 + j, a, k, P.seed)
+                     : 0.0f;
+    }
+    return float4{pr[0], pr[1], pr[2], pr[3]};
+}
+
+template <int BATCH>
 __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     extern __shared__ __attribute__((aligned(16))) float lds_probs[];   // [K][256]
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (P.interleave) {
+        // groups of 8 (the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so an
+        // odd/even split would park all cls work on four XCDs): physical [16g, 16g+8) -> cls 8g..8g+7,
+        // [16g+8, 16g+16) -> box 8g..8g+7; what is left of the longer list follows in logical order.
+        const int nc = P.n_cls_blocks, nb = P.n_box_blocks, m8 = min(nc, nb) & ~7;
+        if (b < 2 * m8) {
+            const int g = b >> 4, w = b & 15;
+            b = (w < 8) ? g * 8 + w : nc + g * 8 + (w - 8);
+        } else if (b - 2 * m8 < nc - m8) {
+            b -= m8;
+        }
+    }
     const int L = P.n_levels;
     // locate role + level (scalar search over <= 24 segment starts)
     int seg = 0;
@@ -103,25 +214,15 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     const int local_b = b - P.seg_begin[seg];
     const int HW = lv.H * lv.W;
     const int tid = threadIdx.x;
+    if (P.debug_roles == 1 && role != 0) return;   // profiling knob: cls blocks only
+    if (P.debug_roles == 2 && role == 0) return;   // profiling knob: box blocks only
 
     if (role != 0) {
-        // ---- box role: element-wise merge of delta (role 1) or reg_var (role 2) ----------------
-        const bool is_delta = role == 1;
-        const int C = is_delta ? 4 : P.D;
-        const float* src = is_delta ? lv.delta : lv.reg_var;
-        float* dst = (is_delta ? P.mean_delta : P.mean_reg_var);
-        if (dst == nullptr || P.n_runs == 1) return;
-        dst += (int64_t)lv.anchor_base * C;
-        const int64_t rs = is_delta ? lv.run_stride_delta : lv.run_stride_reg;
-        const bool vec = is_delta ? P.vec_delta[l] : P.vec_reg[l];
-        const int64_t n = (int64_t)P.A * C * HW;
-        const int64_t i = ((int64_t)local_b * blockDim.x + tid) * 4;
-        if (i >= n) return;
-        st4(dst, i, n, vec, merge_runs4(src, rs, i, n, vec, P.n_runs, P.quirk));
+        if (role == 1 ? P.vec_delta[l] : P.vec_reg[l]) box_role<true, BATCH>(P, lv, l, role, local_b, HW);
+        else box_role<false, 1>(P, lv, l, role, local_b, HW);
         return;
     }
 
-    // ---- cls role -------------------------------------------------------------------------------
     const int K = P.K;
     const int chunks = P.chunks[l];
     const int a = local_b / chunks;
@@ -129,32 +230,11 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     const int k = tid >> 6;             // wave id = class
     const int lane = tid & 63;
     const int hw0 = chunk * 256 + lane * 4;
-    const bool vec = P.vec_cls[l];
-    const bool has_var = P.has_cls_var != 0;
     float4 prob = float4{0.f, 0.f, 0.f, 0.f};
-    if (hw0 < HW) {
-        const int64_t plane = (int64_t)(a * K + k) * HW;
-        const int64_t n = plane + HW;   // bound for the scalar tail path
-        const int64_t i = plane + hw0;
-        const float4 logit = merge_runs4(lv.cls, lv.run_stride_cls, i, n, vec, P.n_runs, P.quirk);
-        float4 lvar = float4{0.f, 0.f, 0.f, 0.f};
-        if (has_var) lvar = merge_runs4(lv.cls_var, lv.run_stride_cls, i, n, vec, P.n_runs, P.quirk);
-        if (P.n_runs > 1) {
-            const int64_t off = (int64_t)lv.anchor_base * K;
-            if (P.mean_cls) st4(P.mean_cls + off, i, n, vec, logit);
-            if (has_var && P.mean_cls_var) st4(P.mean_cls_var + off, i, n, vec, lvar);
-        }
-        const float lg[4] = {logit.x, logit.y, logit.z, logit.w};
-        const float vr[4] = {lvar.x, lvar.y, lvar.z, lvar.w};
-        float pr[4];
-        const int64_t RL = (int64_t)HW * P.A;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (hw0 + j) * P.A + a;
-            ClsEps eps(lv.eps_cls, RL, K, r, k, P.seed, (uint32_t)(lv.anchor_base + r));
-            pr[j] = (hw0 + j < HW) ? class_prob(lg[j], vr[j], has_var, P.cls_samples, eps) : 0.0f;
-        }
-        prob = float4{pr[0], pr[1], pr[2], pr[3]};
+    if (hw0 < HW) prob = P.vec_cls[l] ? cls_role<true, BATCH>(P, lv, l, a, k, hw0, HW) : cls_role<false, 1>(P, lv, l, a, k, hw0, HW);
+    if (P.debug_bits & 1) {
+        if (prob.x + prob.y + prob.z + prob.w > 3.9f) P.cand_count[l] = 1;   // keep the loads alive
+        return;
     }
     *reinterpret_cast<float4*>(&lds_probs[k * 256 + lane * 4]) = prob;
     __syncthreads();
@@ -168,17 +248,98 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
             const float v = lds_probs[kk * 256 + tid];
             best = (v > best) ? v : best;   // torch.max keeps the first maximum; argmax is re-derived in K2b
         }
-        const bool pass = (hw < HW) && (best > P.score_thresh);
-        const unsigned long long m = __ballot(pass);
-        if (m != 0ull) {
-            const int total = __popcll(m);
-            const int mylane = tid & 63;
-            int base = 0;
-            if (mylane == 0) base = atomicAdd(&P.cand_count[l], total);
-            base = __shfl(base, 0, 64);
-            if (pass) {
-                const int off = __popcll(m & ((1ull << mylane) - 1ull));
-                P.cand_keys[(int64_t)lv.anchor_base + base + off] = make_key(best, hw * P.A + a);
+        if (P.maybe_bits != nullptr) {
+            // prune mode: this wave's 64 flags ARE one bitmap word; plain store, no atomics, every word of
+            // every cls workgroup is written (so the bitmap needs no clearing between images).
+            const unsigned long long m = __ballot((hw < HW) && best > 0.5f);
+            if ((tid & 63) == 0) P.maybe_bits[((int64_t)P.seg_begin[l] + local_b) * 4 + (tid >> 6)] = m;
+        } else {
+            const bool pass = (hw < HW) && (best > P.score_thresh);
+            const unsigned long long m = __ballot(pass);
+            if (m != 0ull) {
+                const int total = __popcll(m);
+                const int mylane = tid & 63;
+                int base = 0;
+                if (mylane == 0) base = atomicAdd(&P.cand_count[l], total);
+                base = __shfl(base, 0, 64);
+                if (pass) P.cand_keys[(int64_t)lv.anchor_base + base + __popcll(m & ((1ull << mylane) - 1ull))] = make_key(best, hw * P.A + a);
+            }
+        }
+    }
+}
+
+// ---- K1b score_maybe ---------------------------------------------------------------------------------------
+// Sparse companion of K1's prune mode: draws the cls_samples normals and evaluates
+// mean_s sigmoid(logit + eps_s*sigma) (PI:289-295) only for the anchors K1 flagged, reading the merged
+// logits / log-variances K1 just wrote (or the single run when N == 1).  Persistent grid, static work split
+// (wavefront w owns bitmap words w, w + nwaves, ...: no work-list atomics); a wavefront scores 64/KP flagged
+// anchors at a time (KP = 8 or 16 lanes per anchor, lane = class), reduces max over the class lanes by
+// butterfly and appends the keys of anchors above the threshold with one aggregated atomic.
+struct K1bParams {
+    PodLevel lv[POD_MAX_LEVELS];
+    int32_t word_begin[POD_MAX_LEVELS + 1];   // 4 bitmap words per cls workgroup of K1; level l = [word_begin[l], word_begin[l+1])
+    int32_t chunks[POD_MAX_LEVELS];
+    int32_t n_levels, n_runs, A, K, cls_samples;
+    float score_thresh;
+    uint64_t seed;
+    const float* mean_cls;
+    const float* mean_cls_var;
+    const uint64_t* maybe_bits;
+    uint64_t* cand_keys;
+    int32_t* cand_count;
+};
+
+template <int KP>
+__global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
+    constexpr int G = 64 / KP;                       // anchors per wavefront per round
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / KP, k = lane % KP;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int L = P.n_levels, K = P.K, A = P.A;
+    const int total_words = P.word_begin[L];
+    for (int w = wave; w < total_words; w += nwaves) {
+        unsigned long long m = P.maybe_bits[w];      // wave-uniform
+        if (m == 0ull) continue;
+        int l = 0;
+        while (l + 1 < L && w >= P.word_begin[l + 1]) ++l;
+        const PodLevel& lv = P.lv[l];
+        const int wl = w - P.word_begin[l];
+        const int blk = wl >> 2;                      // K1 cls workgroup inside the level: a * chunks + chunk
+        const int a = blk / P.chunks[l];
+        const int hw_base = (blk - a * P.chunks[l]) * 256 + (wl & 3) * 64;
+        const int64_t HW = (int64_t)lv.H * lv.W;
+        const float* src = P.n_runs > 1 ? P.mean_cls + (int64_t)lv.anchor_base * K : lv.cls;
+        const float* srcv = P.n_runs > 1 ? P.mean_cls_var + (int64_t)lv.anchor_base * K : lv.cls_var;
+        while (m != 0ull) {
+            // hand the next G set bits to the G lane groups
+            int bit = -1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (m != 0ull) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    if (sub == g) bit = b;
+                }
+            }
+            const bool valid = bit >= 0;
+            const int hw = hw_base + bit;
+            float p = 0.0f;
+            if (valid && k < K) {
+                const int64_t e = (int64_t)(a * K + k) * HW + hw;
+                p = class_prob_cell(src[e], srcv[e], true, P.cls_samples, nullptr, HW * A, K, A, l, hw, a, k, P.seed);
+            }
+            float best = p;
+#pragma unroll
+            for (int o = KP >> 1; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+            const bool emit = valid && k == 0 && best > P.score_thresh;
+            const unsigned long long em = __ballot(emit);
+            if (em != 0ull) {
+                const int leader = __ffsll((long long)em) - 1;
+                int pos = 0;
+                if (lane == leader) pos = atomicAdd(&P.cand_count[l], __popcll(em));
+                pos = __shfl(pos, leader, 64);
+                if (emit) P.cand_keys[(int64_t)lv.anchor_base + pos + __popcll(em & ((1ull << lane) - 1ull))] = make_key(best, hw * A + a);
             }
         }
     }
@@ -198,8 +359,14 @@ extern "C" int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t str
 
 extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, float* mean_cls, float* mean_cls_var,
                                   float* mean_delta, float* mean_reg_var, uint64_t* cand_keys, int32_t* cand_count,
-                                  pod_stream_t stream) {
+                                  uint64_t* maybe_bits, pod_stream_t stream) {
     if (!cfg || !levels || !cand_keys || !cand_count) return POD_E_INVALID;
+    if (maybe_bits) {   // prune mode: native RNG + variance head only, and K1b needs the merged planes
+        if (!cfg->has_cls_var) return POD_E_INVALID;
+        if (cfg->n_runs > 1 && (!mean_cls || !mean_cls_var)) return POD_E_INVALID;
+        for (int l = 0; l < cfg->n_levels && l < POD_MAX_LEVELS; ++l)
+            if (levels[l].eps_cls) return POD_E_INVALID;
+    }
     const int L = cfg->n_levels, K = cfg->num_classes, A = cfg->num_anchors, N = cfg->n_runs, D = cfg->cov_dims;
     if (L < 1 || L > POD_MAX_LEVELS || K < 1 || K > POD_MAX_CLASSES || A < 1 || N < 1 || N > POD_MAX_RUNS) return POD_E_INVALID;
     if (!(D == 0 || D == 4 || D == 10)) return POD_E_INVALID;
@@ -240,9 +407,65 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
     P.n_levels = L; P.n_runs = N; P.A = A; P.K = K; P.D = D;
     P.has_cls_var = cfg->has_cls_var; P.quirk = cfg->merge_quirk; P.cls_samples = cfg->cls_samples;
     P.score_thresh = cfg->score_thresh; P.seed = cfg->philox_seed;
+    {
+        const double t = (double)cfg->score_thresh;
+        P.skip_logit = (t > 0.0 && t < 1.0) ? (float)(log(t / (1.0 - t)) - 0.02) : -INFINITY;   // margin covers the fast-math error
+    }
+    P.n_cls_blocks = P.seg_begin[L]; P.n_box_blocks = nb - P.seg_begin[L];
+    {
+        const char* e = getenv("POD_K1_INTERLEAVE");   // tuning knob; measured 41 -> 59 us when on, so default off
+        P.interleave = (e && e[0] == '1') ? 1 : 0;
+        const char* r = getenv("POD_K1_ROLES");        // profiling knob: "cls" / "box" run only that role (results invalid)
+        P.debug_roles = (r && r[0] == 'c') ? 1 : ((r && r[0] == 'b') ? 2 : 0);
+        const char* d = getenv("POD_K1_DEBUG");        // profiling knob (results invalid): 1 skip phase 2, 2 skip stores, 4 skip probs
+        P.debug_bits = d ? atoi(d) : 0;
+    }
     P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var; P.mean_delta = mean_delta; P.mean_reg_var = mean_reg_var;
-    P.cand_keys = cand_keys; P.cand_count = cand_count;
-    hipLaunchKernelGGL(pod::k1_mc_merge_score, dim3(nb), dim3(threads), sizeof(float) * 256 * K, (hipStream_t)stream, P);
+    P.cand_keys = cand_keys; P.cand_count = cand_count; P.maybe_bits = maybe_bits;
+    int batch = 8;
+    {
+        const char* e = getenv("POD_K1_BATCH");   // tuning knob: independent 16-B loads per tensor per lane
+        if (e) batch = atoi(e);
+    }
+    const size_t lds = sizeof(float) * 256 * K;
+    if (batch <= 2) hipLaunchKernelGGL(pod::k1_mc_merge_score<2>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
+    else if (batch <= 4) hipLaunchKernelGGL(pod::k1_mc_merge_score<4>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k1_mc_merge_score<8>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels) {
+    if (!cfg || !levels || cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS) return POD_E_INVALID;
+    int64_t w = 0;
+    for (int l = 0; l < cfg->n_levels; ++l) w += 4 * (int64_t)cfg->num_anchors * (((int64_t)levels[l].H * levels[l].W + 255) / 256);
+    return w;
+}
+
+extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
+                               const uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream) {
+    if (!cfg || !levels || !maybe_bits || !cand_keys || !cand_count) return POD_E_INVALID;
+    const int L = cfg->n_levels, K = cfg->num_classes;
+    if (L < 1 || L > POD_MAX_LEVELS || K < 1 || K > POD_MAX_CLASSES || !cfg->has_cls_var) return POD_E_INVALID;
+    if (cfg->n_runs > 1 && (!mean_cls || !mean_cls_var)) return POD_E_INVALID;
+    if (cfg->cls_samples < 1 || cfg->cls_samples > POD_MAX_CLS_SAMPLES) return POD_E_INVALID;
+    pod::K1bParams P;
+    int32_t wb = 0;
+    for (int l = 0; l < L; ++l) {
+        if (!levels[l].cls || !levels[l].cls_var || levels[l].eps_cls) return POD_E_INVALID;
+        P.lv[l] = levels[l];
+        P.chunks[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 255) / 256);
+        P.word_begin[l] = wb;
+        wb += 4 * cfg->num_anchors * P.chunks[l];
+    }
+    P.word_begin[L] = wb;
+    P.n_levels = L; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = K; P.cls_samples = cfg->cls_samples;
+    P.score_thresh = cfg->score_thresh; P.seed = cfg->philox_seed; P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var;
+    P.maybe_bits = maybe_bits; P.cand_keys = cand_keys; P.cand_count = cand_count;
+    const int blocks = (wb + 3) / 4 < 1024 ? (wb + 3) / 4 : 1024;   // one wavefront per bitmap word up to a persistent 4096
+    const dim3 grid(blocks), block(256);
+    if (K <= 8) hipLaunchKernelGGL(pod::k1b_score_maybe<8>, grid, block, 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k1b_score_maybe<16>, grid, block, 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

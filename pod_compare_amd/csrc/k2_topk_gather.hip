@@ -130,65 +130,102 @@ struct K2bParams {
     int32_t* n_total;
 };
 
-// merged value of one element (plane-layout offset `e` inside a run) in the reference order
-__device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int64_t e, int n_runs, int quirk) {
-    float acc = base[e];
-    if (n_runs == 1) return acc;
-    for (int t = 1; t < n_runs; ++t) acc = acc + base[(int64_t)merge_term_run(t, quirk) * rs + e];
-    return __fdiv_rn(acc, (float)n_runs);
+// Merged value of one element (plane-layout offset `e` inside a run) in the reference order; all N
+// loads of a batch are issued before the first add.  Optionally hands every run's raw value to `sink`.
+template <class Sink>
+__device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int64_t e, int n_runs, int quirk, Sink sink) {
+    float acc = 0.0f;
+    float x0 = 0.0f;
+    for (int r0 = 0; r0 < n_runs; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (r0 + j < n_runs) v[j] = base[(int64_t)(r0 + j) * rs + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int run = r0 + j;
+            if (run < n_runs) {
+                sink(run, v[j]);
+                if (run == 0) {
+                    x0 = v[j];
+                    acc = (quirk && n_runs > 1) ? x0 + x0 : x0;   // term 0 (+ term 1 = run 0 again, PI:216-219)
+                } else if (!quirk || run < n_runs - 1) {
+                    acc = acc + v[j];                             // quirk: the last run is never added
+                }
+            }
+        }
+    }
+    return n_runs == 1 ? acc : __fdiv_rn(acc, (float)n_runs);
 }
 
-__global__ void __launch_bounds__(256) k2b_gather(const K2bParams P) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per selected candidate.  Lane c < C = 2K+4+D owns channel c of the anchor
+// ([0,K) logits, [K,2K) log-variances, then 4 deltas, then D reg_var entries): it loads that
+// channel of all N runs (independent loads), merges them in the reference order, and the K logit
+// lanes then re-derive the class probabilities with K1's device function (bit-identical).
+__global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
+    const int slot = blockIdx.x;
+    const int lane = threadIdx.x;
     const int L = P.n_levels;
-    int total = 0;
-    for (int i = 0; i < L; ++i) total += P.sel_count[i];
-    if (slot == 0) *P.n_total = total;
     const int l = slot / P.topk;
     const int j = slot - l * P.topk;
+    if (slot == 0 && lane == 0) {
+        int total = 0;
+        for (int i = 0; i < L; ++i) total += P.sel_count[i];
+        *P.n_total = total;
+    }
     if (l >= L || j >= P.sel_count[l]) return;
     int dst = j;
     for (int i = 0; i < l; ++i) dst += P.sel_count[i];
     const PodLevel& lv = P.lv[l];
     const uint64_t key = P.sel_keys[(int64_t)l * P.topk + j];
     const int r = key_index(key);
-    const int A = P.A, K = P.K, D = P.D;
+    const int A = P.A, K = P.K, D = P.D, N = P.n_runs;
     const int hw = r / A;
     const int a = r - hw * A;
     const int64_t HW = (int64_t)lv.H * lv.W;
     const bool has_var = P.has_cls_var != 0;
-    // class probabilities, identical code path to K1
-    float best = 0.0f;
+    const int nvar = has_var ? K : 0;
+    const int C = K + nvar + 4 + D;
+    float merged = 0.0f;
+    if (lane < K) {
+        merged = merge_scalar(lv.cls, lv.run_stride_cls, (int64_t)(a * K + lane) * HW + hw, N, P.quirk, [](int, float) {});
+    } else if (lane < K + nvar) {
+        merged = merge_scalar(lv.cls_var, lv.run_stride_cls, (int64_t)(a * K + lane - K) * HW + hw, N, P.quirk, [](int, float) {});
+    } else if (lane < K + nvar + 4) {
+        const int c = lane - K - nvar;
+        float* rd = P.cand_run_delta;
+        merged = merge_scalar(lv.delta, lv.run_stride_delta, (int64_t)(a * 4 + c) * HW + hw, N, P.quirk,
+                              [=](int run, float v) { if (rd) rd[((int64_t)dst * N + run) * 4 + c] = v; });
+        P.cand_delta[(int64_t)dst * 4 + c] = merged;
+    } else if (lane < C) {
+        const int c = lane - K - nvar - 4;
+        merged = merge_scalar(lv.reg_var, lv.run_stride_reg, (int64_t)(a * D + c) * HW + hw, N, P.quirk, [](int, float) {});
+        P.cand_reg_var[(int64_t)dst * D + c] = merged;
+    }
+    const float lvar = has_var ? __shfl(merged, (lane < K ? lane : 0) + K, 64) : 0.0f;
+    float p = -1.0f;
+    if (lane < K) {
+        p = class_prob_cell(merged, lvar, has_var, P.cls_samples, lv.eps_cls, HW * A, K, A, l, hw, a, lane, P.seed);
+        P.cand_probs[(int64_t)dst * K + lane] = p;
+    }
+    // max / first argmax over the K class lanes
+    float best = __shfl(p, 0, 64);
     int best_k = 0;
-    for (int k = 0; k < K; ++k) {
-        const int64_t e = (int64_t)(a * K + k) * HW + hw;
-        const float logit = merge_scalar(lv.cls, lv.run_stride_cls, e, P.n_runs, P.quirk);
-        const float lvar = has_var ? merge_scalar(lv.cls_var, lv.run_stride_cls, e, P.n_runs, P.quirk) : 0.0f;
-        ClsEps eps(lv.eps_cls, HW * A, K, r, k, P.seed, (uint32_t)(lv.anchor_base + r));
-        const float p = class_prob(logit, lvar, has_var, P.cls_samples, eps);
-        P.cand_probs[(int64_t)dst * K + k] = p;
-        if (k == 0 || p > best) {
-            best = p;
+    for (int k = 1; k < K; ++k) {
+        const float v = __shfl(p, k, 64);
+        if (v > best) {
+            best = v;
             best_k = k;
         }
     }
-    P.cand_score[dst] = best;            // == key_score(key) by construction
-    P.cand_class[dst] = best_k;
-    P.cand_anchor_idx[dst] = r;
-    P.cand_level[dst] = l;
-    for (int c = 0; c < 4; ++c) {
-        const int64_t e = (int64_t)(a * 4 + c) * HW + hw;
-        P.cand_delta[(int64_t)dst * 4 + c] = merge_scalar(lv.delta, lv.run_stride_delta, e, P.n_runs, P.quirk);
-        if (P.cand_run_delta)
-            for (int run = 0; run < P.n_runs; ++run)
-                P.cand_run_delta[((int64_t)dst * P.n_runs + run) * 4 + c] = lv.delta[(int64_t)run * lv.run_stride_delta + e];
+    if (lane == 0) {
+        P.cand_score[dst] = best;            // == key_score(key) by construction
+        P.cand_class[dst] = best_k;
+        P.cand_anchor_idx[dst] = r;
+        P.cand_level[dst] = l;
+        const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
+        *reinterpret_cast<float4*>(P.cand_anchor + (int64_t)dst * 4) = anc;
     }
-    for (int c = 0; c < D; ++c) {
-        const int64_t e = (int64_t)(a * D + c) * HW + hw;
-        P.cand_reg_var[(int64_t)dst * D + c] = merge_scalar(lv.reg_var, lv.run_stride_reg, e, P.n_runs, P.quirk);
-    }
-    const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
-    *reinterpret_cast<float4*>(P.cand_anchor + (int64_t)dst * 4) = anc;
 }
 
 }  // namespace pod
@@ -215,6 +252,7 @@ extern "C" int pod_gather_candidates(const PodConfig* cfg, const PodLevel* level
         return POD_E_INVALID;
     if (cfg->cov_dims > 0 && !cand_reg_var) return POD_E_INVALID;
     if (cfg->n_levels * cfg->topk > POD_MAX_CANDIDATES * 4) return POD_E_INVALID;
+    if (2 * cfg->num_classes + 4 + cfg->cov_dims > 64) return POD_E_INVALID;
     pod::K2bParams P;
     for (int l = 0; l < cfg->n_levels; ++l) P.lv[l] = levels[l];
     P.n_levels = cfg->n_levels; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = cfg->num_classes; P.D = cfg->cov_dims;
@@ -224,7 +262,7 @@ extern "C" int pod_gather_candidates(const PodConfig* cfg, const PodLevel* level
     P.cand_probs = cand_probs; P.cand_delta = cand_delta; P.cand_reg_var = cand_reg_var; P.cand_anchor = cand_anchor;
     P.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr; P.n_total = n_total;
     const int slots = cfg->n_levels * cfg->topk;
-    hipLaunchKernelGGL(pod::k2b_gather, dim3((slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(pod::k2b_gather, dim3(slots), dim3(64), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
         // ---- pass 1: draw, decode, block sums --------------------------------------------------------
         float xs[16][4];
         float bs[4] = {0, 0, 0, 0};
+        f32x8n z;   // native mode: one Philox call serves the two samples (2m, 2m+1)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int s = lane * 16 + t;
@@ -107,8 +108,8 @@ __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
                     const float4 e4 = *reinterpret_cast<const float4*>(P.eps_prop + ((size_t)s * P.n_replay + i) * 4);
                     e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
                 } else {
-                    const f32x4n z = philox_normals(P.seed, gid, (uint32_t)s, 0u, STREAM_BOX);
-                    e[0] = z.v[0]; e[1] = z.v[1]; e[2] = z.v[2]; e[3] = z.v[3];
+                    if ((t & 1) == 0) z = philox_normals8(P.seed, gid, (uint32_t)(s >> 1), 0u, STREAM_BOX);
+                    e[0] = z.v[(t & 1) * 4 + 0]; e[1] = z.v[(t & 1) * 4 + 1]; e[2] = z.v[(t & 1) * 4 + 2]; e[3] = z.v[(t & 1) * 4 + 3];
                 }
             }
             float d[4];

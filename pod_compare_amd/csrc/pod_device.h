@@ -10,6 +10,7 @@
 #include "../../include/pod_mi355x.h"
 
 #define POD_WAVE 64
+#define POD_EPS_MAX 4.9f   // > sqrt(-2 ln 2^-17) = 4.855: largest |normal| box_muller16() can return
 
 #define POD_CHECK_LAUNCH()                                  \
     do {                                                    \
@@ -44,30 +45,34 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
-// Box-Muller on two 32-bit words -> two standard normals (native-RNG mode; statistical parity only).
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
-    const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
-    const float rad = sqrtf(-2.0f * __logf(u1));
-    float s, c;
-    __sincosf(6.283185307179586f * u2, &s, &c);
-    n0 = rad * c;
-    n1 = rad * s;
+// Native-RNG normals: Box-Muller on two 16-bit uniforms (one 32-bit Philox word per pair of normals,
+// 8 normals per Philox4x32-10 call).  u1 = (a + 0.5) / 2^16 >= 2^-17 bounds the radius, so
+//     |z| <= sqrt(-2 ln 2^-17) = 4.855 < POD_EPS_MAX,
+// which is what lets K1 prune anchors EXACTLY (see k1_mc_merge_score.hip).  Statistical parity only: the
+// eps-replay mode never comes here.  v_log_f32 is log2; v_sin/v_cos take their argument in revolutions.
+__device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
+    const float u1 = ((float)(w & 0xFFFFu) + 0.5f) * 1.52587890625e-05f;   // (0,1)
+    const float u2 = ((float)(w >> 16) + 0.5f) * 1.52587890625e-05f;       // revolutions
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    n0 = rad * __builtin_amdgcn_cosf(u2);
+    n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
-struct f32x4n {
-    float v[4];
+struct f32x8n {
+    float v[8];
 };
 
 // stream ids for the counter's 4th word
 constexpr uint32_t STREAM_CLS = 0x636c7300u;   // classification logit samples (PI:291-295)
 constexpr uint32_t STREAM_BOX = 0x626f7800u;   // box-delta samples (PI:351-356)
 
-__device__ __forceinline__ f32x4n philox_normals(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t stream) {
+__device__ __forceinline__ f32x8n philox_normals8(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t stream) {
     const u32x4 r = philox4x32_10(u32x4{c0, c1, c2, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));
-    f32x4n o;
-    box_muller(r.x, r.y, o.v[0], o.v[1]);
-    box_muller(r.z, r.w, o.v[2], o.v[3]);
+    f32x8n o;
+    box_muller16(r.x, o.v[0], o.v[1]);
+    box_muller16(r.y, o.v[2], o.v[3]);
+    box_muller16(r.z, o.v[4], o.v[5]);
+    box_muller16(r.w, o.v[6], o.v[7]);
     return o;
 }
 
@@ -77,6 +82,10 @@ __device__ __forceinline__ f32x4n philox_normals(uint64_t seed, uint32_t c0, uin
 
 // torch.sigmoid on CPU: 1 / (1 + exp(-x)) with a correctly rounded divide.
 __device__ __forceinline__ float sigmoid_ref(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
+// native-RNG mode only (no bit-level comparison with the CPU is possible there): v_exp_f32 + v_rcp_f32.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // PI:216-222 merge of N runs, in the reference's association order.
 //   quirk: acc = x0; acc += x0; acc += x1; ... acc += x_{N-2}; acc /= N
@@ -87,41 +96,45 @@ __device__ __forceinline__ int merge_term_run(int t, int quirk) { return (quirk 
 // Class probability of one (anchor, class): PI:289-297.
 //   no variance head : sigmoid(logit)
 //   variance head    : mean_s sigmoid(logit + eps_s * sqrt(exp(var))), s = 0..S-1, summed in order, / S
-template <class EpsFn>
-__device__ __forceinline__ float class_prob(float logit, float logvar, bool has_var, int S, EpsFn eps) {
+//
+// eps source.  Replay (parity mode): tensor (S, R_l, K) in the reference layout, every op the reference's.
+// Native: Philox draws organised per group of 4 consecutive cells (the 4 anchors one K1 lane owns); normal
+// q = j*S + s (j = hw & 3, s = sample) is component q&7 of the call with counter
+// (hw>>2, level<<16 | a<<8 | k, q>>3, STREAM_CLS).  K1, K1b and K2b all come through this one function, so
+// they see bit-identical draws and sums and nothing has to be stored.  Transcendentals use the hardware
+// approximations in native mode (the draws differ from torch's anyway).
+__device__ __forceinline__ float class_prob_cell(float logit, float logvar, bool has_var, int S, const float* replay,
+                                                int64_t level_anchors, int K, int A, int level, int hw, int a, int k, uint64_t seed) {
     if (!has_var) return sigmoid_ref(logit);
-    const float sigma = sqrtf(expf(logvar));
     float acc = 0.0f;
-    for (int s = 0; s < S; ++s) {
-        const float x = logit + eps(s) * sigma;
-        acc = acc + sigmoid_ref(x);
-    }
-    return __fdiv_rn(acc, (float)S);
-}
-
-// Eps source for one (level anchor r, class k): replay tensor (S, R_l, K) in reference layout, or Philox.
-struct ClsEps {
-    const float* replay;     // may be null
-    int64_t stride_s;        // R_l * K
-    int64_t offset;          // r * K + k
-    uint64_t seed;
-    uint32_t gid, k;         // global anchor id, class
-    float c0, c1, c2, c3;
-    int cached_call;
-    __device__ __forceinline__ ClsEps(const float* rp, int64_t rl, int K, int r, int kk, uint64_t sd, uint32_t g)
-        : replay(rp), stride_s(rl * K), offset((int64_t)r * K + kk), seed(sd), gid(g), k((uint32_t)kk), cached_call(-1) {}
-    __device__ __forceinline__ float operator()(int s) {
-        if (replay) return replay[(int64_t)s * stride_s + offset];
-        const int call = s >> 2;
-        if (call != cached_call) {
-            const f32x4n z = philox_normals(seed, gid, k, (uint32_t)call, STREAM_CLS);
-            c0 = z.v[0]; c1 = z.v[1]; c2 = z.v[2]; c3 = z.v[3];
-            cached_call = call;
+    if (replay) {
+        const float sigma = sqrtf(expf(logvar));
+        const float* e = replay + ((int64_t)hw * A + a) * K + k;
+        const int64_t stride_s = level_anchors * K;
+        for (int s = 0; s < S; ++s) {
+            const float x = logit + e[(int64_t)s * stride_s] * sigma;
+            acc = acc + sigmoid_ref(x);
         }
-        const int q = s & 3;
-        return q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+        return __fdiv_rn(acc, (float)S);
     }
-};
+    const float sigma = __builtin_amdgcn_exp2f(0.7213475204444817f * logvar);   // sqrt(exp(v)) = 2^(v / (2 ln 2))
+    const int q0 = (hw & 3) * S, q1 = q0 + S;
+    const uint32_t c0 = (uint32_t)(hw >> 2), c1 = ((uint32_t)level << 16) | ((uint32_t)a << 8) | (uint32_t)k;
+    for (int call = q0 >> 3; call * 8 < q1; ++call) {
+        const u32x4 r = philox4x32_10(u32x4{c0, c1, (uint32_t)call, STREAM_CLS}, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float z[8];
+        box_muller16(r.x, z[0], z[1]);
+        box_muller16(r.y, z[2], z[3]);
+        box_muller16(r.z, z[4], z[5]);
+        box_muller16(r.w, z[6], z[7]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int q = call * 8 + c;
+            if (q >= q0 && q < q1) acc += sigmoid_fast(fmaf(z[c], sigma, logit));
+        }
+    }
+    return acc * __builtin_amdgcn_rcpf((float)S);
+}
 
 // detectron2 Box2BoxTransform.apply_deltas / IU:510-547 on one box; dw, dh clamped at log(1000/16).
 struct Box {

@@ -24,7 +24,7 @@ POD_MAX_CLS_SAMPLES = 64
 POD_MAX_CANDIDATES = 8192
 POD_MAX_DETECTIONS = 128
 
-EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
+EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_finalize", "pod_reg_nll")
 
@@ -72,7 +72,10 @@ def load() -> ctypes.CDLL:
     lib.pod_nms_scratch_bytes.restype = c_size_t
     lib.pod_nms_scratch_bytes.argtypes = [c_int32]
     lib.pod_reset_counters.argtypes = [P, c_int32, P]
-    lib.pod_mc_merge_score.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P, P]
+    lib.pod_mc_merge_score.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P, P, P]
+    lib.pod_maybe_words.argtypes = [POINTER(PodConfig), POINTER(PodLevel)]
+    lib.pod_maybe_words.restype = c_int64
+    lib.pod_score_maybe.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P]
     lib.pod_level_topk.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P]
     lib.pod_gather_candidates.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 14
     lib.pod_decode_cov.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, c_int32, P, P, P, P, P, P, P, c_int32, P, P, P]
@@ -82,7 +85,7 @@ def load() -> ctypes.CDLL:
     lib.pod_finalize.argtypes = [POINTER(PodConfig)] + [P] * 7 + [c_float] * 4 + [P] * 7 + [P]
     lib.pod_reg_nll.argtypes = [P, P, P, c_int32, P, P]
     for name in EXPORTS:
-        if name not in ("pod_abi_version", "pod_nms_scratch_bytes"):
+        if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words"):
             getattr(lib, name).restype = ctypes.c_int
     if lib.pod_abi_version() != POD_ABI_VERSION:
         raise PodError("ABI version mismatch: library {} vs binding {}".format(lib.pod_abi_version(), POD_ABI_VERSION))

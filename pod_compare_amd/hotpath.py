@@ -92,8 +92,10 @@ class HotPath:
         self.mean_delta = f32(self.R * 4) if merged else None
         self.mean_reg_var = f32(self.R * D) if merged and D > 0 else None
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
-        self.counters = torch.zeros(hip.POD_MAX_LEVELS + 8, dtype=torch.int32, device=dev)   # [0:L] cand_count
+        self.counters = torch.zeros(hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count
         self.cand_count = self.counters[: self.L]
+        n_words = sum(4 * A * ((h * w + 255) // 256) for h, w in self.shapes)
+        self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None
         # K2 outputs
         self.sel_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)
         self.sel_count = i32(self.L)
@@ -162,12 +164,18 @@ class HotPath:
         lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
         self._lv_keepalive = (lv, eps_cls)
         P = hip.ptr
-        hip.check(lib.pod_reset_counters(P(self.counters), self.L, st), "pod_reset_counters")
-        wm = write_merged and self.n_runs > 1
+        hip.check(lib.pod_reset_counters(P(self.counters), hip.POD_MAX_LEVELS, st), "pod_reset_counters")
+        # prune mode: native RNG with a variance head -> dense pass flags, K1b samples (see k1_mc_merge_score.hip)
+        prune = self.has_cls_var and eps_cls is None
+        wm = (write_merged or prune) and self.n_runs > 1
         hip.check(lib.pod_mc_merge_score(cfg, lv, P(self.mean_cls) if wm else None, P(self.mean_cls_var) if wm else None,
                                          P(self.mean_delta) if wm else None, P(self.mean_reg_var) if wm else None,
-                                         P(self.cand_keys), P(self.counters), st), "pod_mc_merge_score")
-        hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.counters), P(self.sel_keys), P(self.sel_count), st),
+                                         P(self.cand_keys), P(self.cand_count), P(self.maybe_bits) if prune else None, st),
+                  "pod_mc_merge_score")
+        if prune:
+            hip.check(lib.pod_score_maybe(cfg, lv, P(self.mean_cls), P(self.mean_cls_var), P(self.maybe_bits),
+                                          P(self.cand_keys), P(self.cand_count), st), "pod_score_maybe")
+        hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.cand_count), P(self.sel_keys), P(self.sel_count), st),
                   "pod_level_topk")
         hip.check(lib.pod_gather_candidates(cfg, lv, P(self.anchors), P(self.sel_keys), P(self.sel_count),
                                             P(self.cand_anchor_idx), P(self.cand_level), P(self.cand_score), P(self.cand_class),

@@ -16,7 +16,7 @@ HEADER = os.path.join(ROOT, "include", "pod_mi355x.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(pod_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|size_t)\s+(pod_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

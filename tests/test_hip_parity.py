@@ -155,3 +155,67 @@ def test_reg_nll_matches_scoring_rule():
     out = torch.empty(n, device="cuda")
     hip.check(lib.pod_reg_nll(hip.ptr(d[0]), hip.ptr(d[1]), hip.ptr(d[2]), n, hip.ptr(out), hip.current_stream()), "pod_reg_nll")
     assert float((out.cpu() - ref).abs().max()) <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# native-RNG mode (in-kernel Philox): no bit-level comparison with the CPU is possible; check the
+# exactness of K1's pruning bound, determinism, and statistical agreement with the replay path.
+# ---------------------------------------------------------------------------------------------------
+
+def _native_candidates(hp, hd, prune):
+    from pod_compare_amd import hip
+    P, st, lib = hip.ptr, hip.current_stream(), hp.lib
+    lv = hp._levels(hd.cls, hd.delta, hd.cls_var, hd.reg_var, None)
+    hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")
+    hip.check(lib.pod_mc_merge_score(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta), P(hp.mean_reg_var),
+                                     P(hp.cand_keys), P(hp.cand_count), P(hp.maybe_bits) if prune else None, st), "k1")
+    if prune:
+        hip.check(lib.pod_score_maybe(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits),
+                                      P(hp.cand_keys), P(hp.cand_count), st), "k1b")
+    torch.cuda.synchronize()
+    counts = hp.cand_count.cpu().tolist()
+    keys = [torch.sort(hp.cand_keys[b:b + c].cpu())[0] for b, c in zip(hp.anchor_base, counts)]
+    return counts, keys, [sum(bin(int(x) & (2 ** 64 - 1)).count('1') for x in hp.maybe_bits.cpu().tolist())] if prune else [0]
+
+
+@pytest.mark.parametrize("mode,runs", [("planted", 10), ("worst", 3), ("planted", 1)])
+def test_prune_bound_is_exact(mode, runs):
+    """K1 prune mode + K1b must emit exactly the candidate keys of the dense in-kernel scoring (same Philox
+    draws), on planted data (almost everything pruned) and on worst-case data (nothing pruned)."""
+    ho = synthetic.planted_head_outputs((384, 512), runs, seed=77, num_boxes=12, mode=mode).to("cuda")
+    hp = make_path(ho)
+    c0, k0, _ = _native_candidates(hp, ho, prune=False)
+    c1, k1, maybe = _native_candidates(hp, ho, prune=True)
+    assert c0 == c1 and sum(c0) > 0
+    for a, b in zip(k0, k1):
+        assert torch.equal(a, b)
+    if mode == "planted":
+        assert sum(maybe) < 0.05 * hp.R      # the bound really prunes
+    else:
+        assert sum(maybe) > 0.9 * hp.R
+
+
+def test_native_mode_is_deterministic_and_close_to_replay():
+    g = Golden([p for p in SMALL if "cfg3_bayes_od_mc10_s31" in p][0])
+    ho = g.head_outputs()
+    hp = make_path(ho)
+    hd = ho.to("cuda")
+    kw = dict(image_size=tuple(g.meta["image"]), out_size=tuple(g.meta["out"]))
+    d1 = hp.run("bayes_od", hd.cls, hd.delta, hd.cls_var, hd.reg_var, **kw)
+    b1, c1, m1 = d1.boxes.clone(), d1.cov.clone(), d1.count()
+    d2 = hp.run("bayes_od", hd.cls, hd.delta, hd.cls_var, hd.reg_var, **kw)
+    assert d2.count() == m1 and torch.equal(d2.boxes[:m1], b1[:m1]) and torch.equal(d2.cov[:m1], c1[:m1])
+    # against the reference (torch normals): the same set of detections (order by score may swap between
+    # near-equal scores because the draws differ), means within sampling error, variances within ~30 %
+    ref_b, ref_c, ref_cls = g.t("pred_boxes"), g.t("pred_boxes_covariance"), g.t("pred_classes")
+    assert m1 == ref_b.shape[0]
+    nb, nc, ncls = b1[:m1].cpu(), c1[:m1].cpu(), d1.classes[:m1].cpu().long()
+    dist = (nb[:, None, :] - ref_b[None, :, :]).abs().sum(-1)
+    match = dist.argmin(1)
+    assert sorted(match.tolist()) == list(range(m1))          # one-to-one
+    assert torch.equal(ncls, ref_cls[match])
+    rb, rc = ref_b[match], ref_c[match]
+    sd = rc.diagonal(dim1=1, dim2=2).sqrt()
+    assert bool(((nb - rb).abs() <= 6.0 * sd / (1000 ** 0.5) + 0.05 * sd + 1e-3).all())
+    rel = (nc.diagonal(dim1=1, dim2=2) - rc.diagonal(dim1=1, dim2=2)).abs() / rc.diagonal(dim1=1, dim2=2)
+    assert float(rel.max()) < 0.3

@@ -1,0 +1,67 @@
+// Micro-benchmark: what HBM bandwidth does this box give a 9-streams-in / 1-stream-out fp32 merge
+// (the access pattern of K1's box role) and a plain float4 copy?  hipcc --offload-arch=gfx950 -O3 tools/membw.hip -o /tmp/membw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void copy4(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+template <int NR>
+__global__ void merge4(const float4* __restrict__ a, size_t run_stride, float4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = a[i + r * run_stride];
+    float4 acc = v[0];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) { acc.x += v[r].x; acc.y += v[r].y; acc.z += v[r].z; acc.w += v[r].w; }
+    out[i] = acc;
+}
+template <int NR>
+__global__ void merge4_gs(const float4* __restrict__ a, size_t run_stride, float4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = a[i + r * run_stride];
+        float4 acc = v[0];
+#pragma unroll
+        for (int r = 1; r < NR; ++r) { acc.x += v[r].x; acc.y += v[r].y; acc.z += v[r].z; acc.w += v[r].w; }
+        out[i] = acc;
+    }
+}
+int main() {
+    const size_t run_elems = (size_t)193374 * 22 / 4;       // float4 per run (17 MB)
+    const int NR = 9, SETS = 4, IT = 40;
+    std::vector<float4*> in(SETS), out(SETS);
+    for (int s = 0; s < SETS; ++s) { CK(hipMalloc(&in[s], run_elems * 16 * (NR + 1))); CK(hipMalloc(&out[s], run_elems * 16)); CK(hipMemset(in[s], 1, run_elems * 16 * (NR + 1))); }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, auto launch, double bytes) {
+        for (int i = 0; i < 4; ++i) launch(i % SETS);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < IT; ++i) launch(i % SETS);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-34s %7.2f us/launch  %7.1f GB/s\n", name, 1e3 * ms / IT, bytes / (ms / IT * 1e-3) / 1e9);
+        return 0;
+    };
+    const double mbytes = (double)run_elems * 16 * (NR + 1);
+    for (int threads : {256, 512, 1024}) {
+        char nm[64];
+        snprintf(nm, 64, "merge 9 streams (1 f4/thr, %d thr)", threads);
+        timeit(nm, [&](int s) { merge4<9><<<(run_elems + threads - 1) / threads, threads>>>(in[s], run_elems, out[s], run_elems); }, mbytes);
+    }
+    for (int blocks : {1024, 2048, 4096}) {
+        char nm[64];
+        snprintf(nm, 64, "merge 9 streams grid-stride %d blk", blocks);
+        timeit(nm, [&](int s) { merge4_gs<9><<<blocks, 256>>>(in[s], run_elems, out[s], run_elems); }, mbytes);
+    }
+    const size_t cn = run_elems * 5;    // 85 MB read + 85 MB write
+    timeit("copy float4 (85 MB -> 85 MB)", [&](int s) { copy4<<<(cn + 255) / 256, 256>>>(in[s], in[s] + cn, cn); }, (double)cn * 32);
+    timeit("merge 2 streams", [&](int s) { merge4<2><<<(run_elems * 4 + 255) / 256, 256>>>(in[s], run_elems * 4, out[s], run_elems); }, 0);
+    return 0;
+}
