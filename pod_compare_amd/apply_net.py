@@ -1,0 +1,115 @@
+"""Inference driver: the reference's apply_net.py loop (AN:82-102), image-sharded over the GPUs of one node.
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m pod_compare_amd.apply_net \
+        --config-file <model.yaml> --inference-config <inference.yaml> --num-images 64 --output results.json
+
+The reference pins inference to one process (AN:113-114).  Here rank r handles images r, r+world, ...
+(independent units, batch 1 as AN:35); each rank keeps its detections as fixed-stride records in HBM
+(K7) and ONE collective per flush gathers counts + records to every rank (`all_gather`; backend "nccl" =
+RCCL over xGMI on GPUs, "gloo" in the CPU tests of this sharding/re-ordering logic).  Rank 0 restores the
+image order and writes `coco_instances_results.json` (AN:100-102 format).
+"""
+import argparse
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .inference_utils import record_width, records_to_json
+
+BDD_CAT_MAP = {i: i + 1 for i in range(7)}   # contiguous id -> dataset id (core/datasets/metadata.py, ids 1..7)
+
+
+def shard_indices(num_images: int, rank: int, world: int) -> List[int]:
+    """Images of rank `rank`: i = rank (mod world)."""
+    return list(range(rank, num_images, world))
+
+
+def gather_records(local_ids: Sequence[int], local_counts: torch.Tensor, local_records: torch.Tensor, num_images: int,
+                   world: int) -> Tuple[List[int], torch.Tensor, torch.Tensor]:
+    """One flush: every rank contributes (n_local, max_det, width) records + (n_local,) counts, padded to the
+    common per-rank maximum so a single all_gather moves them.  Returns (image ids, counts, records) in image order."""
+    per_rank = -(-num_images // world)
+    n_local = len(local_ids)
+    dev = local_records.device
+    ids = torch.full((per_rank,), -1, dtype=torch.int64, device=dev)
+    ids[:n_local] = torch.as_tensor(list(local_ids), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((per_rank,), dtype=torch.int32, device=dev)
+    cnt[:n_local] = local_counts.to(torch.int32)
+    rec = torch.zeros((per_rank,) + tuple(local_records.shape[1:]), dtype=local_records.dtype, device=dev)
+    rec[:n_local] = local_records
+    if world > 1:
+        all_ids = [torch.empty_like(ids) for _ in range(world)]
+        all_cnt = [torch.empty_like(cnt) for _ in range(world)]
+        all_rec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(all_ids, ids)
+        dist.all_gather(all_cnt, cnt)
+        dist.all_gather(all_rec, rec)
+        ids, cnt, rec = torch.cat(all_ids), torch.cat(all_cnt), torch.cat(all_rec)
+    valid = ids >= 0
+    ids, cnt, rec = ids[valid], cnt[valid], rec[valid]
+    order = torch.argsort(ids)
+    return ids[order].tolist(), cnt[order], rec[order]
+
+
+def results_json(ids: Sequence[int], counts: torch.Tensor, records: torch.Tensor, num_classes: int,
+                 cat_map: Optional[Dict[int, int]] = None) -> List[dict]:
+    out = []
+    counts = counts.cpu().tolist()
+    records = records.cpu()
+    for i, image_id in enumerate(ids):
+        out.extend(records_to_json(records[i], counts[i], image_id, num_classes, cat_map))
+    return out
+
+
+def main(argv=None):
+    from . import synthetic
+    from .config import setup_config
+    from .probabilistic_inference import build_predictor
+    ap = argparse.ArgumentParser()
+    here = os.path.dirname(os.path.abspath(__file__))
+    ap.add_argument("--config-file", default=os.path.join(here, "configs/BDD-Detection/retinanet/retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml"))
+    ap.add_argument("--inference-config", default=os.path.join(here, "configs/Inference/bayes_od_mc_dropout.yaml"))
+    ap.add_argument("--num-images", type=int, default=8)
+    ap.add_argument("--random-seed", type=int, default=0)
+    ap.add_argument("--output", default="coco_instances_results.json")
+    args = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    cfg = setup_config(args.config_file, args.inference_config, args.random_seed)
+    cfg.MODEL.DEVICE = "cuda:%d" % local_rank
+    torch.manual_seed(args.random_seed)
+    predictor = build_predictor(cfg)
+    K = cfg.MODEL.RETINANET.NUM_CLASSES
+    from . import modeling
+    mine = shard_indices(args.num_images, rank, world)
+    recs, cnts = [], []
+    with torch.no_grad():
+        for i in mine:
+            frame = synthetic.synthetic_frame(i, device=cfg.MODEL.DEVICE)
+            image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+            input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
+            predictor(input_im)
+            det = predictor.last_detections
+            recs.append(det.records)
+            cnts.append(det.n_det)
+    width = record_width(K)
+    rec = torch.stack(recs) if recs else torch.zeros((0, 128, width), device=cfg.MODEL.DEVICE)
+    cnt = torch.stack(cnts) if cnts else torch.zeros((0,), dtype=torch.int32, device=cfg.MODEL.DEVICE)
+    ids, cnt, rec = gather_records(mine, cnt, rec, args.num_images, world)
+    if rank == 0:
+        with open(args.output, "w") as fp:
+            json.dump(results_json(ids, cnt, rec, K, BDD_CAT_MAP), fp, indent=4, separators=(",", ": "))
+        print("wrote %s: %d images, %d detections" % (args.output, len(ids), int(cnt.sum())))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

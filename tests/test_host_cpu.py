@@ -1,0 +1,135 @@
+"""CPU tests of the host logic: config loading, result format, image sharding + gather (gloo, world_size 2)."""
+import glob
+import json
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pod_compare_amd import apply_net, config, inference_utils
+from pod_compare_amd.anchors import grid_anchors, level_shapes, padded_size, resize_shortest_edge
+from pod_compare_amd.structures import Boxes, Instances
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CFG = os.path.join(os.path.dirname(HERE), "pod_compare_amd", "configs")
+REF_CFG = "/root/reference/src/configs"
+
+
+def test_baseline_geometry():
+    """1280x720 -> 750x1333 -> padded 768x1344 -> R = 193374 anchors."""
+    hw = resize_shortest_edge(720, 1280)
+    assert hw == (750, 1333) and padded_size(*hw) == (768, 1344)
+    shapes = level_shapes(768, 1344)
+    assert shapes == [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)]
+    anchors = grid_anchors(shapes)
+    assert sum(a.shape[0] for a in anchors) == 193374
+    # (h, w, a) order, a = size-major x ratio (0.5, 1, 2); first cell of p3
+    assert torch.allclose(anchors[0][0], torch.tensor([-22.6274, -11.3137, 22.6274, 11.3137]), atol=1e-4)
+    assert torch.allclose(anchors[0][9], anchors[0][0] + torch.tensor([8.0, 0.0, 8.0, 0.0]))
+
+
+def test_configs_load_with_reference_keys():
+    cfg = config.setup_config(os.path.join(CFG, "BDD-Detection/retinanet/retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml"),
+                              os.path.join(CFG, "Inference/bayes_od_mc_dropout.yaml"))
+    pi = cfg.PROBABILISTIC_INFERENCE
+    assert pi.INFERENCE_MODE == "bayes_od" and pi.AFFINITY_THRESHOLD == 0.9
+    assert pi.MC_DROPOUT.ENABLE is True and pi.MC_DROPOUT.NUM_RUNS == 10
+    assert pi.BAYES_OD.CLS_MERGE_MODE == "max_score" and pi.BAYES_OD.BOX_MERGE_MODE == "bayesian_inference"
+    pm = cfg.MODEL.PROBABILISTIC_MODELING
+    assert pm.DROPOUT_RATE == 0.2 and pm.CLS_VAR_LOSS.NUM_SAMPLES == 10 and pm.BBOX_COV_LOSS.COVARIANCE_TYPE == "diagonal"
+    assert cfg.MODEL.RETINANET.NUM_CLASSES == 7 and cfg.MODEL.META_ARCHITECTURE == "ProbabilisticRetinaNet"
+    # defaults of core/setup.py:90-133 when the inference yaml is silent
+    d = config.setup_config(os.path.join(CFG, "BDD-Detection/retinanet/retinanet_R_50_FPN_1x.yaml"), os.path.join(CFG, "Inference/standard_nms.yaml"))
+    assert d.PROBABILISTIC_INFERENCE.AFFINITY_THRESHOLD == 0.7 and d.PROBABILISTIC_INFERENCE.MC_DROPOUT.NUM_RUNS == 1
+    assert d.PROBABILISTIC_INFERENCE.ENSEMBLES.RANDOM_SEED_NUMS == [0, 1000, 2000, 3000, 4000]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present")
+def test_own_yamls_equal_reference_yamls():
+    """Every model x inference YAML pair gives the same MODEL / PROBABILISTIC_INFERENCE values as the reference's
+    own files (read in place; the `eval` tag of Base-RetinaNet.yaml:8 is replaced by literal sizes, never evaluated)."""
+    def flat(d, p=""):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, p + k + "."))
+            else:
+                out[p + k] = [list(x) if isinstance(x, (list, tuple)) else x for x in v] if isinstance(v, (list, tuple)) else v
+        return out
+    n = 0
+    for m in glob.glob(REF_CFG + "/BDD-Detection/retinanet/retinanet*.yaml"):
+        for i in glob.glob(REF_CFG + "/Inference/*.yaml"):
+            a = config.setup_config(m, i)
+            b = config.setup_config(m.replace(REF_CFG, CFG), i.replace(REF_CFG, CFG))
+            for sect in ("MODEL", "PROBABILISTIC_INFERENCE"):
+                assert flat(a[sect]) == flat(b[sect]), (m, i)
+            n += 1
+    assert n == 32
+
+
+def test_unknown_meta_architecture_and_mode_raise():
+    from pod_compare_amd import probabilistic_inference as pinf
+    cfg = config.get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+    with pytest.raises(ValueError):
+        pinf.build_predictor(cfg, model=object())
+
+
+def test_instances_to_json_format():
+    inst = Instances((720, 1280))
+    inst.pred_boxes = Boxes(torch.tensor([[10., 20., 110., 220.], [5., 5., 6., 7.]]))
+    inst.scores = torch.tensor([0.9, 0.4])
+    inst.pred_classes = torch.tensor([2, 9])          # class 9 is not in the map -> dropped (IU:477-479, 491)
+    inst.pred_cls_probs = torch.rand(2, 7)
+    c = torch.rand(2, 4, 4)
+    inst.pred_boxes_covariance = c @ c.transpose(1, 2)
+    js = inference_utils.instances_to_json(inst, 42, {i: i + 1 for i in range(7)})
+    assert len(js) == 1 and set(js[0]) == {"image_id", "category_id", "bbox", "score", "cls_prob", "bbox_covar"}
+    assert js[0]["image_id"] == 42 and js[0]["category_id"] == 3 and js[0]["bbox"] == [10.0, 20.0, 100.0, 200.0]
+    t = torch.tensor([[1., 0, 0, 0], [0, 1., 0, 0], [-1., 0, 1., 0], [0, -1., 0, 1.]])
+    assert torch.allclose(torch.tensor(js[0]["bbox_covar"]), t @ inst.pred_boxes_covariance[0] @ t.t(), atol=1e-6)
+    assert inference_utils.instances_to_json(Instances((1, 1), pred_boxes=Boxes(torch.zeros(0, 4))), 1, {}) == []
+
+
+def test_shard_indices_cover_all_images_once():
+    for world in (1, 2, 3, 8):
+        seen = sorted(i for r in range(world) for i in apply_net.shard_indices(21, r, world))
+        assert seen == list(range(21))
+
+
+def _gather_worker(rank, world, port, num_images, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, md = 7, 4
+    width = inference_utils.record_width(K)
+    mine = apply_net.shard_indices(num_images, rank, world)
+    rec = torch.zeros((len(mine), md, width))
+    cnt = torch.zeros((len(mine),), dtype=torch.int32)
+    for j, i in enumerate(mine):
+        cnt[j] = i % (md + 1)
+        for d in range(int(cnt[j])):
+            rec[j, d, :4] = torch.tensor([i, d, 10.0, 20.0])
+            rec[j, d, 4] = 1.0 / (1 + d)
+            rec[j, d, 5] = (i + d) % K
+    ids, c, r = apply_net.gather_records(mine, cnt, rec, num_images, world)
+    if rank == 0:
+        js = apply_net.results_json(ids, c, r, K, apply_net.BDD_CAT_MAP)
+        with open(os.path.join(tmp, "out.json"), "w") as f:
+            json.dump({"ids": ids, "counts": c.tolist(), "js": js}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_images", [7, 8])
+def test_two_rank_gather_restores_image_order(tmp_path, num_images):
+    """world_size-2 gloo run of the sharding + all_gather + re-ordering logic (ragged shards when num_images is odd)."""
+    port = 29500 + (os.getpid() % 2000) + num_images
+    mp.spawn(_gather_worker, args=(2, port, num_images, str(tmp_path)), nprocs=2, join=True)
+    out = json.load(open(tmp_path / "out.json"))
+    assert out["ids"] == list(range(num_images))
+    assert out["counts"] == [i % 5 for i in range(num_images)]
+    assert len(out["js"]) == sum(i % 5 for i in range(num_images))
+    first = [d for d in out["js"] if d["image_id"] == 3]
+    assert [d["bbox"][1] for d in first] == [0.0, 1.0, 2.0] and first[0]["category_id"] == 4

@@ -1,0 +1,111 @@
+"""The reference's plugin surface on the GPU: build_predictor(cfg) -> predictor(input_im) -> Instances, driven by
+the five BASELINE configs' YAMLs with a fake model that returns the golden fixtures' head tensors."""
+import json
+import os
+
+import pytest
+import torch
+
+from pod_compare_amd import config, inference_utils, probabilistic_inference as pinf
+from tests.helpers import GOLDEN, Golden, assert_close
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pod_compare_amd", "configs")
+M = CFG + "/BDD-Detection/retinanet/"
+I = CFG + "/Inference/"
+
+CASES = [  # (fixture, model yaml, inference yaml)  = BASELINE.json configs[0..4]
+    ("cfg1_standard_nms_plain_s11", "retinanet_R_50_FPN_1x.yaml", "standard_nms.yaml"),
+    ("cfg2_bayes_od_regclsvar_s21", "retinanet_R_50_FPN_1x_reg_cls_var.yaml", "bayes_od.yaml"),
+    ("cfg3_bayes_od_mc10_s31", "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", "bayes_od_mc_dropout.yaml"),
+    ("cfg4_anchor_stats_plain_s41", "retinanet_R_50_FPN_1x.yaml", "anchor_statistics.yaml"),
+    ("cfg5_ensembles_pre_nms_s51", "retinanet_R_50_FPN_1x_reg_cls_var.yaml", "ensembles_pre_nms.yaml"),
+    ("mc_dropout_plain_pre_nms_s81", "retinanet_R_50_FPN_1x_dropout.yaml", "mc_dropout_ensembles_pre_nms.yaml"),
+]
+
+
+class FakeModel:
+    """Stands in for ProbabilisticRetinaNet: returns stored head tensors (one run or all runs)."""
+
+    def __init__(self, ho, runs):
+        self.ho, self.runs = ho, runs
+        self.cls_var_num_samples, self.test_topk_candidates, self.test_score_thresh = 10, 1000, 0.05
+        self.test_nms_thresh, self.max_detections_per_image = 0.5, 100
+
+    def __call__(self, image, num_mc_dropout_runs=-1):
+        from pod_compare_amd.synthetic import HeadOutputs
+        h = self.ho
+        sel = (lambda lst: None if lst is None else [t[self.runs].contiguous() for t in lst])
+        return HeadOutputs(sel(h.cls), sel(h.delta), sel(h.cls_var), sel(h.reg_var), h.anchors, h.shapes, h.num_anchors,
+                           h.num_classes, h.image_size)
+
+
+@pytest.mark.parametrize("fixture,model_yaml,inf_yaml", CASES, ids=[c[0] for c in CASES])
+def test_predictor_matches_reference(fixture, model_yaml, inf_yaml):
+    g = Golden(os.path.join(GOLDEN, fixture + ".npz"))
+    cfg = config.setup_config(M + model_yaml, I + inf_yaml)
+    ho = g.head_outputs().to("cuda")
+    n = g.spec["runs"]
+    if cfg.PROBABILISTIC_INFERENCE.INFERENCE_MODE == "ensembles":
+        members = [FakeModel(ho, [r]) for r in range(n)]
+        pred = pinf.build_predictor(cfg, model=members[0], model_list=members)
+    else:
+        pred = pinf.build_predictor(cfg, model=FakeModel(ho, list(range(n))))
+    assert isinstance(pred, pinf.RetinaNetProbabilisticPredictor)
+    pred.eps_fn = g.eps_source()
+    h, w = g.meta["image"]
+    input_im = [{"image": torch.zeros((3, h, w), device="cuda"), "height": g.meta["out"][0], "width": g.meta["out"][1],
+                 "image_id": g.meta["seed"]}]
+    res = pred(input_im)
+    assert res.image_size == tuple(g.meta["out"])
+    assert res.pred_classes.dtype == torch.int64
+    assert torch.equal(res.pred_classes.cpu(), g.t("pred_classes"))
+    assert_close(res.pred_boxes.tensor.cpu(), g.t("pred_boxes"), "boxes")
+    assert_close(res.pred_boxes_covariance.cpu(), g.t("pred_boxes_covariance"), "cov")
+    assert_close(res.scores.cpu(), g.t("scores"), "scores", 2e-6, 1e-7)
+    assert_close(res.pred_cls_probs.cpu(), g.t("pred_cls_probs"), "probs", 2e-6, 1e-7)
+    js = inference_utils.instances_to_json(res, g.meta["seed"], {i: i + 1 for i in range(7)})
+    ref = json.loads(str(g.z["json"]))
+    assert [d["category_id"] for d in js] == [d["category_id"] for d in ref]
+    for a, b in zip(js, ref):
+        assert_close(a["bbox"], b["bbox"], "json bbox")
+        assert_close(a["bbox_covar"], b["bbox_covar"], "json cov")
+    # the device-side records (multi-GPU gather payload) carry the same JSON
+    det = pred.last_detections
+    js2 = inference_utils.records_to_json(det.records, det.count(), g.meta["seed"], 7, {i: i + 1 for i in range(7)})
+    assert len(js2) == len(ref)
+    for a, b in zip(js2, ref):
+        assert a["category_id"] == b["category_id"]
+        assert_close(a["bbox"], b["bbox"], "rec bbox")
+        assert_close(a["bbox_covar"], b["bbox_covar"], "rec cov")
+
+
+def test_anchorwise_surface_returns_reference_tuple():
+    """retinanet_probabilistic_inference (PI:178-388) returns (boxes, cov, prob, classes int64, prob vectors)."""
+    g = Golden(os.path.join(GOLDEN, "cfg1_standard_nms_plain_s11.npz"))
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x.yaml", I + "standard_nms.yaml")
+    pred = pinf.build_predictor(cfg, model=FakeModel(g.head_outputs().to("cuda"), [0]))
+    h, w = g.meta["image"]
+    boxes, cov, prob, cls, pvec = pred.retinanet_probabilistic_inference([{"image": torch.zeros((3, h, w), device="cuda")}])
+    assert cov == [] and cls.dtype == torch.int64                    # plain model: PI:381
+    assert_close(boxes.cpu(), g.t("aw0_boxes"), "boxes")
+    assert torch.equal(cls.cpu(), g.t("aw0_cls"))
+    assert_close(prob.cpu(), g.t("aw0_prob"), "prob", 2e-6, 1e-7)
+    assert pvec.shape == (boxes.shape[0], 7)
+
+
+def test_end_to_end_with_the_torch_model():
+    """build_predictor(cfg) with the real (random-init) ResNet-50-FPN + probabilistic head: runs, returns well-formed
+    Instances (random-init weights give few or no detections)."""
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml")
+    cfg.PROBABILISTIC_INFERENCE.MC_DROPOUT.NUM_RUNS = 3
+    torch.manual_seed(0)
+    pred = pinf.build_predictor(cfg)
+    img = torch.randint(0, 256, (3, 180, 250), dtype=torch.uint8, device="cuda")
+    res = pred([{"image": img, "height": 360, "width": 500, "image_id": 5}])
+    m = len(res)
+    assert res.image_size == (360, 500) and m <= 100
+    assert res.pred_boxes.tensor.shape == (m, 4) and res.pred_boxes_covariance.shape == (m, 4, 4)
+    assert res.pred_cls_probs.shape == (m, 7) and res.pred_classes.dtype == torch.int64
+    assert bool(torch.isfinite(res.pred_boxes.tensor).all())
+    inference_utils.instances_to_json(res, 5, {i: i + 1 for i in range(7)})
