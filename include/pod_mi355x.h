@@ -198,6 +198,26 @@ int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_total, const i
                            float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,
                            pod_stream_t stream);
 
+/* ---- post-NMS ensemble merge ---------------------------------------------------
+ * Replaces: general_black_box_ensembles_post_processing IU:165-289 (callers PI:444-481 MC-dropout post-NMS,
+ * PI:506-534 ensembles post-NMS).
+ * pod_ensemble_append: appends rows keep[0:n_keep) of one member's standard-NMS result (IU:42-53) to the
+ *   concatenated member arrays (torch.cat IU:191-196); `total` (dev int32, zero before the first member) is the
+ *   running row count; cov == NULL appends zeros.
+ * pod_ensemble_merge: sequential same-class clustering IU:203-215 (greedy sweep in index order, IoU >= affinity),
+ *   then per-cluster mean box, residual covariance / (m-1) + mean member covariance, mean prob vector IU:223-247
+ *   and score/class = max of the merged prob vector IU:262-263.  seeds/n_seeds: dev int32[capacity] / int32.
+ *   out_*: dev, `capacity` rows (one per cluster).  The second NMS (IU:269-274) is pod_nms_cluster on the output
+ *   with n_total = n_seeds, then pod_finalize gathers through its keep list. */
+int pod_ensemble_append(const PodConfig* cfg, const int32_t* keep, const int32_t* n_keep, const float* boxes, const float* cov,
+                        const int32_t* classes, const float* probs, int32_t capacity,
+                        float* dst_boxes, float* dst_cov, int32_t* dst_classes, float* dst_probs, int32_t* total,
+                        pod_stream_t stream);
+int pod_ensemble_merge(const PodConfig* cfg, const int32_t* m_total, int32_t capacity, const float* boxes, const float* cov,
+                       const int32_t* classes, const float* probs, int32_t* seeds, int32_t* n_seeds,
+                       float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,
+                       pod_stream_t stream);
+
 /* ---- K7  finalize --------------------------------------------------------------------------
  * Replaces: the keep-gather of general_standard_nms_postprocessing IU:42-53 (when `keep` is
  * non-NULL rows are gathered through it; cov == NULL gives the zeros of IU:52-53) and

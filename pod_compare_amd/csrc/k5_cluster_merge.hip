@@ -242,6 +242,7 @@ struct K6Params {
     const int32_t* classes;
     const float* probs;
     int32_t K, n_capacity;
+    int32_t ensemble_rule;   // 0: anchor statistics (IoU > aff, IU:102 singleton rule); 1: black-box ensembles (IoU >= aff, IU:211-247)
     float aff;
     float* out_boxes;
     float* out_cov;
@@ -266,9 +267,11 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
     double acc[2 + 4 + POD_MAX_CLASSES + 16];
 #pragma unroll
     for (int q = 0; q < 22 + POD_MAX_CLASSES; ++q) acc[q] = 0.0;
+    const bool ens = P.ensemble_rule != 0;
     for (int j = tid; j < n; j += 256) {
         const Box bj = load_box(P.boxes, j);
-        if (!(iou_pair(bc, bj) > P.aff)) continue;                    // IU:91-92
+        const float iou = iou_pair(bc, bj);
+        if (!(ens ? iou >= P.aff : iou > P.aff)) continue;            // IU:91-92 (>) / IU:211-212 (>=)
         acc[0] += 1.0;                                                // IU:102 counts every IoU member
         if (P.classes[j] != ccls) continue;                           // IU:104-106
         acc[1] += 1.0;
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
     }
     block_sum<22 + POD_MAX_CLASSES>(acc, s_red);
     const double m_all = acc[0], m = acc[1];
-    const bool cluster = m_all >= 2.0 && m >= 1.0;
+    const bool cluster = ens ? (m >= 1.0) : (m_all >= 2.0 && m >= 1.0);   // IU:226-247: a 1-member cluster is its own mean
     // the reference forms the mean in fp32 and subtracts it from fp32 boxes (IU:112-114)
     float mu[4] = {0, 0, 0, 0};
     if (cluster)
@@ -292,7 +295,8 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
     if (cluster) {
         for (int j = tid; j < n; j += 256) {
             const Box bj = load_box(P.boxes, j);
-            if (!(iou_pair(bc, bj) > P.aff)) continue;
+            const float iou = iou_pair(bc, bj);
+            if (!(ens ? iou >= P.aff : iou > P.aff)) continue;
             if (P.classes[j] != ccls) continue;
             const float r[4] = {bj.x1 - mu[0], bj.y1 - mu[1], bj.x2 - mu[2], bj.y2 - mu[3]};
             int q = 0;
@@ -335,6 +339,95 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
         P.out_scores[c] = op[bk];
         P.out_classes[c] = bk;
     }
+}
+
+// ---- post-NMS ensemble merge: sequential same-class clustering IU:203-215 ------------------------
+// Box i seeds a cluster unless an EARLIER seed's cluster already contains it (IoU >= aff and same class): a greedy sweep
+// in index order.  One 1024-thread workgroup, LDS "covered" bitmap, thread 0 finds the next uncovered index.
+struct KSeedParams {
+    const int32_t* m_total;
+    int32_t capacity;
+    float aff;
+    const float* boxes;
+    const int32_t* classes;
+    int32_t* seeds;
+    int32_t* n_seeds;
+};
+
+__global__ void __launch_bounds__(1024) k_ensemble_seeds(const KSeedParams P) {
+    __shared__ unsigned long long s_cov[POD_MAX_CANDIDATES / 64];
+    __shared__ int s_cur, s_n;
+    const int tid = threadIdx.x;
+    const int M = min(*P.m_total, P.capacity);
+    for (int i = tid; i < POD_MAX_CANDIDATES / 64; i += 1024) s_cov[i] = 0ull;
+    if (tid == 0) {
+        s_cur = -1;
+        s_n = 0;
+    }
+    __syncthreads();
+    const int nwords = (M + 63) >> 6;
+    while (true) {
+        if (tid == 0) {
+            int next = -1;
+            const int start = s_cur + 1;
+            for (int w = start >> 6; w < nwords; ++w) {
+                unsigned long long live = ~s_cov[w];
+                if (w == (start >> 6)) live &= ~0ull << (start & 63);
+                if (live) {
+                    const int cand = (w << 6) + __ffsll((long long)live) - 1;
+                    if (cand < M) next = cand;
+                    break;
+                }
+            }
+            if (next >= 0) {
+                P.seeds[s_n] = next;
+                s_n = s_n + 1;
+            }
+            s_cur = next;
+        }
+        __syncthreads();
+        const int i = s_cur;
+        if (i < 0) break;
+        const Box bi = load_box(P.boxes, i);
+        const int ci = P.classes[i];
+        for (int j = i + 1 + tid; j < M; j += 1024)
+            if (P.classes[j] == ci && iou_pair(bi, load_box(P.boxes, j)) >= P.aff) atomicOr(&s_cov[j >> 6], 1ull << (j & 63));
+        __syncthreads();
+    }
+    if (tid == 0) *P.n_seeds = s_n;
+}
+
+// Appends the rows `keep[0:n_keep)` of one ensemble member's candidate arrays to the concatenated member-detection
+// arrays (torch.cat of IU:191-196); `total` is the running row count on the device.
+struct KAppendParams {
+    const int32_t* keep;
+    const int32_t* n_keep;
+    const float* boxes;
+    const float* cov;      // may be null -> zeros (IU:52-53)
+    const int32_t* classes;
+    const float* probs;
+    int32_t K, capacity;
+    float* dst_boxes;
+    float* dst_cov;
+    int32_t* dst_classes;
+    float* dst_probs;
+    int32_t* total;
+};
+
+__global__ void __launch_bounds__(POD_MAX_DETECTIONS) k_append_rows(const KAppendParams P) {
+    const int t = threadIdx.x;
+    const int n = *P.n_keep;
+    const int base = *P.total;
+    __syncthreads();
+    if (t < n && base + t < P.capacity) {
+        const int src = P.keep[t], dst = base + t;
+        *reinterpret_cast<float4*>(P.dst_boxes + (size_t)dst * 4) = *reinterpret_cast<const float4*>(P.boxes + (size_t)src * 4);
+        for (int e = 0; e < 16; ++e) P.dst_cov[(size_t)dst * 16 + e] = P.cov ? P.cov[(size_t)src * 16 + e] : 0.0f;
+        P.dst_classes[dst] = P.classes[src];
+        for (int k = 0; k < P.K; ++k) P.dst_probs[(size_t)dst * P.K + k] = P.probs[(size_t)src * P.K + k];
+    }
+    __syncthreads();
+    if (t == 0) *P.total = min(base + n, P.capacity);
 }
 
 struct K7Params {
@@ -482,9 +575,46 @@ extern "C" int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_tot
     if (cfg->max_detections < 1 || cfg->max_detections > POD_MAX_DETECTIONS) return POD_E_INVALID;
     pod::K6Params P;
     P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
-    P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh;
+    P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.ensemble_rule = 0;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
     hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_ensemble_append(const PodConfig* cfg, const int32_t* keep, const int32_t* n_keep, const float* boxes,
+                                   const float* cov, const int32_t* classes, const float* probs, int32_t capacity,
+                                   float* dst_boxes, float* dst_cov, int32_t* dst_classes, float* dst_probs, int32_t* total,
+                                   pod_stream_t stream) {
+    if (!cfg || !keep || !n_keep || !boxes || !classes || !probs || !dst_boxes || !dst_cov || !dst_classes || !dst_probs || !total)
+        return POD_E_INVALID;
+    if (capacity < 1 || capacity > POD_MAX_CANDIDATES || cfg->num_classes < 1 || cfg->num_classes > POD_MAX_CLASSES) return POD_E_INVALID;
+    pod::KAppendParams P;
+    P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs; P.K = cfg->num_classes;
+    P.capacity = capacity; P.dst_boxes = dst_boxes; P.dst_cov = dst_cov; P.dst_classes = dst_classes; P.dst_probs = dst_probs; P.total = total;
+    hipLaunchKernelGGL(pod::k_append_rows, dim3(1), dim3(POD_MAX_DETECTIONS), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_ensemble_merge(const PodConfig* cfg, const int32_t* m_total, int32_t capacity, const float* boxes,
+                                  const float* cov, const int32_t* classes, const float* probs, int32_t* seeds, int32_t* n_seeds,
+                                  float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,
+                                  pod_stream_t stream) {
+    if (!cfg || !m_total || !boxes || !cov || !classes || !probs || !seeds || !n_seeds || !out_boxes || !out_cov || !out_scores ||
+        !out_classes || !out_probs)
+        return POD_E_INVALID;
+    if (capacity < 1 || capacity > POD_MAX_CANDIDATES || cfg->num_classes < 1 || cfg->num_classes > POD_MAX_CLASSES) return POD_E_INVALID;
+    pod::KSeedParams S;
+    S.m_total = m_total; S.capacity = capacity; S.aff = cfg->affinity_thresh; S.boxes = boxes; S.classes = classes; S.seeds = seeds;
+    S.n_seeds = n_seeds;
+    hipLaunchKernelGGL(pod::k_ensemble_seeds, dim3(1), dim3(1024), 0, (hipStream_t)stream, S);
+    POD_CHECK_LAUNCH();
+    pod::K6Params P;
+    P.n_total = m_total; P.keep = seeds; P.n_keep = n_seeds; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
+    P.K = cfg->num_classes; P.n_capacity = capacity; P.aff = cfg->affinity_thresh; P.ensemble_rule = 1;
+    P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
+    hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(capacity), dim3(256), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

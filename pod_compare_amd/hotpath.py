@@ -204,6 +204,33 @@ class HotPath:
         """False reproduces the reference's `all_predicted_boxes_covariance = []` (PI:381)."""
         return self.cov_dims > 0 or self.n_runs > 1
 
+    def nms(self):
+        """K4 on the candidate list: keep[:max_detections] (PI:554-560, IU:31-36, IU:83-89)."""
+        P = hip.ptr
+        hip.check(self.lib.pod_nms_cluster(self.cfg, P(self.n_total), self.n_cap, P(self.boxes), P(self.cand_score),
+                                           P(self.cand_class), P(self.keep), P(self.n_keep), P(self.nms_scratch),
+                                           hip.current_stream()), "pod_nms_cluster")
+
+    def new_detections(self, out_size) -> DeviceDetections:
+        K, md, dev = self.p.num_classes, hip.POD_MAX_DETECTIONS, self.device
+        return DeviceDetections(
+            (int(out_size[0]), int(out_size[1])),
+            torch.empty((md, 4), dtype=torch.float32, device=dev), torch.empty((md, 4, 4), dtype=torch.float32, device=dev),
+            torch.empty((md,), dtype=torch.float32, device=dev), torch.empty((md,), dtype=torch.int32, device=dev),
+            torch.empty((md, K), dtype=torch.float32, device=dev), torch.empty((md, 6 + K + 16), dtype=torch.float32, device=dev),
+            torch.empty((), dtype=torch.int32, device=dev))
+
+    def finalize(self, keep, n_rows, boxes, cov, scores, classes, probs, image_size, out_size) -> DeviceDetections:
+        """K7: gather through `keep` (or identity), rescale to the output resolution, records (IU:42-53, :374-425, :428-502)."""
+        P = hip.ptr
+        out = self.new_detections(out_size)
+        sx, sy = out_size[1] / image_size[1], out_size[0] / image_size[0]   # IU:394-396
+        hip.check(self.lib.pod_finalize(self.cfg, P(keep), P(n_rows), P(boxes), P(cov), P(scores), P(classes), P(probs), sx, sy,
+                                        float(out_size[0]), float(out_size[1]), P(out.boxes), P(out.cov), P(out.scores),
+                                        P(out.classes), P(out.probs), P(out.records), P(out.n_det), hip.current_stream()),
+                  "pod_finalize")
+        return out
+
     def postprocess(self, mode: str, image_size, out_size, box_merge_mode: str = "bayesian_inference",
                     cls_merge_mode: str = "max_score") -> DeviceDetections:
         """K4 (+K5/K6) + K7."""
@@ -212,8 +239,7 @@ class HotPath:
         lib, cfg, st, P = self.lib, self.cfg, hip.current_stream(), hip.ptr
         K, md = self.p.num_classes, hip.POD_MAX_DETECTIONS
         dev = self.device
-        hip.check(lib.pod_nms_cluster(cfg, P(self.n_total), self.n_cap, P(self.boxes), P(self.cand_score), P(self.cand_class),
-                                      P(self.keep), P(self.n_keep), P(self.nms_scratch), st), "pod_nms_cluster")
+        self.nms()
         cov_in = self.cov if self.has_covariance else None
         if mode == "bayes_od":
             if cov_in is None:
@@ -232,17 +258,7 @@ class HotPath:
         else:   # standard NMS (also the pre-NMS MC-dropout / ensemble modes): gather through keep
             src = (self.keep, self.boxes, cov_in, self.cand_score, self.cand_class, self.cand_probs)
         keep, b, c, s, cl, pr = src
-        out = DeviceDetections(
-            (int(out_size[0]), int(out_size[1])),
-            torch.empty((md, 4), dtype=torch.float32, device=dev), torch.empty((md, 4, 4), dtype=torch.float32, device=dev),
-            torch.empty((md,), dtype=torch.float32, device=dev), torch.empty((md,), dtype=torch.int32, device=dev),
-            torch.empty((md, K), dtype=torch.float32, device=dev), torch.empty((md, 6 + K + 16), dtype=torch.float32, device=dev),
-            torch.empty((), dtype=torch.int32, device=dev))
-        sx, sy = out_size[1] / image_size[1], out_size[0] / image_size[0]   # IU:394-396
-        hip.check(lib.pod_finalize(cfg, P(keep), P(self.n_keep), P(b), P(c), P(s), P(cl), P(pr), sx, sy,
-                                   float(out_size[0]), float(out_size[1]), P(out.boxes), P(out.cov), P(out.scores),
-                                   P(out.classes), P(out.probs), P(out.records), P(out.n_det), st), "pod_finalize")
-        return out
+        return self.finalize(keep, self.n_keep, b, c, s, cl, pr, image_size, out_size)
 
     # ------------------------------------------------------------------------------------------
     def run(self, mode: str, cls, delta, cls_var=None, reg_var=None, *, image_size, out_size,
@@ -264,3 +280,53 @@ class HotPath:
                 eps_prop = eps_fn((self.p.prop_num_samples, n, 4)).to(self.device).contiguous()
         self.decode(lv, eps_prop)
         return self.postprocess(mode, image_size, out_size, box_merge_mode, cls_merge_mode)
+
+
+class PostNmsEnsemble:
+    """Post-NMS merge of ensemble members / MC-dropout runs: PI:444-481, PI:506-534 ->
+    general_black_box_ensembles_post_processing IU:165-289.  Every member goes through the single-run path
+    (K1..K4 with N = 1) and its kept rows are appended on the device; the cluster sweep, the per-cluster moments and
+    the second NMS then run once."""
+
+    def __init__(self, hp: HotPath, n_members: int):
+        assert hp.n_runs == 1, "members are processed one run at a time"
+        self.hp, self.n_members = hp, int(n_members)
+        self.cap = self.n_members * hp.p.max_detections
+        if self.cap > hip.POD_MAX_CANDIDATES:
+            raise hip.PodError("too many member detections for the post-NMS merge: {}".format(self.cap))
+        dev, K, cap = hp.device, hp.p.num_classes, self.cap
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        self.m_boxes, self.m_cov, self.m_classes, self.m_probs = f32(cap, 4), f32(cap, 4, 4), i32(cap), f32(cap, K)
+        self.total = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seeds, self.n_seeds = i32(cap), i32(1)
+        self.c_boxes, self.c_cov, self.c_scores, self.c_classes, self.c_probs = f32(cap, 4), f32(cap, 4, 4), f32(cap), i32(cap), f32(cap, K)
+        self.keep, self.n_keep = i32(hip.POD_MAX_DETECTIONS), i32(1)
+        self.scratch = torch.empty(hp.lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+
+    def run(self, members, *, image_size, out_size, eps_fn: Optional[Callable] = None) -> DeviceDetections:
+        """members: iterable of (cls, delta, cls_var, reg_var) per-level tensor lists with N = 1."""
+        hp, P, st = self.hp, hip.ptr, hip.current_stream()
+        self.total.zero_()
+        for cls, delta, cls_var, reg_var in members:
+            eps_cls = eps_prop = None
+            if eps_fn is not None and hp.has_cls_var:
+                A, K = hp.p.num_anchors, hp.p.num_classes
+                eps_cls = [eps_fn((hp.p.cls_var_num_samples, h * w * A, K)).to(hp.device).contiguous() for h, w in hp.shapes]
+            lv = hp.candidates(cls, delta, cls_var, reg_var, eps_cls)
+            if eps_fn is not None and hp.cov_dims > 0:
+                n = int(hp.n_total.item())
+                if n > 0:
+                    eps_prop = eps_fn((hp.p.prop_num_samples, n, 4)).to(hp.device).contiguous()
+            hp.decode(lv, eps_prop)
+            hp.nms()
+            hip.check(hp.lib.pod_ensemble_append(hp.cfg, P(hp.keep), P(hp.n_keep), P(hp.boxes), P(hp.cov) if hp.has_covariance else None,
+                                                 P(hp.cand_class), P(hp.cand_probs), self.cap, P(self.m_boxes), P(self.m_cov),
+                                                 P(self.m_classes), P(self.m_probs), P(self.total), st), "pod_ensemble_append")
+        hip.check(hp.lib.pod_ensemble_merge(hp.cfg, P(self.total), self.cap, P(self.m_boxes), P(self.m_cov), P(self.m_classes),
+                                            P(self.m_probs), P(self.seeds), P(self.n_seeds), P(self.c_boxes), P(self.c_cov),
+                                            P(self.c_scores), P(self.c_classes), P(self.c_probs), st), "pod_ensemble_merge")
+        hip.check(hp.lib.pod_nms_cluster(hp.cfg, P(self.n_seeds), self.cap, P(self.c_boxes), P(self.c_scores), P(self.c_classes),
+                                         P(self.keep), P(self.n_keep), P(self.scratch), st), "pod_nms_cluster")      # IU:269-274
+        return hp.finalize(self.keep, self.n_keep, self.c_boxes, self.c_cov, self.c_scores, self.c_classes, self.c_probs,
+                           image_size, out_size)

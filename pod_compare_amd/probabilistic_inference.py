@@ -19,7 +19,8 @@ CPU fallback.  Differences from the reference, all documented in DESIGN.md:
   * MC dropout is a flag on the model, not `model.train()` (SURVEY Q3);
   * zero candidates give an empty `Instances` for every model type (the reference raises for reg-var
     models, SURVEY Q12); a degenerate BayesOD cluster falls back to its centre;
-  * post-NMS ensemble merges (PI:444-481, PI:506-534) are not implemented yet.
+  * post-NMS ensemble merges (PI:444-481, PI:506-534) run every member through the N = 1 path, then the HIP
+    restatement of general_black_box_ensembles_post_processing (IU:165-289).
 """
 from abc import ABC, abstractmethod
 from typing import Callable, List, Optional
@@ -159,6 +160,19 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         self.last_detections = det
         return detections_to_instances(det)
 
+    def _run_post_nms(self, input_im, members: List[HeadOutputs]) -> Instances:
+        """Per-member standard NMS, then general_black_box_ensembles_post_processing (IU:165-289)."""
+        hp = self._path_for(members[0])
+        self.last_path = hp
+        key = ("post_nms", id(hp), len(members))
+        if key not in self._paths:
+            self._paths[key] = hotpath.PostNmsEnsemble(hp, len(members))
+        image_size, out = self._sizes(input_im, members[0])
+        det = self._paths[key].run([(m.cls, m.delta, m.cls_var, m.reg_var) for m in members], image_size=image_size, out_size=out,
+                                   eps_fn=self.eps_fn)
+        self.last_detections = det
+        return detections_to_instances(det)
+
     # -- reference surface ---------------------------------------------------------------------------
     def retinanet_probabilistic_inference(self, input_im, outputs=None, ensemble_inference=False, outputs_list=None):
         """PI:178-388.  Returns (boxes (n,4), covariances (n,4,4) or [], scores (n,), class ids (n,) int64,
@@ -187,16 +201,24 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
     def post_processing_mc_dropout_ensembles(self, input_im):
         if self.cfg.PROBABILISTIC_INFERENCE.ENSEMBLES_DROPOUT.BOX_MERGE_MODE == "pre_nms":     # PI:442-443
             return self._run("standard_nms", input_im, self._head_outputs(input_im))
-        raise NotImplementedError("post-NMS MC-dropout merge (PI:444-481, IU:165-289) is the 'next' row f-3")
+        ho = self._head_outputs(input_im)                                                      # PI:445-451: N runs, merged post-NMS
+        return self._run_post_nms(input_im, [run_slice(ho, r) for r in range(ho.num_runs)])
 
     def post_processing_ensembles(self, input_im, model_dict):
         if self.cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.BOX_MERGE_MODE == "pre_nms":             # PI:495-505
             members = [m(input_im[0]["image"]) for m in model_dict]
             return self._run("standard_nms", input_im, stack_members(members))
-        raise NotImplementedError("post-NMS ensemble merge (PI:506-534, IU:165-289) is the 'next' row f-3")
+        return self._run_post_nms(input_im, [m(input_im[0]["image"]) for m in model_dict])     # PI:506-534
 
     def post_processing_bayes_od(self, input_im):
         return self._run("bayes_od", input_im, self._head_outputs(input_im))
+
+
+def run_slice(ho: HeadOutputs, run: int) -> HeadOutputs:
+    """Run `run` of a batched HeadOutputs as an N = 1 HeadOutputs (views, no copy: runs are contiguous slabs)."""
+    sel = lambda lst: None if lst is None else [t[run:run + 1] for t in lst]
+    return HeadOutputs(sel(ho.cls), sel(ho.delta), sel(ho.cls_var), sel(ho.reg_var), ho.anchors, ho.shapes, ho.num_anchors,
+                       ho.num_classes, ho.image_size)
 
 
 def stack_members(members: List[HeadOutputs]) -> HeadOutputs:

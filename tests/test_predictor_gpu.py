@@ -21,6 +21,9 @@ CASES = [  # (fixture, model yaml, inference yaml)  = BASELINE.json configs[0..4
     ("cfg4_anchor_stats_plain_s41", "retinanet_R_50_FPN_1x.yaml", "anchor_statistics.yaml"),
     ("cfg5_ensembles_pre_nms_s51", "retinanet_R_50_FPN_1x_reg_cls_var.yaml", "ensembles_pre_nms.yaml"),
     ("mc_dropout_plain_pre_nms_s81", "retinanet_R_50_FPN_1x_dropout.yaml", "mc_dropout_ensembles_pre_nms.yaml"),
+    # post-NMS merges (README "Black Box" rows)
+    ("post_nms_ensembles_s141", "retinanet_R_50_FPN_1x_reg_cls_var.yaml", "ensembles_post_nms.yaml"),
+    ("post_nms_mc_dropout_s151", "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", "mc_dropout_ensembles_post_nms.yaml"),
 ]
 
 
@@ -46,6 +49,8 @@ def test_predictor_matches_reference(fixture, model_yaml, inf_yaml):
     cfg = config.setup_config(M + model_yaml, I + inf_yaml)
     ho = g.head_outputs().to("cuda")
     n = g.spec["runs"]
+    if cfg.PROBABILISTIC_INFERENCE.MC_DROPOUT.ENABLE:
+        cfg.PROBABILISTIC_INFERENCE.MC_DROPOUT.NUM_RUNS = n      # the fixtures use fewer runs than the YAML's 10
     if cfg.PROBABILISTIC_INFERENCE.INFERENCE_MODE == "ensembles":
         members = [FakeModel(ho, [r]) for r in range(n)]
         pred = pinf.build_predictor(cfg, model=members[0], model_list=members)
