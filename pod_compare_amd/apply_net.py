@@ -64,6 +64,52 @@ def results_json(ids: Sequence[int], counts: torch.Tensor, records: torch.Tensor
     return out
 
 
+def _run_ensemble_per_gpu(cfg, args, rank, world):
+    """Config 5 (`ensembles_pre_nms.yaml`): one ensemble member per rank, point-to-point exchange of the dense head
+    tensors onto the image's merge rank (= the rank that owns the image in the sharded order), K1..K7 there."""
+    from . import anchors, ensemble_dist, modeling, synthetic
+    from .probabilistic_inference import RetinaNetProbabilisticPredictor, build_model
+    seeds = list(cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.RANDOM_SEED_NUMS)
+    M = len(seeds)
+    if world < M:
+        raise SystemExit("--ensemble-per-gpu needs at least %d ranks (one per ensemble member), got %d" % (M, world))
+    model = None
+    if rank < M:
+        torch.manual_seed(int(seeds[rank]))          # PI:59-77 loads random_seed_<s> checkpoints; random-init stands in
+        model = build_model(cfg)
+    cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.BOX_MERGE_MODE = "pre_nms"
+    predictor = RetinaNetProbabilisticPredictor(cfg, model=model if model is not None else object(), model_list=[object()] * M)
+    if model is None:
+        # merge-only rank: the predictor only needs the model's test-time attributes
+        predictor.model = build_model(cfg)
+    dev = torch.device(cfg.MODEL.DEVICE)
+    net_hw = anchors.resize_shortest_edge(720, 1280, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+    recs, cnts = [], []
+    layout = stacked = like = None
+    with torch.no_grad():
+        for i in range(args.num_images):
+            dst = ensemble_dist.merge_rank(i, world)
+            frame = synthetic.synthetic_frame(i, device=dev)
+            image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+            packed = None
+            ho = None
+            if rank < M:
+                ho = model(image)
+            if layout is None:
+                like = ho if ho is not None else predictor.model(image)
+                layout = ensemble_dist.MemberLayout.of(like)
+                stacked = torch.empty((M, layout.total), dtype=torch.float32, device=dev)
+            if rank < M:
+                packed = layout.pack(ho)
+            ensemble_dist.exchange_members(packed, stacked if rank == dst else None, M, dst, rank)
+            if rank == dst:
+                input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
+                predictor._run("standard_nms", input_im, layout.views(stacked, like))     # PI:502-505
+                recs.append(predictor.last_detections.records)
+                cnts.append(predictor.last_detections.n_det)
+    return recs, cnts
+
+
 def main(argv=None):
     from . import synthetic
     from .config import setup_config
@@ -75,6 +121,8 @@ def main(argv=None):
     ap.add_argument("--num-images", type=int, default=8)
     ap.add_argument("--random-seed", type=int, default=0)
     ap.add_argument("--output", default="coco_instances_results.json")
+    ap.add_argument("--ensemble-per-gpu", action="store_true",
+                    help="BASELINE config 5: rank s < M runs ensemble member s, dense pre-NMS tensors meet on a rotating merge rank")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,14 +132,16 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     cfg = setup_config(args.config_file, args.inference_config, args.random_seed)
     cfg.MODEL.DEVICE = "cuda:%d" % local_rank
-    torch.manual_seed(args.random_seed)
-    predictor = build_predictor(cfg)
     K = cfg.MODEL.RETINANET.NUM_CLASSES
     from . import modeling
     mine = shard_indices(args.num_images, rank, world)
     recs, cnts = [], []
+    if args.ensemble_per_gpu:
+        recs, cnts = _run_ensemble_per_gpu(cfg, args, rank, world)
+    torch.manual_seed(args.random_seed)
+    predictor = build_predictor(cfg) if not args.ensemble_per_gpu else None
     with torch.no_grad():
-        for i in mine:
+        for i in (mine if predictor is not None else []):
             frame = synthetic.synthetic_frame(i, device=cfg.MODEL.DEVICE)
             image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
             input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]

@@ -131,30 +131,38 @@ class HotPath:
         c.philox_seed = p.philox_seed
         return c
 
+    def _run_strided(self, name, l, t, c):
+        """A level tensor (n_runs, A*c, H, W): every run a contiguous NCHW slab; the run stride is free (batched MC
+        runs: A*c*H*W; ensemble members gathered into packed per-member buffers: the packed size)."""
+        h, w = self.shapes[l]
+        shape = (self.n_runs, self.p.num_anchors * c, h, w)
+        ok = t.dtype == torch.float32 and tuple(t.shape) == shape and tuple(t.stride()[1:]) == (h * w, w, 1) and t.device == self.device
+        if not ok:
+            raise hip.PodError("{}[{}]: expected fp32 {} with contiguous runs on {}, got {} {} strides {} on {}".format(
+                name, l, shape, self.device, t.dtype, tuple(t.shape), tuple(t.stride()), t.device))
+        return t.data_ptr(), (t.stride(0) if self.n_runs > 1 else shape[1] * h * w)
+
     def _levels(self, cls, delta, cls_var, reg_var, eps_cls):
         A, K, D = self.p.num_anchors, self.p.num_classes, self.cov_dims
         arr = self._levels_t()
         for l, (h, w) in enumerate(self.shapes):
-            for name, t, c in (("cls", cls[l], K), ("delta", delta[l], 4)):
-                assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n_runs, A * c, h, w), \
-                    "{}[{}]: expected contiguous fp32 {}, got {} {}".format(name, l, (self.n_runs, A * c, h, w), t.dtype, tuple(t.shape))
             lv = arr[l]
-            lv.cls, lv.delta = cls[l].data_ptr(), delta[l].data_ptr()
-            lv.run_stride_cls, lv.run_stride_delta = A * K * h * w, A * 4 * h * w
+            lv.cls, lv.run_stride_cls = self._run_strided("cls", l, cls[l], K)
+            lv.delta, lv.run_stride_delta = self._run_strided("delta", l, delta[l], 4)
             lv.cls_var = lv.reg_var = lv.eps_cls = None
             lv.run_stride_reg = 0
             if self.has_cls_var:
-                assert tuple(cls_var[l].shape) == (self.n_runs, A * K, h, w) and cls_var[l].is_contiguous()
-                lv.cls_var = cls_var[l].data_ptr()
+                lv.cls_var, rs = self._run_strided("cls_var", l, cls_var[l], K)
+                if rs != lv.run_stride_cls:
+                    raise hip.PodError("cls_var[{}] must share the run stride of cls".format(l))
             if D > 0:
-                assert tuple(reg_var[l].shape) == (self.n_runs, A * D, h, w) and reg_var[l].is_contiguous()
-                lv.reg_var = reg_var[l].data_ptr()
-                lv.run_stride_reg = A * D * h * w
+                lv.reg_var, lv.run_stride_reg = self._run_strided("reg_var", l, reg_var[l], D)
             if eps_cls is not None:
                 e = eps_cls[l]
                 assert tuple(e.shape) == (self.p.cls_var_num_samples, h * w * A, K) and e.is_contiguous() and e.device == self.device
                 lv.eps_cls = e.data_ptr()
             lv.H, lv.W, lv.anchor_base = h, w, self.anchor_base[l]
+        self._keep_inputs = (cls, delta, cls_var, reg_var)
         return arr
 
     # ------------------------------------------------------------------------------------------

@@ -133,3 +133,50 @@ def test_two_rank_gather_restores_image_order(tmp_path, num_images):
     assert len(out["js"]) == sum(i % 5 for i in range(num_images))
     first = [d for d in out["js"] if d["image_id"] == 3]
     assert [d["bbox"][1] for d in first] == [0.0, 1.0, 2.0] and first[0]["category_id"] == 4
+
+
+# ---- config 5 topology: one seed per rank, dense pre-NMS exchange ------------------------------------------------
+
+def test_member_layout_roundtrip():
+    from pod_compare_amd import ensemble_dist, synthetic
+    ho = synthetic.planted_head_outputs((96, 128), 3, seed=3, num_boxes=4)
+    from pod_compare_amd.probabilistic_inference import run_slice
+    lay = ensemble_dist.MemberLayout.of(ho)
+    assert lay.total % 4 == 0 and all(off % 4 == 0 for off, *_ in lay.offsets.values())
+    stacked = torch.stack([lay.pack(run_slice(ho, r)) for r in range(3)])
+    v = lay.views(stacked, ho)
+    for name in ("cls", "delta", "cls_var", "reg_var"):
+        for a, b in zip(getattr(v, name), getattr(ho, name)):
+            assert a.shape == b.shape and torch.equal(a, b)
+            assert a.stride(0) == lay.total and a[1].is_contiguous()
+
+
+def _exchange_worker(rank, world, port, n_members, tmp):
+    from pod_compare_amd import ensemble_dist, synthetic
+    from pod_compare_amd.probabilistic_inference import run_slice
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ho = synthetic.planted_head_outputs((96, 128), n_members, seed=9, num_boxes=4)      # run s plays member s
+    lay = ensemble_dist.MemberLayout.of(ho)
+    ok = True
+    for image in range(4):
+        dst = ensemble_dist.merge_rank(image, world)
+        packed = lay.pack(run_slice(ho, rank)) + float(image) if rank < n_members else None
+        stacked = torch.zeros((n_members, lay.total)) if rank == dst else None
+        ensemble_dist.exchange_members(packed, stacked, n_members, dst, rank)
+        if rank == dst:
+            v = lay.views(stacked, ho)
+            for name in ("cls", "delta", "cls_var", "reg_var"):
+                for a, b in zip(getattr(v, name), getattr(ho, name)):
+                    ok = ok and torch.equal(a, b + float(image))
+    with open(os.path.join(tmp, "ok_%d" % rank), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ensemble_exchange_three_ranks_two_members(tmp_path):
+    """gloo, world 3, 2 member ranks, merge rank rotating over all 3 (incl. a non-member rank)."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(3, port, 2, str(tmp_path)), nprocs=3, join=True)
+    assert [open(tmp_path / ("ok_%d" % r)).read() for r in range(3)] == ["1", "1", "1"]

@@ -114,3 +114,25 @@ def test_end_to_end_with_the_torch_model():
     assert res.pred_cls_probs.shape == (m, 7) and res.pred_classes.dtype == torch.int64
     assert bool(torch.isfinite(res.pred_boxes.tensor).all())
     inference_utils.instances_to_json(res, 5, {i: i + 1 for i in range(7)})
+
+
+def test_ensemble_members_in_packed_strided_buffer_match_reference():
+    """Config 5 data path on one GPU: members packed into the (M, packed) exchange buffer and handed to K1 as
+    run-strided views (no re-layout) give the reference's result."""
+    from pod_compare_amd import ensemble_dist
+    g = Golden(os.path.join(GOLDEN, "cfg5_ensembles_pre_nms_s51.npz"))
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var.yaml", I + "ensembles_pre_nms.yaml")
+    ho = g.head_outputs().to("cuda")
+    n = g.spec["runs"]
+    lay = ensemble_dist.MemberLayout.of(ho)
+    stacked = torch.stack([lay.pack(pinf.run_slice(ho, r)) for r in range(n)])
+    views = lay.views(stacked, ho)
+    assert views.cls[0].stride(0) == lay.total
+    pred = pinf.build_predictor(cfg, model=FakeModel(ho, [0]), model_list=[object()] * n)
+    pred.eps_fn = g.eps_source()
+    h, w = g.meta["image"]
+    input_im = [{"image": torch.zeros((3, h, w), device="cuda"), "height": g.meta["out"][0], "width": g.meta["out"][1], "image_id": 1}]
+    res = pred._run("standard_nms", input_im, views)
+    assert torch.equal(res.pred_classes.cpu(), g.t("pred_classes"))
+    assert_close(res.pred_boxes.tensor.cpu(), g.t("pred_boxes"), "boxes")
+    assert_close(res.pred_boxes_covariance.cpu(), g.t("pred_boxes_covariance"), "cov")
