@@ -113,14 +113,14 @@ int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
 
 /* ---- K1b score_maybe ------------------------------------------------------------------------
  * Sparse companion of K1's prune mode (native RNG + cls_var head): when `maybe_bits`
- * (dev uint64[pod_maybe_words()], no initialisation needed) is passed to pod_mc_merge_score, the dense pass
+ * (dev uint64[pod_maybe_words()], all zero on entry; pod_score_maybe leaves it zeroed again) is passed to pod_mc_merge_score, the dense pass
  * draws no samples; it writes a bitmap of the anchors that can still reach `score_thresh` under the sampler's
  * hard bound |eps| < 4.9 (an exact superset of the candidates) and this kernel evaluates
  * mean_s sigmoid(logit + eps_s*sigma) (PI:289-295) for those only, appending the keys of the anchors
  * above the threshold to `cand_keys` / `cand_count` exactly as K1 does otherwise. */
 int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels);
 int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
-                    const uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream);
+                    uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream);
 
 /* Zeroes `n` int32 device words on the stream (graph-capturable memset node). */
 int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);

@@ -44,6 +44,9 @@ struct K1Params {
     uint64_t* cand_keys;
     int32_t* cand_count;
     uint64_t* maybe_bits;    // prune mode: bitmap of the anchors that MAY pass the threshold (exact superset); scored by K1b
+    int32_t word_begin[POD_MAX_LEVELS + 1];   // bitmap: level l owns words [word_begin[l], word_begin[l+1]); anchor shape a owns wpa[l] of them
+    int32_t wpa[POD_MAX_LEVELS];              // words per anchor shape = ceil(H*W / 64); bit (a, hw) = word a*wpa + hw/64, bit hw%64
+    int32_t pseg_begin[3 * POD_MAX_LEVELS + 1];   // workgroup ranges of k1_prune_stream (256 threads): [cls pair l..][delta l..][reg l..]
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -171,19 +174,6 @@ __device__ __forceinline__ float4 cls_role(const K1Params& P, const PodLevel& lv
     const float lg[4] = {m[0].x, m[0].y, m[0].z, m[0].w};
     const float vr[4] = {m[1].x, m[1].y, m[1].z, m[1].w};
     float pr[4];
-    if (P.maybe_bits != nullptr) {
-        // Prune mode (native RNG, variance head).  box_muller16() bounds every draw by |eps| < POD_EPS_MAX, so
-        // mean_s sigmoid(logit + eps_s*sigma) <= sigmoid(logit + POD_EPS_MAX*sigma): an (anchor, class) with
-        // logit + POD_EPS_MAX*sigma <= logit(score_thresh) can never become a candidate.  The dense pass only
-        // flags the (few) anchors that may pass; K1b draws the samples for those.  No Philox work here.
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool may = (hw0 + j < HW) && !(P.debug_bits & 4) &&
-                             fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit;
-            pr[j] = may ? 1.0f : 0.0f;
-        }
-        return float4{pr[0], pr[1], pr[2], pr[3]};
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool live = hw0 + j < HW && !(P.debug_bits & 4);
@@ -254,12 +244,7 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
             const float v = lds_probs[kk * 256 + tid];
             best = (v > best) ? v : best;   // torch.max keeps the first maximum; argmax is re-derived in K2b
         }
-        if (P.maybe_bits != nullptr) {
-            // prune mode: this wave's 64 flags ARE one bitmap word; plain store, no atomics, every word of
-            // every cls workgroup is written (so the bitmap needs no clearing between images).
-            const unsigned long long m = __ballot((hw < HW) && best > 0.5f);
-            if ((tid & 63) == 0) P.maybe_bits[((int64_t)P.seg_begin[l] + local_b) * 4 + (tid >> 6)] = m;
-        } else {
+        {
             const bool pass = (hw < HW) && (best > P.score_thresh);
             const unsigned long long m = __ballot(pass);
             if (m != 0ull) {
@@ -274,6 +259,85 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     }
 }
 
+// ---- K1 prune mode: one flat streaming kernel ------------------------------------------------------------------
+// Native RNG + variance head.  box_muller16() bounds every draw by |eps| < POD_EPS_MAX, so
+//     mean_s sigmoid(logit + eps_s*sigma) <= sigmoid(logit + POD_EPS_MAX*sigma):
+// an (anchor, class) with logit + POD_EPS_MAX*sigma <= logit(score_thresh) can never become a candidate.  The dense
+// pass therefore draws nothing: it merges, stores, and sets one bit per anchor that MAY pass (exact superset);
+// K1b samples those.  With no max-over-classes left there is no LDS, no barrier and no class-per-wave shape: every
+// tensor is walked as a flat array, 256 threads x 16 B = 4 KiB contiguous per run per workgroup (the access
+// pattern of a plain streaming merge), logit and log-variance planes side by side.
+template <bool VEC, int BATCH>
+__device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv, int l, int local_b, int HW) {
+    const int K = P.K;
+    const int64_t n = (int64_t)P.A * K * HW;
+    const int64_t i = ((int64_t)local_b * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 m[2];
+    const float* base[2] = {lv.cls, lv.cls_var};
+    merge_runs4<VEC, 2, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
+    if (P.n_runs > 1 && !(P.debug_bits & 2)) {
+        const int64_t off = (int64_t)lv.anchor_base * K;
+        st4<VEC>(P.mean_cls + off, i, n, m[0]);
+        st4<VEC>(P.mean_cls_var + off, i, n, m[1]);
+    }
+    const float lg[4] = {m[0].x, m[0].y, m[0].z, m[0].w};
+    const float vr[4] = {m[1].x, m[1].y, m[1].z, m[1].w};
+    uint64_t* bits = P.maybe_bits + P.word_begin[l];
+    if (VEC) {   // H*W % 4 == 0: the four elements are consecutive cells of one plane
+        const int plane = (int)(i / HW);
+        const int hw = (int)(i - (int64_t)plane * HW);
+        unsigned nib = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit) nib |= 1u << j;
+        if (P.debug_bits & 4) nib = 0;
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + (plane / K) * P.wpa[l] + (hw >> 6));
+        if ((HW & 63) == 0) {
+            // planes are whole bitmap words and a wavefront starts on a 256-element boundary: 16 consecutive lanes
+            // own exactly one word -> OR-reduce their nibbles in registers, one atomic per non-zero word
+            unsigned long long w = (unsigned long long)nib << (hw & 63);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
+            if ((threadIdx.x & 15) == 0 && w != 0ull) atomicOr(word, w);
+        } else if (nib) {
+            atomicOr(word, (unsigned long long)nib << (hw & 63));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i + j >= n) break;
+            if (!(fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit)) continue;
+            const int plane = (int)((i + j) / HW);
+            const int hw = (int)(i + j - (int64_t)plane * HW);
+            atomicOr(reinterpret_cast<unsigned long long*>(bits + (plane / K) * P.wpa[l] + (hw >> 6)), 1ull << (hw & 63));
+        }
+    }
+}
+
+template <int BATCH>
+__global__ void __launch_bounds__(256) k1_prune_stream(const K1Params P) {
+    const int b = blockIdx.x;
+    const int L = P.n_levels;
+    int seg = 0;
+#pragma unroll 1
+    while (seg + 1 < 3 * L && b >= P.pseg_begin[seg + 1]) ++seg;
+    const int role = seg / L;
+    const int l = seg - role * L;
+    const PodLevel& lv = P.lv[l];
+    const int local_b = b - P.pseg_begin[seg];
+    const int HW = lv.H * lv.W;
+    if (P.debug_roles == 1 && role != 0) return;
+    if (P.debug_roles == 2 && role == 0) return;
+    if (role == 0) {
+        if (P.vec_cls[l]) prune_cls<true, BATCH>(P, lv, l, local_b, HW);
+        else prune_cls<false, 1>(P, lv, l, local_b, HW);
+    } else {
+        if (role == 1 ? P.vec_delta[l] : P.vec_reg[l]) box_role<true, BATCH>(P, lv, l, role, local_b, HW);
+        else box_role<false, 1>(P, lv, l, role, local_b, HW);
+    }
+}
+
 // ---- K1b score_maybe ---------------------------------------------------------------------------------------
 // Sparse companion of K1's prune mode: draws the cls_samples normals and evaluates
 // mean_s sigmoid(logit + eps_s*sigma) (PI:289-295) only for the anchors K1 flagged, reading the merged
@@ -283,14 +347,14 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
 // butterfly and appends the keys of anchors above the threshold with one aggregated atomic.
 struct K1bParams {
     PodLevel lv[POD_MAX_LEVELS];
-    int32_t word_begin[POD_MAX_LEVELS + 1];   // 4 bitmap words per cls workgroup of K1; level l = [word_begin[l], word_begin[l+1])
-    int32_t chunks[POD_MAX_LEVELS];
+    int32_t word_begin[POD_MAX_LEVELS + 1];   // level l = bitmap words [word_begin[l], word_begin[l+1])
+    int32_t wpa[POD_MAX_LEVELS];              // words per anchor shape: bit (a, hw) = word a*wpa + hw/64, bit hw%64
     int32_t n_levels, n_runs, A, K, cls_samples;
     float score_thresh;
     uint64_t seed;
     const float* mean_cls;
     const float* mean_cls_var;
-    const uint64_t* maybe_bits;
+    uint64_t* maybe_bits;
     uint64_t* cand_keys;
     int32_t* cand_count;
 };
@@ -307,13 +371,13 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
     for (int w = wave; w < total_words; w += nwaves) {
         unsigned long long m = P.maybe_bits[w];      // wave-uniform
         if (m == 0ull) continue;
+        if (lane == 0) P.maybe_bits[w] = 0ull;       // leave the bitmap cleared for the next image
         int l = 0;
         while (l + 1 < L && w >= P.word_begin[l + 1]) ++l;
         const PodLevel& lv = P.lv[l];
         const int wl = w - P.word_begin[l];
-        const int blk = wl >> 2;                      // K1 cls workgroup inside the level: a * chunks + chunk
-        const int a = blk / P.chunks[l];
-        const int hw_base = (blk - a * P.chunks[l]) * 256 + (wl & 3) * 64;
+        const int a = wl / P.wpa[l];
+        const int hw_base = (wl - a * P.wpa[l]) * 64;
         const int64_t HW = (int64_t)lv.H * lv.W;
         const float* src = P.n_runs > 1 ? P.mean_cls + (int64_t)lv.anchor_base * K : lv.cls;
         const float* srcv = P.n_runs > 1 ? P.mean_cls_var + (int64_t)lv.anchor_base * K : lv.cls_var;
@@ -428,6 +492,32 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
     }
     P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var; P.mean_delta = mean_delta; P.mean_reg_var = mean_reg_var;
     P.cand_keys = cand_keys; P.cand_count = cand_count; P.maybe_bits = maybe_bits;
+    if (maybe_bits) {
+        // prune mode: flat streaming kernel, 256-thread workgroups
+        int32_t wb = 0, pb = 0, q = 0;
+        for (int l = 0; l < L; ++l) {
+            P.word_begin[l] = wb;
+            P.wpa[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 63) / 64);
+            wb += A * P.wpa[l];
+        }
+        P.word_begin[L] = wb;
+        for (int role = 0; role <= 2; ++role)
+            for (int l = 0; l < L; ++l) {
+                P.pseg_begin[q++] = pb;
+                const int C = role == 0 ? K : (role == 1 ? 4 : D);
+                const bool active = role == 0 || (N > 1 && C > 0 && (role == 1 ? mean_delta != nullptr : mean_reg_var != nullptr));
+                if (active) pb += (int32_t)((((int64_t)A * C * levels[l].H * levels[l].W + 3) / 4 + 255) / 256);
+            }
+        P.pseg_begin[q] = pb;
+        int pbatch = 4;
+        const char* e = getenv("POD_K1_BATCH");
+        if (e) pbatch = atoi(e);
+        if (pbatch <= 2) hipLaunchKernelGGL(pod::k1_prune_stream<2>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
+        else if (pbatch <= 4) hipLaunchKernelGGL(pod::k1_prune_stream<4>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(pod::k1_prune_stream<8>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
+        POD_CHECK_LAUNCH();
+        return POD_OK;
+    }
     int batch = 4;   // measured (prune mode, N = 10): batch 2/4 ~34.8 us, batch 8 ~37.3 us
     {
         const char* e = getenv("POD_K1_BATCH");   // tuning knob: independent 16-B loads per tensor per lane
@@ -444,12 +534,12 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
 extern "C" int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels) {
     if (!cfg || !levels || cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS) return POD_E_INVALID;
     int64_t w = 0;
-    for (int l = 0; l < cfg->n_levels; ++l) w += 4 * (int64_t)cfg->num_anchors * (((int64_t)levels[l].H * levels[l].W + 255) / 256);
+    for (int l = 0; l < cfg->n_levels; ++l) w += (int64_t)cfg->num_anchors * (((int64_t)levels[l].H * levels[l].W + 63) / 64);
     return w;
 }
 
 extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
-                               const uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream) {
+                               uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream) {
     if (!cfg || !levels || !maybe_bits || !cand_keys || !cand_count) return POD_E_INVALID;
     const int L = cfg->n_levels, K = cfg->num_classes;
     if (L < 1 || L > POD_MAX_LEVELS || K < 1 || K > POD_MAX_CLASSES || !cfg->has_cls_var) return POD_E_INVALID;
@@ -460,9 +550,9 @@ extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, con
     for (int l = 0; l < L; ++l) {
         if (!levels[l].cls || !levels[l].cls_var || levels[l].eps_cls) return POD_E_INVALID;
         P.lv[l] = levels[l];
-        P.chunks[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 255) / 256);
+        P.wpa[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 63) / 64);
         P.word_begin[l] = wb;
-        wb += 4 * cfg->num_anchors * P.chunks[l];
+        wb += cfg->num_anchors * P.wpa[l];
     }
     P.word_begin[L] = wb;
     P.n_levels = L; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = K; P.cls_samples = cfg->cls_samples;

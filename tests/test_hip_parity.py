@@ -169,13 +169,16 @@ def _native_candidates(hp, hd, prune):
     hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")
     hip.check(lib.pod_mc_merge_score(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta), P(hp.mean_reg_var),
                                      P(hp.cand_keys), P(hp.cand_count), P(hp.maybe_bits) if prune else None, st), "k1")
+    n_maybe = 0
     if prune:
+        n_maybe = sum(bin(int(x) & (2 ** 64 - 1)).count("1") for x in hp.maybe_bits.cpu().tolist())   # K1b clears the bitmap
         hip.check(lib.pod_score_maybe(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits),
                                       P(hp.cand_keys), P(hp.cand_count), st), "k1b")
     torch.cuda.synchronize()
     counts = hp.cand_count.cpu().tolist()
     keys = [torch.sort(hp.cand_keys[b:b + c].cpu())[0] for b, c in zip(hp.anchor_base, counts)]
-    return counts, keys, [sum(bin(int(x) & (2 ** 64 - 1)).count('1') for x in hp.maybe_bits.cpu().tolist())] if prune else [0]
+    assert not prune or int(hp.maybe_bits.abs().sum().item()) == 0      # left zeroed for the next image
+    return counts, keys, [n_maybe]
 
 
 @pytest.mark.parametrize("mode,runs", [("planted", 10), ("worst", 3), ("planted", 1)])

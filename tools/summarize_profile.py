@@ -40,12 +40,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k1_mc_merge_score" in r["Kernel_Name"]:
+        if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pm[k] = (sum(v) / len(v), min(v), max(v), len(v))
 if pm:
-    lines += ["## PMC counters of `k1_mc_merge_score` (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)", "",
+    lines += ["## PMC counters of K1 (`k1_prune_stream` / `k1_mc_merge_score`) (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)", "",
               "| counter | mean per launch | min | max | launches |", "|---|---|---|---|---|"]
     for k, (m, lo, hi, n) in sorted(pm.items()):
         lines.append("| %s | %.6g | %.6g | %.6g | %d |" % (k, m, lo, hi, n))
