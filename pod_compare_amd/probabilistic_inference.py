@@ -134,7 +134,7 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
                                                has_cls_var=ho.cls_var is not None, cov_dims=cov_dims, device=ho.cls[0].device)
         return self._paths[key]
 
-    def _head_outputs(self, input_im, outputs=None, ensemble_inference=False, outputs_list=None) -> HeadOutputs:
+    def _head_outputs(self, input_im, outputs=None, ensemble_inference=False, outputs_list=None, need_all_runs=False) -> HeadOutputs:
         """PI:199-273: which raw outputs feed the path (MC-dropout runs, ensemble members or a single pass)."""
         if outputs is not None:
             return outputs
@@ -142,6 +142,10 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
             return stack_members(outputs_list)
         image = input_im[0]["image"]
         if self.mc_dropout_enabled and self.num_mc_dropout_runs > 1:
+            if isinstance(self.model, modeling.ProbabilisticRetinaNet):
+                # the quirky merge (PI:216-222) never reads the last run's cls / cls_var / reg_var: do not compute them
+                return self.model(image, num_mc_dropout_runs=self.num_mc_dropout_runs,
+                                  skip_unused_last_run=self.merge_quirk and not need_all_runs)
             return self.model(image, num_mc_dropout_runs=self.num_mc_dropout_runs)      # PI:203-206
         return self.model(image)                                                          # PI:273
 
@@ -201,7 +205,7 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
     def post_processing_mc_dropout_ensembles(self, input_im):
         if self.cfg.PROBABILISTIC_INFERENCE.ENSEMBLES_DROPOUT.BOX_MERGE_MODE == "pre_nms":     # PI:442-443
             return self._run("standard_nms", input_im, self._head_outputs(input_im))
-        ho = self._head_outputs(input_im)                                                      # PI:445-451: N runs, merged post-NMS
+        ho = self._head_outputs(input_im, need_all_runs=True)                                  # PI:445-451: N runs, merged post-NMS
         return self._run_post_nms(input_im, [run_slice(ho, r) for r in range(ho.num_runs)])
 
     def post_processing_ensembles(self, input_im, model_dict):
