@@ -89,6 +89,7 @@ def main():
     model = modeling.ProbabilisticRetinaNet(
         dropout_rate=spec["dropout"], cls_var_loss="loss_attenuation" if spec["cls_var"] else "none", cls_var_num_samples=10,
         bbox_cov_loss="negative_log_likelihood" if spec["reg_var"] else "none").to(dev).eval()
+    modeling.fold_frozen_bn(model)   # FrozenBN folded into the conv weights (inference-only algebra, same affine map)
     net_hw = A.resize_shortest_edge(*FRAME_HW)                 # 750 x 1333
     padded = A.padded_size(*net_hw)                            # 768 x 1344
     n_img = max(1, args.images)

@@ -232,6 +232,12 @@ int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_row
                  float* det_boxes, float* det_cov, float* det_scores, int32_t* det_classes, float* det_probs,
                  float* records, int32_t* n_det, pod_stream_t stream);
 
+/* ---- conv-net side: fused ReLU + dropout -------------------------------------------------------
+ * Replaces: the `nn.ReLU(), nn.Dropout(p)` pair after every 3x3 conv of the head subnets (PR:403-424) in
+ * MC-dropout mode (PR:103-108), in place, one pass.  x: dev fp32, 16-byte aligned, n elements.
+ * Element e uses Philox counter (offset + e/4): pass a different `offset` (or seed) per call. */
+int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+
 /* ---- NLL scoring rule ----------------------------------------------------------------------
  * Replaces: compute_reg_scores core/evaluation_tools/scoring_rules.py:68-74
  * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */

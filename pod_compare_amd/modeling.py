@@ -53,6 +53,27 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
 
 
+def fold_frozen_bn(module: nn.Module) -> int:
+    """Folds every `Sequential(Conv2d(bias=False), FrozenBatchNorm2d)` pair into one biased conv (w * scale, shift):
+    the same affine map without ~100 tiny element-wise launches per image in the batch-1 backbone.  Returns the number
+    of pairs folded.  Inference only (the statistics are frozen by definition)."""
+    n = 0
+    for child in module.children():
+        if isinstance(child, nn.Sequential) and len(child) == 2 and isinstance(child[0], nn.Conv2d) and \
+                isinstance(child[1], FrozenBatchNorm2d) and child[0].bias is None:
+            conv, bn = child[0], child[1]
+            scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
+            shift = bn.bias - bn.running_mean * scale
+            with torch.no_grad():
+                conv.weight.mul_(scale.reshape(-1, 1, 1, 1))
+                conv.bias = nn.Parameter(shift.clone(), requires_grad=False)
+            child[1] = nn.Identity()
+            n += 1
+        else:
+            n += fold_frozen_bn(child)
+    return n
+
+
 def _conv_bn(cin, cout, k, stride=1, padding=0):
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill
@@ -133,6 +154,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
         super().__init__()
         self.num_anchors, self.num_classes = num_anchors, num_classes
         self.dropout_rate = float(dropout_rate)
+        self.fused_relu_dropout = True      # GPU only; falls back to torch ops on CPU tensors
+        self.dropout_seed = 0x0D50ED
+        self._drop_calls = 0                # distinct Philox counter block per call
         self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims = compute_cls_var, compute_bbox_cov, bbox_cov_dims
         self.cls_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
         self.bbox_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
@@ -162,7 +186,19 @@ class ProbabilisticRetinaNetHead(nn.Module):
             return x                                  # batch 1; shared by every copy
         x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
         for conv in convs[1:]:
-            x = F.dropout(F.relu(conv(x)), self.dropout_rate, training=True)
+            x = self._relu_dropout(conv(x))
+        return x
+
+    def _relu_dropout(self, x: torch.Tensor) -> torch.Tensor:
+        """ReLU + Dropout(p) after a subnet conv (PR:403-424).  On the GPU one fused in-place HIP pass
+        (pod_relu_dropout) instead of torch's clamp + fused_dropout kernels."""
+        if not (self.fused_relu_dropout and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+            return F.dropout(F.relu(x), self.dropout_rate, training=True)
+        from . import hip
+        lib = hip.load()
+        self._drop_calls += 1
+        hip.check(lib.pod_relu_dropout(x.data_ptr(), x.numel(), float(self.dropout_rate), self.dropout_seed,
+                                       self._drop_calls << 34, hip.current_stream()), "pod_relu_dropout")
         return x
 
     def forward(self, features: List[torch.Tensor], num_runs: int = 1, mc_dropout: bool = False,

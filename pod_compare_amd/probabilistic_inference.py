@@ -42,7 +42,11 @@ def build_model(cfg) -> modeling.ProbabilisticRetinaNet:
         test_topk_candidates=cfg.MODEL.RETINANET.TOPK_CANDIDATES_TEST, test_nms_thresh=cfg.MODEL.RETINANET.NMS_THRESH_TEST,
         max_detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, min_size_test=cfg.INPUT.MIN_SIZE_TEST,
         max_size_test=cfg.INPUT.MAX_SIZE_TEST)
-    return model.to(torch.device(cfg.MODEL.DEVICE)).eval()
+    model = model.to(torch.device(cfg.MODEL.DEVICE)).eval()
+    # NB: call modeling.fold_frozen_bn(model) AFTER loading weights (inference-only algebraic folding of FrozenBN);
+    # for the random-init models used here the statistics are the identity, so it is applied right away.
+    modeling.fold_frozen_bn(model)
+    return model
 
 
 def build_predictor(cfg, model=None, model_list=None):

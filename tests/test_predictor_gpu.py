@@ -136,3 +136,45 @@ def test_ensemble_members_in_packed_strided_buffer_match_reference():
     assert torch.equal(res.pred_classes.cpu(), g.t("pred_classes"))
     assert_close(res.pred_boxes.tensor.cpu(), g.t("pred_boxes"), "boxes")
     assert_close(res.pred_boxes_covariance.cpu(), g.t("pred_boxes_covariance"), "cov")
+
+
+def test_fused_relu_dropout_statistics():
+    """pod_relu_dropout == dropout(relu(x), p): zeros where x <= 0, survivors scaled by 1/(1-p), keep rate 1-p,
+    different masks for different counter offsets, deterministic for equal (seed, offset)."""
+    from pod_compare_amd import hip
+    lib = hip.load()
+    x = torch.randn(3, 256, 37, 41, device="cuda")          # numel % 4 != 0 exercises the tail
+    p = 0.2
+    def run(off):
+        y = x.clone()
+        hip.check(lib.pod_relu_dropout(y.data_ptr(), y.numel(), p, 1234, off, hip.current_stream()), "pod_relu_dropout")
+        return y
+    y, y_again, y_other = run(0), run(0), run(1 << 34)
+    assert torch.equal(y, y_again) and not torch.equal(y, y_other)
+    pos = x > 0
+    assert bool((y[~pos] == 0).all())
+    kept = y[pos] != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 5e-3
+    assert torch.allclose(y[pos][kept], x[pos][kept] / (1 - p), rtol=1e-6, atol=0)
+    # neighbouring elements are not correlated (one Philox call feeds 4 elements)
+    k = (y != 0).float().reshape(-1)[: (x.numel() // 4) * 4].reshape(-1, 4)
+    m = pos.reshape(-1)[: (x.numel() // 4) * 4].reshape(-1, 4).all(1)
+    c = torch.corrcoef(k[m].t())
+    assert float((c - torch.eye(4, device="cuda")).abs().max()) < 0.02
+
+
+def test_bn_folding_is_the_same_affine_map():
+    from pod_compare_amd import modeling
+    torch.manual_seed(3)
+    net = modeling.ResNet50().cuda().eval()
+    for mod in net.modules():                                   # non-trivial frozen statistics
+        if isinstance(mod, modeling.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.2, 0.2)
+            mod.running_mean.uniform_(-0.1, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(1, 3, 96, 128, device="cuda")
+    with torch.no_grad():
+        ref = net(x)
+        assert modeling.fold_frozen_bn(net) == 53
+        out = net(x)
+    for a, b in zip(out, ref):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
