@@ -74,13 +74,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    # POD_BENCH_BACKEND=gloo + POD_BENCH_SHARE_GPU=1: debugging aid to exercise the multi-rank code path on a box with
+    # a single GPU (all ranks on cuda:0, collectives staged through the host).  The real path is nccl = RCCL over xGMI.
+    backend = os.environ.get("POD_BENCH_BACKEND", "nccl")
+    if os.environ.get("POD_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    stage = (lambda t: t.cpu()) if backend != "nccl" else (lambda t: t)
     spec = CONFIGS[args.config]
     N = spec["runs"]
 
@@ -139,8 +148,8 @@ def main():
         # the path's only collective: gather the fixed-stride detection records of this flush
         if world > 1:
             import torch.distributed as dist
-            rec = torch.stack([d.records for d in dets])
-            cnt = torch.stack([d.n_det for d in dets])
+            rec = stage(torch.stack([d.records for d in dets]))
+            cnt = stage(torch.stack([d.n_det for d in dets]))
             all_rec = [torch.empty_like(rec) for _ in range(world)]
             all_cnt = [torch.empty_like(cnt) for _ in range(world)]
             dist.all_gather(all_rec, rec)
@@ -151,7 +160,7 @@ def main():
         dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = stage(torch.tensor([dt], device=dev, dtype=torch.float64))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_det_mean = float(torch.stack([d.n_det for d in dets]).float().mean().item())
