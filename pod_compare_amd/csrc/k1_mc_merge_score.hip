@@ -236,12 +236,13 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     __syncthreads();
 
     // ---- 256 threads: one anchor each; max/argmax over classes; candidate emission ------------------
-    if (tid < 256) {
-        const int hw = chunk * 256 + tid;
-        float best = lds_probs[tid];
+    // (blockDim = 64*K may be smaller than 256 when K < 4: whole wavefronts walk the 256 anchors)
+    for (int p = tid; p < 256; p += blockDim.x) {
+        const int hw = chunk * 256 + p;
+        float best = lds_probs[p];
 #pragma unroll 1
         for (int kk = 1; kk < K; ++kk) {
-            const float v = lds_probs[kk * 256 + tid];
+            const float v = lds_probs[kk * 256 + p];
             best = (v > best) ? v : best;   // torch.max keeps the first maximum; argmax is re-derived in K2b
         }
         {
