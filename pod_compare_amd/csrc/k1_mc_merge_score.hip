@@ -363,6 +363,7 @@ struct K1bParams {
 template <int KP>
 __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
     constexpr int G = 64 / KP;                       // anchors per wavefront per round
+    __shared__ uint64_t s_park[4 * 64];
     const int lane = threadIdx.x & 63;
     const int sub = lane / KP, k = lane % KP;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -382,6 +383,10 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
         const int64_t HW = (int64_t)lv.H * lv.W;
         const float* src = P.n_runs > 1 ? P.mean_cls + (int64_t)lv.anchor_base * K : lv.cls;
         const float* srcv = P.n_runs > 1 ? P.mean_cls_var + (int64_t)lv.anchor_base * K : lv.cls_var;
+        // keys of this word's anchors above the threshold are parked in LDS and appended with ONE atomic per word
+        // (the per-round atomics of an all-candidates image serialise on 5 counters: 283 us -> see DESIGN.md)
+        uint64_t* park = s_park + (threadIdx.x >> 6) * 64;
+        int parked = 0;
         while (m != 0ull) {
             // hand the next G set bits to the G lane groups
             int bit = -1;
@@ -405,13 +410,14 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
             for (int o = KP >> 1; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
             const bool emit = valid && k == 0 && best > P.score_thresh;
             const unsigned long long em = __ballot(emit);
-            if (em != 0ull) {
-                const int leader = __ffsll((long long)em) - 1;
-                int pos = 0;
-                if (lane == leader) pos = atomicAdd(&P.cand_count[l], __popcll(em));
-                pos = __shfl(pos, leader, 64);
-                if (emit) P.cand_keys[(int64_t)lv.anchor_base + pos + __popcll(em & ((1ull << lane) - 1ull))] = make_key(best, hw * A + a);
-            }
+            if (emit) park[parked + __popcll(em & ((1ull << lane) - 1ull))] = make_key(best, hw * A + a);
+            parked += __popcll(em);
+        }
+        if (parked > 0) {
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&P.cand_count[l], parked);
+            pos = __shfl(pos, 0, 64);
+            if (lane < parked) P.cand_keys[(int64_t)lv.anchor_base + pos + lane] = park[lane];   // same wave wrote park[]
         }
     }
 }

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     __shared__ uint64_t s_keys[SORT_CAP];
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_prefix;
-    __shared__ int32_t s_remaining, s_fill;
+    __shared__ int32_t s_remaining, s_fill, s_bucket;
     const int l = blockIdx.x;
     const int tid = threadIdx.x;
     const uint64_t* keys = P.cand_keys + P.anchor_base[l];
@@ -63,21 +63,46 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
         for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = (i < C) ? keys[i] : 0ull;
         __syncthreads();
     } else {
-        // radix select: k-th largest of C distinct 64-bit keys, 8 bits per pass from the top
+        // Radix select from the top byte down, until the keys that can still be in the top-k fit the LDS sort buffer:
+        // after a pass the candidates are {keys above the chosen bucket} + {the bucket}; typically 2-4 passes.
+        // 8 independent 8-byte loads per thread per step (a lone load per iteration made every pass latency-bound).
         if (tid == 0) {
             s_prefix = 0ull;
             s_remaining = k;
+            s_fill = 0;
         }
         __syncthreads();
+        uint64_t lower_bound = 0ull;     // every key >= lower_bound is still a top-k candidate; there are <= SORT_CAP of them at exit
         for (int pass = 7; pass >= 0; --pass) {
             const int shift = pass * 8;
             if (tid < 256) s_hist[tid] = 0u;
             __syncthreads();
             const uint64_t prefix = s_prefix;
             const uint64_t himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
-            for (int i = tid; i < C; i += TOPK_THREADS) {
-                const uint64_t key = keys[i];
-                if ((key & himask) == prefix) atomicAdd(&s_hist[(uint32_t)(key >> shift) & 255u], 1u);
+            for (int i0 = 0; i0 < C; i0 += TOPK_THREADS * 8) {
+                uint64_t kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * TOPK_THREADS + tid;
+                    kk[u] = (i < C) ? keys[i] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * TOPK_THREADS + tid;
+                    const bool live = i < C && (kk[u] & himask) == prefix;
+                    // top digits of score keys are heavily skewed: one LDS atomic when the whole wavefront agrees
+                    const uint32_t digit = (uint32_t)(kk[u] >> shift) & 255u;
+                    const unsigned long long lm = __ballot(live);
+                    if (lm != 0ull) {
+                        const int leader = __ffsll((long long)lm) - 1;
+                        const uint32_t d0 = __shfl(digit, leader, 64);
+                        if (__ballot(live && digit == d0) == lm) {
+                            if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[d0], (uint32_t)__popcll(lm));
+                        } else if (live) {
+                            atomicAdd(&s_hist[digit], 1u);
+                        }
+                    }
+                }
             }
             __syncthreads();
             if (tid == 0) {
@@ -88,20 +113,32 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
                     if (c >= rem) break;
                     rem -= c;
                 }
-                s_remaining = rem;
+                s_remaining = rem;                                  // still needed from bucket d
                 s_prefix = prefix | ((uint64_t)d << shift);
+                s_bucket = (int)s_hist[d];
             }
             __syncthreads();
+            lower_bound = s_prefix;
+            // candidates = (k - remaining) keys above the bucket + the bucket itself
+            if ((k - s_remaining) + s_bucket <= SORT_CAP) break;
         }
-        const uint64_t thr = s_prefix;   // exactly k keys are >= thr
-        if (tid == 0) s_fill = 0;
+        const int n_cand = (k - s_remaining) + s_bucket;            // exact count of keys >= lower_bound
         n_sort = 1;
-        while (n_sort < k) n_sort <<= 1;
+        while (n_sort < n_cand) n_sort <<= 1;
         for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = 0ull;
         __syncthreads();
-        for (int i = tid; i < C; i += TOPK_THREADS) {
-            const uint64_t key = keys[i];
-            if (key >= thr) s_keys[atomicAdd(&s_fill, 1)] = key;
+        for (int i0 = 0; i0 < C; i0 += TOPK_THREADS * 8) {
+            uint64_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * TOPK_THREADS + tid;
+                kk[u] = (i < C) ? keys[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * TOPK_THREADS + tid;
+                if (i < C && kk[u] >= lower_bound) s_keys[atomicAdd(&s_fill, 1)] = kk[u];
+            }
         }
         __syncthreads();
     }
