@@ -238,6 +238,19 @@ int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_row
  * Element e uses Philox counter (offset + e/4): pass a different `offset` (or seed) per call. */
 int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
 
+/* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
+ * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set
+ * in one call.  Images are concatenated: image m owns detections [det_off[m], det_off[m+1]) and ground-truth boxes
+ * [gt_off[m], gt_off[m+1]) (<= 128 detections per image); det_img / gt_img give the image slot of every row.
+ * Outputs: gt_fn[g] = 1 iff every IoU <= iou_min (EU:245); gt_match_count[g] detections with IoU >= iou_correct, their
+ * global indices / IoUs in gt_match_idx / gt_match_iou (n_gt x 128) ordered by descending max class probability
+ * (entry 0 = the true positive, the rest duplicates, EU:282-299); det_fp[d] = 1 iff IoU <= iou_min with every
+ * ground truth of its image (EU:255; an image without ground truth makes all its detections false positives). */
+int pod_match_groundtruth(const float* det_boxes, const float* det_probs, const int32_t* det_off, const int32_t* det_img,
+                          int32_t n_det, const float* gt_boxes, const int32_t* gt_off, const int32_t* gt_img, int32_t n_gt,
+                          int32_t num_classes, float iou_min, float iou_correct, int32_t* gt_fn, int32_t* gt_match_count,
+                          int32_t* gt_match_idx, float* gt_match_iou, int32_t* det_fp, pod_stream_t stream);
+
 /* ---- NLL scoring rule ----------------------------------------------------------------------
  * Replaces: compute_reg_scores core/evaluation_tools/scoring_rules.py:68-74
  * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */

@@ -39,3 +39,25 @@ def load_reference():
     iu = importlib.import_module("probabilistic_inference.inference_utils")
     mu = importlib.import_module("probabilistic_modeling.modeling_utils")
     return pi, iu, mu
+
+
+def load_reference_evaluation():
+    """Returns (evaluation_utils module, scoring_rules module) of the reference's core/evaluation_tools (SURVEY f-1).
+    `ujson`, `tqdm`-free stand-ins and dummy `core.datasets` modules are seeded; the reference's own files are imported
+    by path so that its `core/__init__.py` (project paths) is not needed."""
+    import importlib.util
+    import json
+    load_reference()
+    sys.modules.setdefault("ujson", json)
+    for name in ("core.datasets", "core.datasets.metadata", "core.evaluation_tools"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["core"].datasets = sys.modules["core.datasets"]
+    sys.modules["core.datasets"].metadata = sys.modules["core.datasets.metadata"]
+    mods = []
+    for fname in ("evaluation_utils", "scoring_rules"):
+        path = os.path.join(REFERENCE_SRC, "core", "evaluation_tools", fname + ".py")
+        spec = importlib.util.spec_from_file_location("core.evaluation_tools." + fname, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    return tuple(mods)

@@ -27,7 +27,7 @@ POD_MAX_DETECTIONS = 128
 EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
-           "pod_finalize", "pod_reg_nll", "pod_relu_dropout")
+           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_match_groundtruth")
 
 
 class PodLevel(Structure):
@@ -87,6 +87,7 @@ def load() -> ctypes.CDLL:
     lib.pod_ensemble_merge.argtypes = [POINTER(PodConfig), P, c_int32, P, P, P, P, P, P, P, P, P, P, P, P]
     lib.pod_finalize.argtypes = [POINTER(PodConfig)] + [P] * 7 + [c_float] * 4 + [P] * 7 + [P]
     lib.pod_reg_nll.argtypes = [P, P, P, c_int32, P, P]
+    lib.pod_match_groundtruth.argtypes = [P, P, P, P, c_int32, P, P, P, c_int32, c_int32, c_float, c_float, P, P, P, P, P, P]
     lib.pod_relu_dropout.argtypes = [P, c_int64, c_float, c_uint64, c_uint64, P]
     for name in EXPORTS:
         if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words"):
