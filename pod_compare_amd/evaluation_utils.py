@@ -98,3 +98,44 @@ def retinanet_compute_cls_scores(input_matches: Dict, valid_idxs: torch.Tensor) 
     if p.shape[0] == 0:
         return {"ignorance_score_mean": None}
     return {"ignorance_score_mean": float((-torch.log(p)).mean())}
+
+
+def eval_predictions_preprocess(predicted_instances, min_allowed_score: float = 0.0, is_odd: bool = False, device="cpu"):
+    """EU:19-73 (SURVEY f-2, the on-disk result format read back): list of `instances_to_json` dicts -> per-image tensors.
+    XYWH boxes back to XYXY; covariances back through T' = [[1,0,0,0],[0,1,0,0],[1,0,1,0],[0,1,0,1]] (the inverse of
+    covar_xyxy_to_xywh's T), detections with category_id == -1 (unless `is_odd`) or max cls_prob < min_allowed_score
+    dropped.  Vectorised per image instead of one torch.cat per detection."""
+    from collections import defaultdict
+    rows = defaultdict(list)
+    for inst in predicted_instances:
+        top = max(inst["cls_prob"])
+        if (not is_odd and inst["category_id"] == -1) or top < min_allowed_score:
+            continue
+        rows[inst["image_id"]].append(inst)
+    tinv = torch.tensor([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [1.0, 0, 1.0, 0], [0, 1.0, 0.0, 1.0]], dtype=torch.float64)
+    boxes, probs, covs = {}, {}, {}
+    for image_id, insts in rows.items():
+        b = torch.tensor([i["bbox"] for i in insts], dtype=torch.float64)
+        b[:, 2] += b[:, 0]
+        b[:, 3] += b[:, 1]
+        c = torch.tensor([i["bbox_covar"] for i in insts], dtype=torch.float64)
+        boxes[image_id] = b.to(torch.float32).to(device)
+        probs[image_id] = torch.tensor([i["cls_prob"] for i in insts], dtype=torch.float32, device=device)
+        covs[image_id] = (tinv @ c @ tinv.t()).to(torch.float32).to(device)
+    return {"predicted_boxes": boxes, "predicted_cls_probs": probs, "predicted_covar_mats": covs}
+
+
+def eval_gt_preprocess(gt_instances, device="cpu"):
+    """EU:76-92: COCO annotations -> per-image XYXY boxes and (n,1) category ids."""
+    from collections import defaultdict
+    rows = defaultdict(list)
+    for g in gt_instances:
+        rows[g["image_id"]].append(g)
+    boxes, cats = {}, {}
+    for image_id, gs in rows.items():
+        b = torch.tensor([g["bbox"] for g in gs], dtype=torch.float64)
+        b[:, 2] += b[:, 0]
+        b[:, 3] += b[:, 1]
+        boxes[image_id] = b.to(torch.float32).to(device)
+        cats[image_id] = torch.tensor([[g["category_id"]] for g in gs], dtype=torch.float32, device=device)
+    return {"gt_boxes": boxes, "gt_cat_idxs": cats}
