@@ -211,6 +211,17 @@ def main():
     k1_ms.sort()
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
     k1_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk)
+    # HBM traffic of K1 comes from separate rocprofv3 --pmc passes (a counter run cannot share a process with this timing
+    # run); the committed summary of the latest pass is read back when it was taken on this very workload.
+    traffic, traffic_src = args.k1_traffic_bytes, "--k1-traffic-bytes"
+    if traffic is None:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k1_traffic.json")), reverse=True):
+            t = json.load(open(path))
+            w = t.get("workload", {})
+            if w.get("anchors_R") == R and w.get("mc_runs") == N and w.get("config") == args.config and w.get("synthetic_mode") == args.synth:
+                traffic, traffic_src = t["k1_traffic_bytes"], os.path.relpath(path, ROOT) + ": " + t.get("source", "")
+                break
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
 
     out = {
@@ -223,7 +234,7 @@ def main():
                    "images_per_gpu_step": 1, "parallelism": "image-sharded dp%d" % world, "rng": "in-kernel Philox4x32-10"},
         "hot_path_ms_per_image": hp_ms, "mean_detections": n_det_mean,
         "roofline": {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": args.k1_traffic_bytes, "algorithmic_bytes": k1_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None, "algorithmic_bytes": k1_bytes,
                      "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_ms[0],
                      "survey_bytes_4RC(N+1)": 4 * R * (params.num_classes * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)},
     }

@@ -25,7 +25,8 @@ def sha(tensors) -> str:
 
 
 def fixture_paths(prefix=""):
-    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if not p.endswith("unit_functions.npz"))
+    skip = ("unit_functions.npz", "eval_matching.npz")      # not whole-predictor fixtures
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if not p.endswith(skip))
 
 
 def fixture_id(path):

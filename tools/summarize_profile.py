@@ -56,7 +56,9 @@ if pm:
                   "", "    reads  = 2 * FETCH_SIZE * 1024 = %.1f MB" % (2 * fetch_b / 1e6),
                   "    writes =     WRITE_SIZE * 1024 = %.1f MB" % (write_b / 1e6),
                   "    traffic = %.0f bytes" % (2 * fetch_b + write_b), ""]
-        json.dump({"k1_traffic_bytes": 2 * fetch_b + write_b, "fetch_bytes_corrected": 2 * fetch_b, "write_bytes": write_b},
+        json.dump({"k1_traffic_bytes": 2 * fetch_b + write_b, "fetch_bytes_corrected": 2 * fetch_b, "write_bytes": write_b,
+                   "workload": {"anchors_R": 193374, "mc_runs": 10, "config": "cfg3", "synthetic_mode": "planted"},
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/k1_only.py 12; FETCH_SIZE x2 (gfx950)"},
                   open(os.path.join(dst, "%s_k1_traffic.json" % tag), "w"))
 ev = os.path.join(src, "k1_events.txt")
 if os.path.exists(ev):
