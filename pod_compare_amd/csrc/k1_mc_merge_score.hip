@@ -19,8 +19,6 @@
 //   * "box" workgroups: flat element-wise merge of the delta / reg_var planes (pure streaming).
 // ~1.6k workgroups, ~11k waves at BASELINE size (R = 193374, N = 10): every CU holds several
 // waves with >= 16 loads in flight each.  No MFMA: element-wise + reductions.
-#include <stdlib.h>
-
 #include "pod_device.h"
 
 namespace pod {
@@ -35,7 +33,6 @@ struct K1Params {
     int32_t n_levels, n_runs, A, K, D, has_cls_var, quirk, cls_samples;
     float score_thresh;
     float skip_logit;                            // native mode: logit + EPS_MAX*sigma <= skip_logit can never pass the threshold
-    int32_t n_cls_blocks, n_box_blocks, interleave, debug_roles, debug_bits;
     uint64_t seed;
     float* mean_cls;
     float* mean_cls_var;
@@ -166,7 +163,7 @@ __device__ __forceinline__ float4 cls_role(const K1Params& P, const PodLevel& lv
     const float* base[2] = {lv.cls, lv.cls_var};
     if (has_var) merge_runs4<VEC, 2, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
     else merge_runs4<VEC, 1, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
-    if (P.n_runs > 1 && !(P.debug_bits & 2)) {
+    if (P.n_runs > 1) {
         const int64_t off = (int64_t)lv.anchor_base * K;
         if (P.mean_cls) st4<VEC>(P.mean_cls + off, i, n, m[0]);
         if (has_var && P.mean_cls_var) st4<VEC>(P.mean_cls_var + off, i, n, m[1]);
@@ -176,7 +173,7 @@ __device__ __forceinline__ float4 cls_role(const K1Params& P, const PodLevel& lv
     float pr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool live = hw0 + j < HW && !(P.debug_bits & 4);
+        const bool live = hw0 + j < HW;
         pr[j] = live ? class_prob_cell(lg[j], vr[j], has_var, P.cls_samples, lv.eps_cls, (int64_t)HW * P.A, K, P.A, l, hw0 + j, a, k, P.seed)
                      : 0.0f;
     }
@@ -186,19 +183,7 @@ __device__ __forceinline__ float4 cls_role(const K1Params& P, const PodLevel& lv
 template <int BATCH>
 __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     extern __shared__ __attribute__((aligned(16))) float lds_probs[];   // [K][256]
-    int b = blockIdx.x;
-    if (P.interleave) {
-        // groups of 8 (the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so an
-        // odd/even split would park all cls work on four XCDs): physical [16g, 16g+8) -> cls 8g..8g+7,
-        // [16g+8, 16g+16) -> box 8g..8g+7; what is left of the longer list follows in logical order.
-        const int nc = P.n_cls_blocks, nb = P.n_box_blocks, m8 = min(nc, nb) & ~7;
-        if (b < 2 * m8) {
-            const int g = b >> 4, w = b & 15;
-            b = (w < 8) ? g * 8 + w : nc + g * 8 + (w - 8);
-        } else if (b - 2 * m8 < nc - m8) {
-            b -= m8;
-        }
-    }
+    const int b = blockIdx.x;
     const int L = P.n_levels;
     // locate role + level (scalar search over <= 24 segment starts)
     int seg = 0;
@@ -210,8 +195,6 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     const int local_b = b - P.seg_begin[seg];
     const int HW = lv.H * lv.W;
     const int tid = threadIdx.x;
-    if (P.debug_roles == 1 && role != 0) return;   // profiling knob: cls blocks only
-    if (P.debug_roles == 2 && role == 0) return;   // profiling knob: box blocks only
 
     if (role != 0) {
         if (role == 1 ? P.vec_delta[l] : P.vec_reg[l]) box_role<true, BATCH>(P, lv, l, role, local_b, HW);
@@ -228,10 +211,6 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
     const int hw0 = chunk * 256 + lane * 4;
     float4 prob = float4{0.f, 0.f, 0.f, 0.f};
     if (hw0 < HW) prob = P.vec_cls[l] ? cls_role<true, BATCH>(P, lv, l, a, k, hw0, HW) : cls_role<false, 1>(P, lv, l, a, k, hw0, HW);
-    if (P.debug_bits & 1) {
-        if (prob.x + prob.y + prob.z + prob.w > 3.9f) P.cand_count[l] = 1;   // keep the loads alive
-        return;
-    }
     *reinterpret_cast<float4*>(&lds_probs[k * 256 + lane * 4]) = prob;
     __syncthreads();
 
@@ -277,7 +256,7 @@ __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv,
     float4 m[2];
     const float* base[2] = {lv.cls, lv.cls_var};
     merge_runs4<VEC, 2, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
-    if (P.n_runs > 1 && !(P.debug_bits & 2)) {
+    if (P.n_runs > 1) {
         const int64_t off = (int64_t)lv.anchor_base * K;
         st4<VEC>(P.mean_cls + off, i, n, m[0]);
         st4<VEC>(P.mean_cls_var + off, i, n, m[1]);
@@ -292,7 +271,6 @@ __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv,
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit) nib |= 1u << j;
-        if (P.debug_bits & 4) nib = 0;
         unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + (plane / K) * P.wpa[l] + (hw >> 6));
         if ((HW & 63) == 0) {
             // planes are whole bitmap words and a wavefront starts on a 256-element boundary: 16 consecutive lanes
@@ -328,8 +306,6 @@ __global__ void __launch_bounds__(256) k1_prune_stream(const K1Params P) {
     const PodLevel& lv = P.lv[l];
     const int local_b = b - P.pseg_begin[seg];
     const int HW = lv.H * lv.W;
-    if (P.debug_roles == 1 && role != 0) return;
-    if (P.debug_roles == 2 && role == 0) return;
     if (role == 0) {
         if (P.vec_cls[l]) prune_cls<true, BATCH>(P, lv, l, local_b, HW);
         else prune_cls<false, 1>(P, lv, l, local_b, HW);
@@ -488,15 +464,6 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
         const double t = (double)cfg->score_thresh;
         P.skip_logit = (t > 0.0 && t < 1.0) ? (float)(log(t / (1.0 - t)) - 0.02) : -INFINITY;   // margin covers the fast-math error
     }
-    P.n_cls_blocks = P.seg_begin[L]; P.n_box_blocks = nb - P.seg_begin[L];
-    {
-        const char* e = getenv("POD_K1_INTERLEAVE");   // tuning knob; measured 41 -> 59 us when on, so default off
-        P.interleave = (e && e[0] == '1') ? 1 : 0;
-        const char* r = getenv("POD_K1_ROLES");        // profiling knob: "cls" / "box" run only that role (results invalid)
-        P.debug_roles = (r && r[0] == 'c') ? 1 : ((r && r[0] == 'b') ? 2 : 0);
-        const char* d = getenv("POD_K1_DEBUG");        // profiling knob (results invalid): 1 skip phase 2, 2 skip stores, 4 skip probs
-        P.debug_bits = d ? atoi(d) : 0;
-    }
     P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var; P.mean_delta = mean_delta; P.mean_reg_var = mean_reg_var;
     P.cand_keys = cand_keys; P.cand_count = cand_count; P.maybe_bits = maybe_bits;
     if (maybe_bits) {
@@ -516,24 +483,13 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
                 if (active) pb += (int32_t)((((int64_t)A * C * levels[l].H * levels[l].W + 3) / 4 + 255) / 256);
             }
         P.pseg_begin[q] = pb;
-        int pbatch = 4;
-        const char* e = getenv("POD_K1_BATCH");
-        if (e) pbatch = atoi(e);
-        if (pbatch <= 2) hipLaunchKernelGGL(pod::k1_prune_stream<2>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
-        else if (pbatch <= 4) hipLaunchKernelGGL(pod::k1_prune_stream<4>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
-        else hipLaunchKernelGGL(pod::k1_prune_stream<8>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
+        // 4 independent 16-B loads per tensor per lane: measured 34.2 us vs 34.1 (2) and 34.6 (8) per launch
+        hipLaunchKernelGGL(pod::k1_prune_stream<4>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
         POD_CHECK_LAUNCH();
         return POD_OK;
     }
-    int batch = 4;   // measured (prune mode, N = 10): batch 2/4 ~34.8 us, batch 8 ~37.3 us
-    {
-        const char* e = getenv("POD_K1_BATCH");   // tuning knob: independent 16-B loads per tensor per lane
-        if (e) batch = atoi(e);
-    }
     const size_t lds = sizeof(float) * 256 * K;
-    if (batch <= 2) hipLaunchKernelGGL(pod::k1_mc_merge_score<2>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
-    else if (batch <= 4) hipLaunchKernelGGL(pod::k1_mc_merge_score<4>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(pod::k1_mc_merge_score<8>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(pod::k1_mc_merge_score<4>, dim3(nb), dim3(threads), lds, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
