@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--synth", default="planted", choices=["planted", "worst"])
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
     ap.add_argument("--k1-traffic-bytes", type=float, default=None,
                     help="HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): 2*FETCH_SIZE + WRITE_SIZE")
     args = ap.parse_args()
@@ -255,7 +255,7 @@ def main():
                        run_outputs=runs if N > 1 else None)
             t_cpu += time.perf_counter() - t1
             n_cpu += 1
-            if t_cpu > 30.0:
+            if t_cpu > 12.0:
                 break
         out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "images/s", "cores": threads, "kind": "port",
                                "host_cpus": cores,
