@@ -247,9 +247,12 @@ def main():
         torch.set_num_threads(threads)
         op = po.PathParams()
         n_cpu, t_cpu = 0, 0.0
+        cpu_sets = []
+        for h in heads:                                   # host copies in the reference's (1, HWA, C) layout, made once
+            hc = h.to("cpu")
+            cpu_sets.append([synthetic.to_reference_layout(hc, r) for r in range(N)])
         for i in range(args.cpu_images):
-            h = heads[i % n_img].to("cpu")
-            runs = [synthetic.to_reference_layout(h, r) for r in range(N)]
+            runs = cpu_sets[i % n_img]
             t1 = time.perf_counter()
             po.predict(spec["mode"], op, net_hw, FRAME_HW, outputs=runs[0] if N == 1 else None,
                        run_outputs=runs if N > 1 else None)
