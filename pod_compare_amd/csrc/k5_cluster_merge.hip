@@ -122,15 +122,17 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
     const int tid = threadIdx.x;
 
     // pass A: total precision, precision-weighted mean, member count, prob sums
-    double acc[16 + 4 + 1 + POD_MAX_CLASSES];
+    double acc[16 + 4 + 2 + POD_MAX_CLASSES];   // [0,16) sum of precisions, [16,20) sum P mu, [20] same-class members, [21] IoU members, [22,..) prob sums
 #pragma unroll
-    for (int q = 0; q < 21 + POD_MAX_CLASSES; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 22 + POD_MAX_CLASSES; ++q) acc[q] = 0.0;
     for (int j = tid; j < n; j += 256) {
         const Box bj = load_box(P.boxes, j);
         if (!(iou_pair(bc, bj) > P.aff)) continue;                    // PI:565-566
         if (P.cls_mode == 1) {                                        // PI:583-585: mean over ALL IoU members
-            for (int k = 0; k < K; ++k) acc[21 + k] += (double)P.probs[(size_t)j * K + k];
-            acc[21 + K] += 1.0;                                       // slot K < POD_MAX_CLASSES: member count
+#pragma unroll
+            for (int k = 0; k < POD_MAX_CLASSES; ++k)             // static indices: the accumulators stay in registers
+                if (k < K) acc[22 + k] += (double)P.probs[(size_t)j * K + k];
+            acc[21] += 1.0;
         }
         if (argmax_probs(P.probs + (size_t)j * K, K) != ccls) continue;   // PI:580-582
         M4 cv, pr;
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
         for (int r = 0; r < 4; ++r) acc[16 + r] += pr.a[r * 4 + 0] * mu[0] + pr.a[r * 4 + 1] * mu[1] + pr.a[r * 4 + 2] * mu[2] + pr.a[r * 4 + 3] * mu[3];
         acc[20] += 1.0;
     }
-    block_sum<21 + POD_MAX_CLASSES>(acc, s_red);
+    block_sum<22 + POD_MAX_CLASSES>(acc, s_red);
     const double m_same = acc[20];
     M4 total;
 #pragma unroll
@@ -212,15 +214,18 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
             for (int q = 0; q < 16; ++q) oc[q] = P.cov[(size_t)ctr * 16 + q];
         }
         float* op = P.out_probs + (size_t)c * K;
-        if (P.cls_mode == 1 && acc[21 + K] > 0.0) {                   // PI:583-585, :609-613
+        if (P.cls_mode == 1 && acc[21] > 0.0) {                       // PI:583-585, :609-613
             float best = 0.0f;
             int bk = 0;
-            for (int k = 0; k < K; ++k) {
-                const float p = (float)(acc[21 + k] / acc[21 + K]);
-                op[k] = p;
-                if (k == 0 || p > best) {
-                    best = p;
-                    bk = k;
+#pragma unroll
+            for (int k = 0; k < POD_MAX_CLASSES; ++k) {
+                if (k < K) {
+                    const float p = (float)(acc[22 + k] / acc[21]);
+                    op[k] = p;
+                    if (k == 0 || p > best) {
+                        best = p;
+                        bk = k;
+                    }
                 }
             }
             P.out_scores[c] = best;
@@ -276,7 +281,9 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
         if (P.classes[j] != ccls) continue;                           // IU:104-106
         acc[1] += 1.0;
         acc[2] += bj.x1; acc[3] += bj.y1; acc[4] += bj.x2; acc[5] += bj.y2;
-        for (int k = 0; k < K; ++k) acc[6 + k] += (double)P.probs[(size_t)j * K + k];
+#pragma unroll
+        for (int k = 0; k < POD_MAX_CLASSES; ++k)                 // static indices: the accumulators stay in registers
+            if (k < K) acc[6 + k] += (double)P.probs[(size_t)j * K + k];
         if (has_cov)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[6 + POD_MAX_CLASSES + q] += (double)P.cov[(size_t)j * 16 + q];
@@ -327,7 +334,9 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
                 for (int e = 0; e < 16; ++e) oc[e] = oc[e] + (float)(acc[6 + POD_MAX_CLASSES + e] / m);
 #pragma unroll
             for (int r = 0; r < 4; ++r) ob[r] = mu[r];
-            for (int k = 0; k < K; ++k) op[k] = (float)(acc[6 + k] / m);   // IU:126
+#pragma unroll
+            for (int k = 0; k < POD_MAX_CLASSES; ++k)
+                if (k < K) op[k] = (float)(acc[6 + k] / m);           // IU:126
         } else {                                                      // IU:127-133
 #pragma unroll
             for (int r = 0; r < 4; ++r) ob[r] = P.boxes[(size_t)ctr * 4 + r];
