@@ -39,6 +39,9 @@ CONFIGS = {
                  mode="bayes_od", runs=10, cls_var=True, reg_var=True, dropout=0.2),
     "cfg4": dict(name="retinanet_R_50_FPN_1x + anchor_statistics.yaml", mode="anchor_statistics", runs=1, cls_var=False,
                  reg_var=False, dropout=0.0),
+    # BASELINE configs[4] with all 5 members on ONE GPU (the one-seed-per-GPU topology is apply_net --ensemble-per-gpu)
+    "cfg5": dict(name="5-seed ensembles_pre_nms.yaml (reg_cls_var), members stacked on one GPU", mode="ensembles", runs=5,
+                 cls_var=True, reg_var=True, dropout=0.0, members=5),
 }
 FRAME_HW = (720, 1280)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -99,6 +102,13 @@ def main():
         dropout_rate=spec["dropout"], cls_var_loss="loss_attenuation" if spec["cls_var"] else "none", cls_var_num_samples=10,
         bbox_cov_loss="negative_log_likelihood" if spec["reg_var"] else "none").to(dev).eval()
     modeling.fold_frozen_bn(model)   # FrozenBN folded into the conv weights (inference-only algebra, same affine map)
+    members = [model]
+    for seed in (1000, 2000, 3000, 4000)[: spec.get("members", 1) - 1]:       # ENSEMBLES.RANDOM_SEED_NUMS
+        torch.manual_seed(seed)
+        mm = modeling.ProbabilisticRetinaNet(dropout_rate=0.0, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                             bbox_cov_loss="negative_log_likelihood").to(dev).eval()
+        modeling.fold_frozen_bn(mm)
+        members.append(mm)
     net_hw = A.resize_shortest_edge(*FRAME_HW)                 # 750 x 1333
     padded = A.padded_size(*net_hw)                            # 768 x 1344
     n_img = max(1, args.images)
@@ -118,7 +128,11 @@ def main():
             img = modeling.resize_test_image(frames[i % n_img])
             # conv net: run and timed; output discarded (see docstring).  The hot path runs with the reference's merge
             # quirk, which never reads the last run's cls / cls_var / reg_var, so the head does not compute them.
-            model(img, num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk)
+            if len(members) > 1:
+                for mm in members:                                 # PI:498-500: one full forward per ensemble member
+                    mm(img)
+            else:
+                model(img, num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk)
         h = heads[i % n_img]
         if timed_idx is not None:
             ev_hp[timed_idx][0].record()

@@ -140,13 +140,14 @@ def main(argv=None):
         recs, cnts = _run_ensemble_per_gpu(cfg, args, rank, world)
     torch.manual_seed(args.random_seed)
     predictor = build_predictor(cfg) if not args.ensemble_per_gpu else None
+    if predictor is not None:
+        predictor.return_device = True      # no per-image host sync: records and counts stay in HBM until the gather
     with torch.no_grad():
         for i in (mine if predictor is not None else []):
             frame = synthetic.synthetic_frame(i, device=cfg.MODEL.DEVICE)
             image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
             input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
-            predictor(input_im)
-            det = predictor.last_detections
+            det = predictor(input_im)
             recs.append(det.records)
             cnts.append(det.n_det)
     width = record_width(K)

@@ -122,6 +122,9 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         self._paths = {}
         self.last_path: Optional[hotpath.HotPath] = None
         self.last_detections: Optional[hotpath.DeviceDetections] = None   # device-resident records of the last image
+        # True: predictor(input_im) returns the fixed-capacity DeviceDetections (no host sync at all: the count stays on
+        # the GPU) instead of an `Instances`; the image-sharded driver uses it so the host can run ahead of the device
+        self.return_device = False
 
     # -- helpers -----------------------------------------------------------------------------------
     def _path_for(self, ho: HeadOutputs) -> hotpath.HotPath:
@@ -166,7 +169,7 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         det = hp.run(mode, ho.cls, ho.delta, ho.cls_var, ho.reg_var, image_size=image_size, out_size=out, eps_fn=self.eps_fn,
                      box_merge_mode=bo.BOX_MERGE_MODE, cls_merge_mode=bo.CLS_MERGE_MODE)
         self.last_detections = det
-        return detections_to_instances(det)
+        return det if self.return_device else detections_to_instances(det)
 
     def _run_post_nms(self, input_im, members: List[HeadOutputs]) -> Instances:
         """Per-member standard NMS, then general_black_box_ensembles_post_processing (IU:165-289)."""
@@ -179,7 +182,7 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         det = self._paths[key].run([(m.cls, m.delta, m.cls_var, m.reg_var) for m in members], image_size=image_size, out_size=out,
                                    eps_fn=self.eps_fn)
         self.last_detections = det
-        return detections_to_instances(det)
+        return det if self.return_device else detections_to_instances(det)
 
     # -- reference surface ---------------------------------------------------------------------------
     def retinanet_probabilistic_inference(self, input_im, outputs=None, ensemble_inference=False, outputs_list=None):
