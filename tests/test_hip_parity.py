@@ -181,11 +181,11 @@ def _native_candidates(hp, hd, prune):
     return counts, keys, [n_maybe]
 
 
-@pytest.mark.parametrize("mode,runs", [("planted", 10), ("worst", 3), ("planted", 1)])
-def test_prune_bound_is_exact(mode, runs):
+@pytest.mark.parametrize("mode,runs,K", [("planted", 10, 7), ("worst", 3, 7), ("planted", 1, 7), ("planted", 2, 12), ("worst", 2, 3)])
+def test_prune_bound_is_exact(mode, runs, K):
     """K1 prune mode + K1b must emit exactly the candidate keys of the dense in-kernel scoring (same Philox
     draws), on planted data (almost everything pruned) and on worst-case data (nothing pruned)."""
-    ho = synthetic.planted_head_outputs((384, 512), runs, seed=77, num_boxes=12, mode=mode).to("cuda")
+    ho = synthetic.planted_head_outputs((384, 512), runs, seed=77, num_boxes=12, mode=mode, num_classes=K).to("cuda")
     hp = make_path(ho)
     c0, k0, _ = _native_candidates(hp, ho, prune=False)
     c1, k1, maybe = _native_candidates(hp, ho, prune=True)
@@ -193,7 +193,7 @@ def test_prune_bound_is_exact(mode, runs):
     for a, b in zip(k0, k1):
         assert torch.equal(a, b)
     if mode == "planted":
-        assert sum(maybe) < 0.05 * hp.R      # the bound really prunes
+        assert sum(maybe) < 0.10 * hp.R      # the bound really prunes (more classes = more chances per anchor)
     else:
         assert sum(maybe) > 0.9 * hp.R
 
