@@ -166,8 +166,10 @@ int pod_decode_cov(const PodConfig* cfg, const PodLevel* levels, const int32_t* 
  * Replaces: detectron2 batched_nms -> torchvision coordinate-trick NMS (call sites PI:554-560,
  * IU:31-36, IU:83-89): boxes + class*(max_coord+1), stable descending-score order, suppress
  * iff IoU > nms_thresh, first `max_detections` survivors.
+ * classes : dev int32[n] in [0, cfg->num_classes) (other ids are honoured, on a slower single-workgroup route).
  * keep : dev int32[max_detections] candidate indices in keep order;  n_keep : dev int32 (written).
- * scratch : dev, pod_nms_scratch_bytes(n_capacity) bytes. */
+ * scratch : dev, 16-byte aligned, pod_nms_scratch_bytes(n_capacity) bytes, no initialisation needed
+ *           (per-class survivor lists between the two launches).  boxes must be 16-byte aligned. */
 size_t pod_nms_scratch_bytes(int32_t n_capacity);
 int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capacity,
                     const float* boxes, const float* scores, const int32_t* classes,
