@@ -47,11 +47,13 @@ FRAME_HW = (720, 1280)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def k1_algorithmic_bytes(R, K, D, N, has_cls_var, quirk):
+def k1_algorithmic_bytes(R, K, D, N, has_cls_var, quirk, dense_box=True):
     """4*R*C*(N+1), C = 2K+4+D channels per anchor, N runs read + merged tensors written.
     The reference's merge (PI:216-222) never reads the last run, so with the quirk on only N-1 runs are
-    streamed: the smaller figure is used so the fraction is never flattered.  N = 1: score pass only."""
-    C = K * (2 if has_cls_var else 1) + 4 + D
+    streamed: the smaller figure is used so the fraction is never flattered.  N = 1: score pass only.
+    dense_box=False: the product path, where box_delta / box_reg_var are merged at the candidates by K2b and K1
+    streams the C = 2K class channels only."""
+    C = K * (2 if has_cls_var else 1) + ((4 + D) if dense_box else 0)
     if N == 1:
         return 4 * R * K * (2 if has_cls_var else 1)
     reads = (N - 1) if quirk else N
@@ -188,54 +190,63 @@ def main():
 
     prune = spec["cls_var"]   # native RNG + variance head: K1 runs in prune mode, exactly as in the timed steps
 
-    def k1_call(j):
-        hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta),
-                                                 P(hp.mean_reg_var), P(hp.cand_keys), P(hp.cand_count),
-                                                 P(hp.maybe_bits) if prune else None, st),
-                          "pod_mc_merge_score")
+    # the product path merges box_delta / box_reg_var at the candidates (K2b); the dense variant also writes their merged
+    # planes for every anchor, as PI:243-270 does (HotPath(dense_box_merge=True)).  Both are timed; `roofline` is the
+    # product path's launch, `roofline_dense_merge` the reference-shaped dense merge of all 2K+4+D channels.
+    dense_delta = torch.empty(R * 4, dtype=torch.float32, device=dev) if N > 1 else None
+    dense_reg = torch.empty(R * D, dtype=torch.float32, device=dev) if N > 1 and D > 0 else None
 
-    def k1_launch(j):
-        lib.pod_reset_counters(P(hp.counters), 8, st)
-        k1_call(j)
+    def time_k1(mean_delta, mean_reg_var):
+        def k1_call(j):
+            hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(mean_delta),
+                                                     P(mean_reg_var), P(hp.cand_keys), P(hp.cand_count),
+                                                     P(hp.maybe_bits) if prune else None, st),
+                              "pod_mc_merge_score")
 
-    for j in range(3):
-        k1_launch(j)
-    torch.cuda.synchronize()
-    # HIP events on the launch stream.  The host must stay AHEAD of the device (otherwise the start event fires
-    # before the kernel has even been enqueued and the pair measures host launch latency): park the stream behind
-    # a ~1 ms spin kernel, enqueue everything, synchronise once.  Each sample = one event pair around K1B
-    # back-to-back launches (rotating over the distinct input sets), so the per-event overhead (~3 us on a 34 us
-    # kernel when every launch is bracketed) is amortised and the figure is comparable with rocprofv3's average.
-    K1B = 10
-    n_batches = max(4, k1_iters // K1B)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_batches)]
-    torch.cuda._sleep(3_000_000)
-    for bidx in range(n_batches):
-        lib.pod_reset_counters(P(hp.counters), 8, st)
-        evs[bidx][0].record()
-        for j in range(K1B):
-            if not prune:
-                lib.pod_reset_counters(P(hp.counters), 8, st)   # dense-scoring mode appends candidates: keep the lists bounded
-            k1_call(bidx * K1B + j)
-        evs[bidx][1].record()
-    torch.cuda.synchronize()
-    if prune:
-        hp.maybe_bits.zero_()
-    k1_ms = [a.elapsed_time(b) / K1B for a, b in evs]
-    k1_ms.sort()
-    k1_avg_ms = sum(k1_ms) / len(k1_ms)
-    k1_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk)
+        for j in range(3):
+            lib.pod_reset_counters(P(hp.counters), 8, st)
+            k1_call(j)
+        torch.cuda.synchronize()
+        # HIP events on the launch stream.  The host must stay AHEAD of the device (otherwise the start event fires
+        # before the kernel has even been enqueued and the pair measures host launch latency): park the stream behind
+        # a ~1 ms spin kernel, enqueue everything, synchronise once.  Each sample = one event pair around K1B
+        # back-to-back launches (rotating over the distinct input sets), so the per-event overhead (~3 us on a 30 us
+        # kernel when every launch is bracketed) is amortised and the figure is comparable with rocprofv3's average.
+        K1B = 10
+        n_batches = max(4, k1_iters // K1B)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_batches)]
+        torch.cuda._sleep(3_000_000)
+        for bidx in range(n_batches):
+            lib.pod_reset_counters(P(hp.counters), 8, st)
+            evs[bidx][0].record()
+            for j in range(K1B):
+                if not prune:
+                    lib.pod_reset_counters(P(hp.counters), 8, st)   # dense-scoring mode appends candidates: keep the lists bounded
+                k1_call(bidx * K1B + j)
+            evs[bidx][1].record()
+        torch.cuda.synchronize()
+        if prune:
+            hp.maybe_bits.zero_()
+        ms = sorted(a.elapsed_time(b) / K1B for a, b in evs)
+        return sum(ms) / len(ms), ms[0]
+
+    k1_avg_ms, k1_min_ms = time_k1(hp.mean_delta, hp.mean_reg_var)
+    k1_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk, dense_box=hp.dense_box_merge)
+    kd_avg_ms, kd_min_ms = time_k1(dense_delta, dense_reg)
+    kd_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk, dense_box=True)
     # HBM traffic of K1 comes from separate rocprofv3 --pmc passes (a counter run cannot share a process with this timing
     # run); the committed summary of the latest pass is read back when it was taken on this very workload.
-    traffic, traffic_src = args.k1_traffic_bytes, "--k1-traffic-bytes"
-    if traffic is None:
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k1_traffic.json")), reverse=True):
-            t = json.load(open(path))
-            w = t.get("workload", {})
-            if w.get("anchors_R") == R and w.get("mc_runs") == N and w.get("config") == args.config and w.get("synthetic_mode") == args.synth:
-                traffic, traffic_src = t["k1_traffic_bytes"], os.path.relpath(path, ROOT) + ": " + t.get("source", "")
-                break
+    traffic, traffic_src, traffic_dense = args.k1_traffic_bytes, "--k1-traffic-bytes", None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k1_traffic.json")), reverse=True):
+        t = json.load(open(path))
+        w = t.get("workload", {})
+        if w.get("anchors_R") == R and w.get("mc_runs") == N and w.get("config") == args.config and w.get("synthetic_mode") == args.synth:
+            key = "k1_dense_traffic_bytes" if hp.dense_box_merge else "k1_class_traffic_bytes"
+            if traffic is None and t.get(key) is not None:
+                traffic, traffic_src = t[key], os.path.relpath(path, ROOT) + ": " + t.get("source", "")
+            traffic_dense = t.get("k1_dense_traffic_bytes")
+            break
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
 
     out = {
@@ -249,8 +260,15 @@ def main():
         "hot_path_ms_per_image": hp_ms, "mean_detections": n_det_mean,
         "roofline": {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None, "algorithmic_bytes": k1_bytes,
-                     "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_ms[0],
-                     "survey_bytes_4RC(N+1)": 4 * R * (params.num_classes * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)},
+                     "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
+                     "channels_streamed": "2K class channels (box_delta / box_reg_var are merged at the candidates by K2b)"
+                                          if not hp.dense_box_merge else "2K+4+D"},
+        # the same kernel asked for the reference-shaped dense merge of every channel (PI:211-270), for comparison
+        "roofline_dense_merge": {"kernel": "pod_mc_merge_score, mean_delta / mean_reg_var requested", "bound": "hbm",
+                                 "achieved": kd_bytes / (kd_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": kd_bytes / (kd_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_dense,
+                                 "algorithmic_bytes": kd_bytes, "avg_launch_us": 1e3 * kd_avg_ms, "min_launch_us": 1e3 * kd_min_ms,
+                                 "survey_bytes_4RC(N+1)": 4 * R * (params.num_classes * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)},
     }
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on this host's cores, rank 0, N=1 ----------

@@ -302,16 +302,17 @@ __global__ void __launch_bounds__(256) k1_prune_stream(const K1Params P) {
 #pragma unroll 1
     while (seg + 1 < 3 * L && b >= P.pseg_begin[seg + 1]) ++seg;
     const int role = seg / L;
-    const int l = seg - role * L;
+    const int l = L - 1 - (seg - role * L);   // last (smallest) level first: its ragged maps take the scalar path, whose
+                                              // longer chain of dependent loads then overlaps the bulk instead of trailing it
     const PodLevel& lv = P.lv[l];
     const int local_b = b - P.pseg_begin[seg];
     const int HW = lv.H * lv.W;
     if (role == 0) {
         if (P.vec_cls[l]) prune_cls<true, BATCH>(P, lv, l, local_b, HW);
-        else prune_cls<false, 1>(P, lv, l, local_b, HW);
+        else prune_cls<false, 4>(P, lv, l, local_b, HW);
     } else {
         if (role == 1 ? P.vec_delta[l] : P.vec_reg[l]) box_role<true, BATCH>(P, lv, l, role, local_b, HW);
-        else box_role<false, 1>(P, lv, l, role, local_b, HW);
+        else box_role<false, 4>(P, lv, l, role, local_b, HW);
     }
 }
 
@@ -476,7 +477,7 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
         }
         P.word_begin[L] = wb;
         for (int role = 0; role <= 2; ++role)
-            for (int l = 0; l < L; ++l) {
+            for (int l = L - 1; l >= 0; --l) {   // segment order inside a role: last level first (see k1_prune_stream)
                 P.pseg_begin[q++] = pb;
                 const int C = role == 0 ? K : (role == 1 ? 4 : D);
                 const bool active = role == 0 || (N > 1 && C > 0 && (role == 1 ? mean_delta != nullptr : mean_reg_var != nullptr));

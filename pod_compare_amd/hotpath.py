@@ -59,8 +59,13 @@ class HotPath:
     """Workspace + launcher for one (level geometry, head configuration)."""
 
     def __init__(self, shapes: Sequence[Tuple[int, int]], anchors: Sequence[torch.Tensor], params: PathParams,
-                 n_runs: int = 1, has_cls_var: bool = False, cov_dims: int = 0, device="cuda"):
+                 n_runs: int = 1, has_cls_var: bool = False, cov_dims: int = 0, device="cuda", dense_box_merge: bool = False):
+        """dense_box_merge: also have K1 write the merged box_delta / box_reg_var planes (PI:243-270) for every anchor.
+        Nothing downstream reads them -- K2b evaluates the same merge, in the same order, at the <= L*topk candidates
+        (k2_topk_gather.hip) -- so the product path leaves it off and K1 streams the 2K class channels only
+        (108 MB instead of 170 MB per image at BASELINE size).  On = the full dense merge of the reference."""
         self.lib = hip.load()
+        self.dense_box_merge = bool(dense_box_merge)
         self.p = params
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
@@ -89,8 +94,8 @@ class HotPath:
         merged = self.n_runs > 1
         self.mean_cls = f32(self.R * K) if merged else None
         self.mean_cls_var = f32(self.R * K) if merged and has_cls_var else None
-        self.mean_delta = f32(self.R * 4) if merged else None
-        self.mean_reg_var = f32(self.R * D) if merged and D > 0 else None
+        self.mean_delta = f32(self.R * 4) if merged and dense_box_merge else None
+        self.mean_reg_var = f32(self.R * D) if merged and D > 0 and dense_box_merge else None
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
         self.counters = torch.zeros(hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count
         self.cand_count = self.counters[: self.L]
@@ -177,7 +182,8 @@ class HotPath:
         prune = self.has_cls_var and eps_cls is None
         wm = (write_merged or prune) and self.n_runs > 1
         hip.check(lib.pod_mc_merge_score(cfg, lv, P(self.mean_cls) if wm else None, P(self.mean_cls_var) if wm else None,
-                                         P(self.mean_delta) if wm else None, P(self.mean_reg_var) if wm else None,
+                                         P(self.mean_delta) if wm and self.dense_box_merge else None,
+                                         P(self.mean_reg_var) if wm and self.dense_box_merge and self.cov_dims else None,
                                          P(self.cand_keys), P(self.cand_count), P(self.maybe_bits) if prune else None, st),
                   "pod_mc_merge_score")
         if prune:

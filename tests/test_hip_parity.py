@@ -252,3 +252,57 @@ def test_native_candidate_moments_match_replay_statistically():
     assert float(z.max()) < 6.0 and float((z > 3).float().mean()) < 0.02
     rel = (c1[b].diagonal(dim1=1, dim2=2) / c0[a].diagonal(dim1=1, dim2=2) - 1).abs()
     assert float(rel.max()) < 0.25
+
+
+# ---------------------------------------------------------------------------------------------------
+# K1's dense outputs: the merged planes are the reference's PI:211-270 tensors, bit for bit
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("quirk", [True, False])
+@pytest.mark.parametrize("runs,padded,prune", [(10, (384, 512), True), (5, (384, 512), False), (3, (96, 352), True), (2, (160, 224), False)])
+def test_dense_merge_planes_equal_reference_merge(runs, padded, prune, quirk):
+    """pod_mc_merge_score with every mean_* output requested (HotPath(dense_box_merge=True)) against the oracle's
+    left-to-right merge (PI:216-222: x0 twice, last run never, one divide), in both kernels (streaming prune kernel /
+    LDS class-per-wave kernel) and on ragged maps (scalar tails).  Layout: level-major, NCHW inside a level."""
+    from pod_compare_amd import hip
+    ho = synthetic.planted_head_outputs(padded, runs, seed=31 + runs, num_boxes=8)
+    params = hotpath.PathParams(num_classes=ho.num_classes, num_anchors=ho.num_anchors, merge_quirk=quirk)
+    hp = hotpath.HotPath(ho.shapes, ho.anchors, params, n_runs=runs, has_cls_var=True, cov_dims=4, device="cuda", dense_box_merge=True)
+    hd = ho.to("cuda")
+    P, st, lib = hip.ptr, hip.current_stream(), hp.lib
+    lv = hp._levels(hd.cls, hd.delta, hd.cls_var, hd.reg_var, None)
+    for t in (hp.mean_cls, hp.mean_cls_var, hp.mean_delta, hp.mean_reg_var):
+        t.fill_(float("nan"))
+    hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")
+    hip.check(lib.pod_mc_merge_score(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta), P(hp.mean_reg_var),
+                                     P(hp.cand_keys), P(hp.cand_count), P(hp.maybe_bits) if prune else None, st), "k1")
+    torch.cuda.synchronize()
+    if prune:
+        hp.maybe_bits.zero_()
+    for name, out, src in (("cls", hp.mean_cls, ho.cls), ("cls_var", hp.mean_cls_var, ho.cls_var),
+                           ("delta", hp.mean_delta, ho.delta), ("reg_var", hp.mean_reg_var, ho.reg_var)):
+        off = 0
+        for l, x in enumerate(src):
+            ref = po.merge_runs([x[r] for r in range(runs)], quirk=quirk)           # (A*C, H, W)
+            got = out[off:off + ref.numel()].cpu().view_as(ref)
+            assert torch.equal(got, ref), (name, l, float((got - ref).abs().max()))
+            off += ref.numel()
+        assert off == out.numel()
+
+
+def test_product_path_skips_the_dense_box_merge_and_gets_the_same_detections():
+    """The default HotPath leaves box_delta / box_reg_var to K2b (merged at the candidates only); requesting the dense
+    planes as well must not change a single output bit."""
+    ho = synthetic.planted_head_outputs((384, 512), 6, seed=5, num_boxes=10)
+    hd = ho.to("cuda")
+    outs = []
+    for dense in (False, True):
+        params = hotpath.PathParams(num_classes=ho.num_classes, num_anchors=ho.num_anchors)
+        hp = hotpath.HotPath(ho.shapes, ho.anchors, params, n_runs=6, has_cls_var=True, cov_dims=4, device="cuda", dense_box_merge=dense)
+        assert (hp.mean_delta is not None) == dense
+        det = hp.run("bayes_od", hd.cls, hd.delta, hd.cls_var, hd.reg_var, image_size=(380, 500), out_size=(760, 1000))
+        outs.append((det.count(), det.boxes.clone(), det.cov.clone(), det.scores.clone(), det.classes.clone()))
+    assert outs[0][0] == outs[1][0] > 0
+    m = outs[0][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a[:m], b[:m])

@@ -1,5 +1,5 @@
 """Runs only K1 (pod_mc_merge_score) on BASELINE-size planted inputs: for rocprofv3 counter passes.
-    python tools/k1_only.py [iters] [images] [synth]"""
+    python tools/k1_only.py [iters] [images] [synth]        K1_DENSE=1: also merge box_delta / box_reg_var densely"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +12,12 @@ synth = sys.argv[3] if len(sys.argv) > 3 else "planted"
 N = int(os.environ.get("K1_RUNS", "10"))
 dev = torch.device("cuda", 0)
 padded = A.padded_size(*A.resize_shortest_edge(720, 1280))
-heads = [synthetic.planted_head_outputs(padded, N, seed=1000 + i, num_boxes=24, mode=synth, device=dev) for i in range(n_img)]
-hp = hotpath.HotPath(heads[0].shapes, heads[0].anchors, hotpath.PathParams(), n_runs=N, has_cls_var=True, cov_dims=4, device=dev)
+kw = {}
+if os.environ.get("K1_SINGLE", "0") == "1":      # one level with the same number of anchors (diagnostic: cost of the level structure)
+    padded, kw = (1024, 1344), dict(strides=(8,), sizes=(A.ANCHOR_SIZES[0],))
+heads = [synthetic.planted_head_outputs(padded, N, seed=1000 + i, num_boxes=24, mode=synth, device=dev, **kw) for i in range(n_img)]
+hp = hotpath.HotPath(heads[0].shapes, heads[0].anchors, hotpath.PathParams(), n_runs=N, has_cls_var=True, cov_dims=4, device=dev,
+                     dense_box_merge=os.environ.get("K1_DENSE", "0") == "1")
 lvs = [hp._levels(h.cls, h.delta, h.cls_var, h.reg_var, None) for h in heads]
 st = current_stream()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -36,7 +40,7 @@ torch.cuda._sleep(3_000_000)       # let the host run ahead so event pairs are b
 for j in range(iters): launch(j)
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
-print("K1 events: avg %.2f us  min %.2f  med %.2f  max %.2f  (R=%d N=%d, %s)" % (1e3 * sum(ms) / len(ms), 1e3 * ms[0], 1e3 * ms[len(ms) // 2], 1e3 * ms[-1], hp.R, N, synth))
+print("K1 events: avg %.2f us  min %.2f  med %.2f  max %.2f  (R=%d N=%d, %s, %s)" % (1e3 * sum(ms) / len(ms), 1e3 * ms[0], 1e3 * ms[len(ms) // 2], 1e3 * ms[-1], hp.R, N, synth, "all channels" if hp.dense_box_merge else "class channels"))
 if prune:
     mb = sorted(a.elapsed_time(b) for a, b in evb)
     print("K1b events: avg %.2f us  min %.2f" % (1e3 * sum(mb) / len(mb), 1e3 * mb[0]))

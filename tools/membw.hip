@@ -21,6 +21,25 @@ __global__ void merge4(const float4* __restrict__ a, size_t run_stride, float4* 
     for (int r = 1; r < NR; ++r) { acc.x += v[r].x; acc.y += v[r].y; acc.z += v[r].z; acc.w += v[r].w; }
     out[i] = acc;
 }
+// two tensors x NR runs, both merged and stored (K1's class role: logits + log-variances)
+template <int NR, bool NT>
+__global__ void merge4x2(const float4* __restrict__ a, const float4* __restrict__ b, size_t run_stride, float4* __restrict__ oa,
+                         float4* __restrict__ ob, size_t n) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f4 va[NR], vb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        va[r] = NT ? __builtin_nontemporal_load((const f4*)(a + i + r * run_stride)) : *(const f4*)(a + i + r * run_stride);
+        vb[r] = NT ? __builtin_nontemporal_load((const f4*)(b + i + r * run_stride)) : *(const f4*)(b + i + r * run_stride);
+    }
+    f4 x = va[0], y = vb[0];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) { x += va[r]; y += vb[r]; }
+    *(f4*)(oa + i) = x;
+    *(f4*)(ob + i) = y;
+}
 template <int NR>
 __global__ void merge4_gs(const float4* __restrict__ a, size_t run_stride, float4* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -59,6 +78,25 @@ int main() {
         char nm[64];
         snprintf(nm, 64, "merge 9 streams grid-stride %d blk", blocks);
         timeit(nm, [&](int s) { merge4_gs<9><<<blocks, 256>>>(in[s], run_elems, out[s], run_elems); }, mbytes);
+    }
+    // size dependence: the same merge on the 2K = 14 class channels only (108 MB, the product path's K1) and on 4x the data
+    {
+        const size_t re14 = (size_t)193374 * 14 / 4;
+        timeit("merge 9 streams, 14 ch (108 MB)", [&](int s) { merge4<9><<<(re14 + 255) / 256, 256>>>(in[s], run_elems, out[s], re14); }, (double)re14 * 16 * 10);
+        {   // 2 x 9 streams of 7 channels each, run stride = one 7-channel plane set (the real (N, A*K, H, W) layout)
+            const size_t re7 = (size_t)193374 * 7 / 4;
+            float4* b2 = in[0] + re7 * 10;   // second tensor right behind the first (10 runs each)
+            timeit("merge 2x9 streams, 7+7 ch, nt", [&](int s) { merge4x2<9, true><<<(re7 + 255) / 256, 256>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
+            timeit("merge 2x9 streams, 7+7 ch", [&](int s) { merge4x2<9, false><<<(re7 + 255) / 256, 256>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
+            timeit("merge 9 streams, 14 ch, stride 14", [&](int s) { merge4<9><<<(re14 + 255) / 256, 256>>>(in[s], re14, out[s], re14); }, (double)re14 * 16 * 10);
+            (void)b2;
+        }
+        float4 *big, *bigo;
+        const size_t reb = run_elems * 4;
+        CK(hipMalloc(&big, reb * 16 * 10)); CK(hipMalloc(&bigo, reb * 16)); CK(hipMemset(big, 1, reb * 16 * 10));
+        timeit("merge 9 streams, 88 ch (681 MB)", [&](int) { merge4<9><<<(reb + 255) / 256, 256>>>(big, reb, bigo, reb); }, (double)reb * 16 * 10);
+        timeit("empty-ish launch (1 block)", [&](int s) { copy4<<<1, 64>>>(in[s], out[s], 1); }, 0);
+        hipFree(big); hipFree(bigo);
     }
     const size_t cn = run_elems * 5;    // 85 MB read + 85 MB write
     timeit("copy float4 (85 MB -> 85 MB)", [&](int s) { copy4<<<(cn + 255) / 256, 256>>>(in[s], in[s] + cn, cn); }, (double)cn * 32);

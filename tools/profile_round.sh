@@ -13,7 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -o full -- pyt
 # (3) HBM traffic of K1: separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
+  K1_DENSE=1 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_dense_$c -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
 python tools/k1_only.py 60 > $OUT/k1_events.txt 2>&1
+K1_DENSE=1 python tools/k1_only.py 60 >> $OUT/k1_events.txt 2>&1
 ls -R $OUT | head -40

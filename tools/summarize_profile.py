@@ -20,6 +20,10 @@ for name, title in (("hotpath/hp", "`rocprofv3 --kernel-trace --stats -- python 
     for r in rows[:22]:
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    if any("naive_conv" in r["Name"] for r in rows[:22]):
+        lines += ["", "(`naive_conv_*` and most of the first rows are MIOpen's find pass on the first image -- every solver is tried once per",
+                  "conv shape, including the naive reference kernel -- not the steady state: the timed steps take ms_per_step in the bench",
+                  "line below, see `tools/cnn_profile.py` / DESIGN.md for the steady-state conv breakdown.)"]
     lines.append("")
     out = os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name.split("/")[0]))
     with open(out, "w") as fo:
@@ -33,19 +37,28 @@ for j in ("bench_hotpath.json", "bench_full.json"):
         txt = [l for l in open(p) if l.startswith("{")]
         if txt:
             lines += ["## bench line (%s)" % j, "", "```json", txt[-1].strip(), "```", ""]
-pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
-    f = glob.glob(os.path.join(src, "pmc_%s" % c, "*counter_collection.csv"))
-    if not f:
+def k1_counters(prefix):
+    pm = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+        f = glob.glob(os.path.join(src, "pmc_%s%s" % (prefix, c), "*counter_collection.csv"))
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pm[k] = (sum(v) / len(v), min(v), max(v), len(v))
+    return pm
+
+traffic = {"workload": {"anchors_R": 193374, "mc_runs": 10, "config": "cfg3", "synthetic_mode": "planted"},
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/k1_only.py 12; FETCH_SIZE x2 (gfx950)"}
+for prefix, key, what in (("", "k1_class_traffic_bytes", "product path: K1 streams the 2K class channels"),
+                          ("dense_", "k1_dense_traffic_bytes", "K1_DENSE=1: dense merge of all 2K+4+D channels")):
+    pm = k1_counters(prefix)
+    if not pm:
         continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        pm[k] = (sum(v) / len(v), min(v), max(v), len(v))
-if pm:
-    lines += ["## PMC counters of K1 (`k1_prune_stream` / `k1_mc_merge_score`) (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)", "",
+    lines += ["## PMC counters of K1 (`k1_prune_stream`), %s (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)" % what, "",
               "| counter | mean per launch | min | max | launches |", "|---|---|---|---|---|"]
     for k, (m, lo, hi, n) in sorted(pm.items()):
         lines.append("| %s | %.6g | %.6g | %.6g | %d |" % (k, m, lo, hi, n))
@@ -56,10 +69,11 @@ if pm:
                   "", "    reads  = 2 * FETCH_SIZE * 1024 = %.1f MB" % (2 * fetch_b / 1e6),
                   "    writes =     WRITE_SIZE * 1024 = %.1f MB" % (write_b / 1e6),
                   "    traffic = %.0f bytes" % (2 * fetch_b + write_b), ""]
-        json.dump({"k1_traffic_bytes": 2 * fetch_b + write_b, "fetch_bytes_corrected": 2 * fetch_b, "write_bytes": write_b,
-                   "workload": {"anchors_R": 193374, "mc_runs": 10, "config": "cfg3", "synthetic_mode": "planted"},
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/k1_only.py 12; FETCH_SIZE x2 (gfx950)"},
-                  open(os.path.join(dst, "%s_k1_traffic.json" % tag), "w"))
+        traffic[key] = 2 * fetch_b + write_b
+        traffic[key.replace("traffic_bytes", "fetch_bytes_corrected")] = 2 * fetch_b
+        traffic[key.replace("traffic_bytes", "write_bytes")] = write_b
+if len(traffic) > 2:
+    json.dump(traffic, open(os.path.join(dst, "%s_k1_traffic.json" % tag), "w"))
 ev = os.path.join(src, "k1_events.txt")
 if os.path.exists(ev):
     lines += ["## K1 alone, HIP events (`python tools/k1_only.py 60`)", "", "```"] + [l.rstrip() for l in open(ev) if "events" in l or "counts" in l] + ["```", ""]
