@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 1
+#define POD_ABI_VERSION 2
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -104,7 +104,8 @@ int pod_abi_version(void);
  *     key = (float_bits(score) << 32) | (0xFFFFFFFF - r)      (descending key = score desc, r asc)
  * mean_* : dev, level-concatenated plane layout: level l starts at anchor_base_l * C elements.
  * cand_keys : dev uint64[R_total], level l's list starts at anchor_base_l.
- * cand_count: dev int32[n_levels], MUST be zero on entry (pod_reset_counters).
+ * cand_count: dev int32[n_levels], MUST be zero on entry (pod_reset_counters once after allocation;
+ *             pod_level_topk leaves it zeroed again).
  * HBM-bound; algorithmic bytes per image = 4 * R * (2K + 4 + D) * (N + 1)  (SURVEY 8d). */
 int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
                        float* mean_cls, float* mean_cls_var, float* mean_delta, float* mean_reg_var,
@@ -130,9 +131,11 @@ int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
  * Exact top-`topk` of each level's candidate list, sorted by descending key (ties: lower anchor
  * index first).  One workgroup per level: LDS bitonic sort, preceded by an 8-pass radix select
  * when a level has more than POD_MAX_TOPK candidates.
- * sel_keys : dev uint64[n_levels * topk];  sel_count : dev int32[n_levels] (written). */
+ * sel_keys : dev uint64[n_levels * topk];  sel_count : dev int32[n_levels] (written).
+ * cand_count is consumed: every level's counter is left at ZERO, ready for the next image's
+ * pod_mc_merge_score (no pod_reset_counters between images). */
 int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
-                   const int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream);
+                   int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream);
 
 /* ---- K2b gather_candidates -----------------------------------------------------------------
  * Replaces: the index gathers PI:305-338 and the level concatenation PI:341-342, 387-388.
@@ -257,6 +260,44 @@ int pod_match_groundtruth(const float* det_boxes, const float* det_probs, const 
  * Replaces: compute_reg_scores core/evaluation_tools/scoring_rules.py:68-74
  * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */
 int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t n, float* nll, pod_stream_t stream);
+
+/* ---- one image, one call --------------------------------------------------------------------
+ * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
+ * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence
+ *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_candidates -> pod_decode_cov
+ *   -> pod_nms_cluster -> {pod_bayes_fuse | pod_anchor_stats_merge | -} -> pod_finalize
+ * enqueued from C on `stream`, in-kernel Philox draws (levels[].eps_cls must be NULL: the eps-replay parity
+ * mode needs the host between launches and uses the individual entry points).  Nothing here
+ * synchronises or allocates; the workspace is caller-owned, every pointer is device memory sized as the
+ * individual entry points document, n_capacity = n_levels * topk.  mean_delta / mean_reg_var may be NULL
+ * (the merged box planes are not needed downstream), mean_cls / mean_cls_var only when n_runs == 1. */
+typedef struct PodWorkspace {
+    const float* anchors;          /* (R, 4) level-concatenated */
+    float* mean_cls;  float* mean_cls_var;  float* mean_delta;  float* mean_reg_var;
+    uint64_t* cand_keys;  int32_t* cand_count;  uint64_t* maybe_bits;
+    uint64_t* sel_keys;   int32_t* sel_count;
+    int32_t* n_total;     int32_t* cand_anchor_idx;  int32_t* cand_level;  int32_t* cand_class;
+    float* cand_score;    float* cand_probs;  float* cand_delta;  float* cand_reg_var;  float* cand_anchor;
+    float* cand_run_delta;
+    float* boxes;  float* cov;
+    int32_t* keep;  int32_t* n_keep;  void* nms_scratch;
+    float* m_boxes;  float* m_cov;  float* m_scores;  int32_t* m_classes;  float* m_probs;
+    int32_t n_capacity;  int32_t reserved;
+} PodWorkspace;
+
+typedef struct PodDetections {     /* pod_finalize's outputs */
+    float* boxes;  float* cov;  float* scores;  int32_t* classes;  float* probs;  float* records;  int32_t* n_det;
+} PodDetections;
+
+#define POD_MODE_STANDARD_NMS 0    /* also the pre-NMS MC-dropout / ensemble modes (PI:402-442, PI:483-505) */
+#define POD_MODE_BAYES_OD 1
+#define POD_MODE_ANCHOR_STATISTICS 2
+
+/* image_h/w: network input size (IU:39-41), out_h/w: output resolution (PI:106-107);
+ * box_merge_mode / cls_merge_mode as in pod_bayes_fuse (ignored by the other modes). */
+int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
+                  int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
+                  int32_t out_h, int32_t out_w, const PodDetections* out, pod_stream_t stream);
 
 #ifdef __cplusplus
 }

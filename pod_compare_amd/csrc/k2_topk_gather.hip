@@ -41,7 +41,7 @@ struct K2Params {
     int32_t anchor_base[POD_MAX_LEVELS];
     int32_t topk;
     const uint64_t* cand_keys;
-    const int32_t* cand_count;
+    int32_t* cand_count;
     uint64_t* sel_keys;
     int32_t* sel_count;
 };
@@ -55,6 +55,8 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     const int tid = threadIdx.x;
     const uint64_t* keys = P.cand_keys + P.anchor_base[l];
     const int C = P.cand_count[l];
+    __syncthreads();
+    if (tid == 0) P.cand_count[l] = 0;   // consumed: the next image's K1 appends from zero (no reset launch per image)
     const int k = min(P.topk, C);
     int n_sort;
     if (C <= SORT_CAP) {
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
 }  // namespace pod
 
 extern "C" int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
-                              const int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream) {
+                              int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream) {
     if (!cfg || !levels || !cand_keys || !cand_count || !sel_keys || !sel_count) return POD_E_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS || cfg->topk < 1 || cfg->topk > POD_MAX_TOPK) return POD_E_INVALID;
     pod::K2Params P;

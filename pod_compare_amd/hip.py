@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 1
+POD_ABI_VERSION = 2
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -27,7 +27,8 @@ POD_MAX_DETECTIONS = 128
 EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
-           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_match_groundtruth")
+           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_match_groundtruth", "pod_run_image")
+POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
 class PodLevel(Structure):
@@ -42,6 +43,20 @@ class PodConfig(Structure):
                 ("prop_samples", c_int32), ("topk", c_int32), ("max_detections", c_int32),
                 ("score_thresh", c_float), ("nms_thresh", c_float), ("affinity_thresh", c_float),
                 ("box_weights", c_float * 4), ("philox_seed", c_uint64)]
+
+
+class PodWorkspace(Structure):
+    """include/pod_mi355x.h: PodWorkspace (device pointers of the per-geometry workspace, caller-owned)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "anchors", "mean_cls", "mean_cls_var", "mean_delta", "mean_reg_var", "cand_keys", "cand_count", "maybe_bits",
+        "sel_keys", "sel_count", "n_total", "cand_anchor_idx", "cand_level", "cand_class", "cand_score", "cand_probs",
+        "cand_delta", "cand_reg_var", "cand_anchor", "cand_run_delta", "boxes", "cov", "keep", "n_keep", "nms_scratch",
+        "m_boxes", "m_cov", "m_scores", "m_classes", "m_probs")] + [("n_capacity", c_int32), ("reserved", c_int32)]
+
+
+class PodDetections(Structure):
+    """include/pod_mi355x.h: PodDetections (pod_finalize's outputs)."""
+    _fields_ = [(n, c_void_p) for n in ("boxes", "cov", "scores", "classes", "probs", "records", "n_det")]
 
 
 class PodError(RuntimeError):
@@ -89,6 +104,8 @@ def load() -> ctypes.CDLL:
     lib.pod_reg_nll.argtypes = [P, P, P, c_int32, P, P]
     lib.pod_match_groundtruth.argtypes = [P, P, P, P, c_int32, P, P, P, c_int32, c_int32, c_float, c_float, P, P, P, P, P, P]
     lib.pod_relu_dropout.argtypes = [P, c_int64, c_float, c_uint64, c_uint64, P]
+    lib.pod_run_image.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
     for name in EXPORTS:
         if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words"):
             getattr(lib, name).restype = ctypes.c_int

@@ -8,6 +8,7 @@ The eps-replay parity mode needs one host sync to learn the candidate count n be
 (1000, n, 4) normal tensor can be drawn -- exactly where the reference draws it
 (probabilistic_inference.py:351-356).
 """
+import functools
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -36,18 +37,52 @@ class PathParams:
     philox_seed: int = 0x5EED
 
 
-@dataclass
 class DeviceDetections:
-    """Fixed-capacity detection buffers in HBM + device count (no host sync until `.count()`)."""
-    image_size: Tuple[int, int]
-    boxes: torch.Tensor          # (max_det, 4) fp32 XYXY in output pixels
-    cov: torch.Tensor            # (max_det, 4, 4)
-    scores: torch.Tensor         # (max_det,)
-    classes: torch.Tensor        # (max_det,) int32
-    probs: torch.Tensor          # (max_det, K)
-    records: torch.Tensor        # (max_det, 6 + K + 16) fixed-stride JSON payload (XYWH box, T cov T^T)
-    n_det: torch.Tensor          # () int32 on device
-    _n: Optional[int] = None
+    """Fixed-capacity detection buffers in HBM + device count (no host sync until `.count()`).
+
+    One allocation per image; the field tensors are views made on first access (the launch path only needs the
+    pointers, so a throughput loop that reads `records` / `n_det` never pays for the other views)."""
+    __slots__ = ("image_size", "buf", "K", "md", "_n", "_views")
+
+    def __init__(self, image_size: Tuple[int, int], num_classes: int, max_det: int, device):
+        self.image_size, self.K, self.md, self._n, self._views = image_size, num_classes, max_det, None, {}
+        self.buf = torch.empty(self.layout(num_classes, max_det)["end"][0], dtype=torch.float32, device=device)
+
+    @staticmethod
+    @functools.lru_cache(maxsize=None)
+    def layout(K: int, md: int):
+        """name -> (offset in floats, shape, elements); 16-byte aligned segments."""
+        out, off = {}, 0
+        for name, shape in (("boxes", (md, 4)), ("cov", (md, 4, 4)), ("scores", (md,)), ("classes", (md,)), ("probs", (md, K)),
+                            ("records", (md, 6 + K + 16)), ("n_det", ())):
+            n = 1
+            for d in shape:
+                n *= d
+            out[name] = (off, shape, n)
+            off += (n + 3) // 4 * 4
+        out["end"] = (off, (), 0)
+        return out
+
+    def ptr(self, name: str) -> int:
+        return self.buf.data_ptr() + 4 * self.layout(self.K, self.md)[name][0]
+
+    def _view(self, name: str) -> torch.Tensor:
+        v = self._views.get(name)
+        if v is None:
+            off, shape, n = self.layout(self.K, self.md)[name]
+            v = self.buf[off:off + n]
+            if name in ("classes", "n_det"):
+                v = v.view(torch.int32)
+            v = self._views[name] = v.view(shape)
+        return v
+
+    boxes = property(lambda self: self._view("boxes"))        # (max_det, 4) fp32 XYXY in output pixels
+    cov = property(lambda self: self._view("cov"))            # (max_det, 4, 4)
+    scores = property(lambda self: self._view("scores"))      # (max_det,)
+    classes = property(lambda self: self._view("classes"))    # (max_det,) int32
+    probs = property(lambda self: self._view("probs"))        # (max_det, K)
+    records = property(lambda self: self._view("records"))    # (max_det, 6 + K + 16) fixed-stride JSON payload (XYWH box, T cov T^T)
+    n_det = property(lambda self: self._view("n_det"))        # () int32 on device
 
     def count(self) -> int:
         if self._n is None:
@@ -122,6 +157,20 @@ class HotPath:
         self.m_classes, self.m_probs = i32(md), f32(md, K)
         self.cfg = self._make_cfg()
         self._levels_t = hip.PodLevel * self.L
+        ws = hip.PodWorkspace()
+        for name, t in (("anchors", self.anchors), ("mean_cls", self.mean_cls), ("mean_cls_var", self.mean_cls_var),
+                        ("mean_delta", self.mean_delta), ("mean_reg_var", self.mean_reg_var), ("cand_keys", self.cand_keys),
+                        ("cand_count", self.cand_count), ("maybe_bits", self.maybe_bits), ("sel_keys", self.sel_keys),
+                        ("sel_count", self.sel_count), ("n_total", self.n_total), ("cand_anchor_idx", self.cand_anchor_idx),
+                        ("cand_level", self.cand_level), ("cand_class", self.cand_class), ("cand_score", self.cand_score),
+                        ("cand_probs", self.cand_probs), ("cand_delta", self.cand_delta), ("cand_reg_var", self.cand_reg_var),
+                        ("cand_anchor", self.cand_anchor), ("cand_run_delta", self.cand_run_delta), ("boxes", self.boxes),
+                        ("cov", self.cov), ("keep", self.keep), ("n_keep", self.n_keep), ("nms_scratch", self.nms_scratch),
+                        ("m_boxes", self.m_boxes), ("m_cov", self.m_cov), ("m_scores", self.m_scores),
+                        ("m_classes", self.m_classes), ("m_probs", self.m_probs)):
+            setattr(ws, name, hip.ptr(t))
+        ws.n_capacity = self.n_cap
+        self.ws = ws
 
     # ------------------------------------------------------------------------------------------
     def _make_cfg(self) -> hip.PodConfig:
@@ -177,7 +226,7 @@ class HotPath:
         lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
         self._lv_keepalive = (lv, eps_cls)
         P = hip.ptr
-        hip.check(lib.pod_reset_counters(P(self.counters), hip.POD_MAX_LEVELS, st), "pod_reset_counters")
+        # cand_count is zero here: allocated zeroed, and pod_level_topk consumes (re-zeroes) it every image
         # prune mode: native RNG with a variance head -> dense pass flags, K1b samples (see k1_mc_merge_score.hip)
         prune = self.has_cls_var and eps_cls is None
         wm = (write_merged or prune) and self.n_runs > 1
@@ -226,13 +275,7 @@ class HotPath:
                                            hip.current_stream()), "pod_nms_cluster")
 
     def new_detections(self, out_size) -> DeviceDetections:
-        K, md, dev = self.p.num_classes, hip.POD_MAX_DETECTIONS, self.device
-        return DeviceDetections(
-            (int(out_size[0]), int(out_size[1])),
-            torch.empty((md, 4), dtype=torch.float32, device=dev), torch.empty((md, 4, 4), dtype=torch.float32, device=dev),
-            torch.empty((md,), dtype=torch.float32, device=dev), torch.empty((md,), dtype=torch.int32, device=dev),
-            torch.empty((md, K), dtype=torch.float32, device=dev), torch.empty((md, 6 + K + 16), dtype=torch.float32, device=dev),
-            torch.empty((), dtype=torch.int32, device=dev))
+        return DeviceDetections((int(out_size[0]), int(out_size[1])), self.p.num_classes, hip.POD_MAX_DETECTIONS, self.device)
 
     def finalize(self, keep, n_rows, boxes, cov, scores, classes, probs, image_size, out_size) -> DeviceDetections:
         """K7: gather through `keep` (or identity), rescale to the output resolution, records (IU:42-53, :374-425, :428-502)."""
@@ -240,8 +283,9 @@ class HotPath:
         out = self.new_detections(out_size)
         sx, sy = out_size[1] / image_size[1], out_size[0] / image_size[0]   # IU:394-396
         hip.check(self.lib.pod_finalize(self.cfg, P(keep), P(n_rows), P(boxes), P(cov), P(scores), P(classes), P(probs), sx, sy,
-                                        float(out_size[0]), float(out_size[1]), P(out.boxes), P(out.cov), P(out.scores),
-                                        P(out.classes), P(out.probs), P(out.records), P(out.n_det), hip.current_stream()),
+                                        float(out_size[0]), float(out_size[1]), out.ptr("boxes"), out.ptr("cov"), out.ptr("scores"),
+                                        out.ptr("classes"), out.ptr("probs"), out.ptr("records"), out.ptr("n_det"),
+                                        hip.current_stream()),
                   "pod_finalize")
         return out
 
@@ -275,14 +319,39 @@ class HotPath:
         return self.finalize(keep, self.n_keep, b, c, s, cl, pr, image_size, out_size)
 
     # ------------------------------------------------------------------------------------------
+    _MODE_ID = {"standard_nms": hip.POD_MODE_STANDARD_NMS, "mc_dropout_ensembles": hip.POD_MODE_STANDARD_NMS,
+                "ensembles": hip.POD_MODE_STANDARD_NMS, "bayes_od": hip.POD_MODE_BAYES_OD,
+                "anchor_statistics": hip.POD_MODE_ANCHOR_STATISTICS}
+
+    def run_image(self, mode: str, cls, delta, cls_var, reg_var, image_size, out_size,
+                  box_merge_mode: str = "bayesian_inference", cls_merge_mode: str = "max_score") -> DeviceDetections:
+        """pod_run_image: K1 .. K7 of one image enqueued by one C call (native Philox draws)."""
+        if mode not in MODES:
+            raise ValueError("Invalid inference mode {}.".format(mode))   # PI:100-103
+        if mode == "bayes_od" and not self.has_covariance:
+            raise hip.PodError("bayes_od needs box covariances (a reg_var head or MC runs)")
+        lv = self._levels(cls, delta, cls_var, reg_var, None)
+        self._lv_keepalive = (lv, None)
+        out = self.new_detections(out_size)
+        d = hip.PodDetections(out.ptr("boxes"), out.ptr("cov"), out.ptr("scores"), out.ptr("classes"), out.ptr("probs"),
+                              out.ptr("records"), out.ptr("n_det"))
+        bm = {"bayesian_inference": 0, "covariance_intersection": 1}[box_merge_mode]
+        cm = {"max_score": 0, "bayesian_inference": 1}[cls_merge_mode]
+        hip.check(self.lib.pod_run_image(self.cfg, lv, self.ws, self._MODE_ID[mode], bm, cm, int(image_size[0]), int(image_size[1]),
+                                         int(out_size[0]), int(out_size[1]), d, hip.current_stream()), "pod_run_image")
+        return out
+
     def run(self, mode: str, cls, delta, cls_var=None, reg_var=None, *, image_size, out_size,
             eps_fn: Optional[Callable] = None, box_merge_mode: str = "bayesian_inference",
-            cls_merge_mode: str = "max_score", write_merged: bool = True) -> DeviceDetections:
+            cls_merge_mode: str = "max_score", write_merged: bool = True, one_call: bool = True) -> DeviceDetections:
         """predictor(input_im) minus the conv net: dense head tensors -> detections.
 
-        eps_fn=None  : native mode, in-kernel Philox4x32-10, fully asynchronous.
+        eps_fn=None  : native mode, in-kernel Philox4x32-10, fully asynchronous; with one_call the whole launch
+          sequence is enqueued by ONE C call (pod_run_image) instead of one ctypes call per kernel.
         eps_fn=callable(shape)->CPU tensor : eps-replay parity mode; draws are requested in the
           reference's order (one (S_cls, R_l, K) tensor per level, then one (1000, n, 4))."""
+        if eps_fn is None and one_call and write_merged:
+            return self.run_image(mode, cls, delta, cls_var, reg_var, image_size, out_size, box_merge_mode, cls_merge_mode)
         eps_cls = eps_prop = None
         if eps_fn is not None and self.has_cls_var:
             A, K = self.p.num_anchors, self.p.num_classes
