@@ -45,14 +45,18 @@ def test_struct_layout_matches_c(lib_path, tmp_path):
     """sizeof/offsetof of the ctypes mirrors against the C header (compiled with gcc)."""
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pod_mi355x.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PodLevel), offsetof(PodLevel, run_stride_cls),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PodLevel), offsetof(PodLevel, run_stride_cls),'
                    ' offsetof(PodLevel, H), sizeof(PodConfig), offsetof(PodConfig, score_thresh), offsetof(PodConfig, box_weights),'
-                   ' offsetof(PodConfig, philox_seed)); return 0;}\n')
+                   ' offsetof(PodConfig, philox_seed), sizeof(PodWorkspace), offsetof(PodWorkspace, cand_run_delta),'
+                   ' offsetof(PodWorkspace, m_probs), offsetof(PodWorkspace, n_capacity), sizeof(PodDetections),'
+                   ' offsetof(PodDetections, n_det)); return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(hip.PodLevel), hip.PodLevel.run_stride_cls.offset, hip.PodLevel.H.offset, ctypes.sizeof(hip.PodConfig),
-            hip.PodConfig.score_thresh.offset, hip.PodConfig.box_weights.offset, hip.PodConfig.philox_seed.offset]
+            hip.PodConfig.score_thresh.offset, hip.PodConfig.box_weights.offset, hip.PodConfig.philox_seed.offset,
+            ctypes.sizeof(hip.PodWorkspace), hip.PodWorkspace.cand_run_delta.offset, hip.PodWorkspace.m_probs.offset,
+            hip.PodWorkspace.n_capacity.offset, ctypes.sizeof(hip.PodDetections), hip.PodDetections.n_det.offset]
     assert got == want
 
 
@@ -63,6 +67,8 @@ def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
     assert lib.pod_reset_counters(None, 4, None) == -1
     assert lib.pod_level_topk(cfg, None, None, None, None, None, None) == -1
     assert lib.pod_reg_nll(None, None, None, 3, None, None) == -1
+    assert lib.pod_run_image(cfg, None, None, 0, 0, 0, 10, 10, 10, 10, None, None) == -1
+    assert lib.pod_nms_cluster(cfg, None, 8, None, None, None, None, None, None, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):
