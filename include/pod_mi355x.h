@@ -243,6 +243,16 @@ int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_row
  * Element e uses Philox counter (offset + e/4): pass a different `offset` (or seed) per call. */
 int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
 
+/* ---- conv-net side: bias + residual + ReLU + dropout in one pass ------------------------------------
+ * Replaces: the element-wise tail of every convolution of the model (PR:403-424 head subnets; detectron2's
+ * ResNet bottleneck `relu(conv3(x) + shortcut(x))` and FrozenBN-folded `relu(conv(x) + b)` of the backbone):
+ * x (N, C, H, W) fp32, in place:  x = dropout(relu((x + bias[c]) + (residual + res_bias[c])), p).
+ * torch runs the conv bias as a separate add, then clamp, then dropout (2-4 passes over the activation); the
+ * conv is called without bias and this is the only pass.  bias / residual / res_bias may be NULL, relu 0/1,
+ * p = 0 disables dropout; Philox counters as pod_relu_dropout.  n = N*C*H*W, HW = H*W. */
+int pod_bias_act(float* x, const float* bias, const float* residual, const float* res_bias, int64_t n, int32_t C,
+                 int64_t HW, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set
  * in one call.  Images are concatenated: image m owns detections [det_off[m], det_off[m+1]) and ground-truth boxes

@@ -35,7 +35,97 @@ __global__ void __launch_bounds__(256) k_relu_dropout(float* __restrict__ x, int
     }
 }
 
+// pod_bias_act: x[n, c, :] = dropout(relu((x + bias[c]) + (residual + res_bias[c])), p) in place, every stage optional.
+// torch's conv on ROCm is MIOpen's kernel followed by a separate bias `add_`; with ReLU (+ dropout, + the residual
+// add of a bottleneck) that is 2-4 element-wise passes over the activation.  The convolution is called without its
+// bias and this ONE pass does the rest.  Same Philox counters as k_relu_dropout (counter = offset + float4 index).
+struct BiasActParams {
+    float* x;
+    const float* bias;       // [C] or NULL
+    const float* residual;   // same shape as x or NULL
+    const float* res_bias;   // [C] or NULL (bias of the shortcut conv that produced `residual`)
+    int64_t n4, n, HW;
+    int32_t C, relu;
+    uint32_t thresh;         // 0 = no dropout
+    float scale;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float bias_act_one(float v, float b, float r, int relu, bool keep, float scale) {
+    v = (v + b) + r;
+    if (relu) v = fmaxf(v, 0.0f);
+    return keep ? v * scale : 0.0f;
+}
+
+template <bool ALIGNED_PLANES>
+__global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n4; i += stride) {
+        u32x4 r = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (P.thresh) {
+            const uint64_t ctr = P.offset + (uint64_t)i;
+            r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT}, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+        }
+        float4 v = *reinterpret_cast<const float4*>(P.x + i * 4);
+        float4 res = float4{0.f, 0.f, 0.f, 0.f};
+        if (P.residual) res = *reinterpret_cast<const float4*>(P.residual + i * 4);
+        float b[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ALIGNED_PLANES) {   // H*W % 4 == 0: the four elements share a channel
+            const int c = (int)(((i * 4) / P.HW) % P.C);
+            if (P.bias) b[0] = b[1] = b[2] = b[3] = P.bias[c];
+            if (P.res_bias) rb[0] = rb[1] = rb[2] = rb[3] = P.res_bias[c];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (int)(((i * 4 + j) / P.HW) % P.C);
+                if (P.bias) b[j] = P.bias[c];
+                if (P.res_bias) rb[j] = P.res_bias[c];
+            }
+        }
+        v.x = bias_act_one(v.x, b[0], res.x + rb[0], P.relu, r.x >= P.thresh, P.scale);
+        v.y = bias_act_one(v.y, b[1], res.y + rb[1], P.relu, r.y >= P.thresh, P.scale);
+        v.z = bias_act_one(v.z, b[2], res.z + rb[2], P.relu, r.z >= P.thresh, P.scale);
+        v.w = bias_act_one(v.w, b[3], res.w + rb[3], P.relu, r.w >= P.thresh, P.scale);
+        *reinterpret_cast<float4*>(P.x + i * 4) = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (P.n & 3)) {   // tail (n % 4 elements)
+        const int64_t e = P.n4 * 4 + threadIdx.x;
+        bool keep = true;
+        if (P.thresh) {
+            const uint64_t ctr = P.offset + (uint64_t)P.n4 + threadIdx.x;
+            const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, STREAM_DROPOUT}, (uint32_t)P.seed,
+                                          (uint32_t)(P.seed >> 32));
+            keep = r.x >= P.thresh;
+        }
+        const int c = (int)((e / P.HW) % P.C);
+        const float res = (P.residual ? P.residual[e] : 0.0f) + (P.res_bias ? P.res_bias[c] : 0.0f);
+        P.x[e] = bias_act_one(P.x[e], P.bias ? P.bias[c] : 0.0f, res, P.relu, keep, P.scale);
+    }
+}
+
 }  // namespace pod
+
+extern "C" int pod_bias_act(float* x, const float* bias, const float* residual, const float* res_bias, int64_t n, int32_t C,
+                            int64_t HW, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
+    if (!x || n < 0 || C < 1 || HW < 1 || !(p >= 0.0f && p < 1.0f)) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(residual) & 15u) != 0) return POD_E_INVALID;
+    if (res_bias && !residual) return POD_E_INVALID;
+    if (n % ((int64_t)C * HW) != 0) return POD_E_INVALID;   // x is (N, C, H, W)
+    if (n == 0) return POD_OK;
+    pod::BiasActParams P;
+    P.x = x; P.bias = bias; P.residual = residual; P.res_bias = res_bias;
+    P.n4 = n / 4; P.n = n; P.HW = HW; P.C = C; P.relu = relu;
+    P.thresh = (uint32_t)((double)p * 4294967296.0);   // keep iff u32 >= p * 2^32
+    P.scale = 1.0f / (1.0f - p);
+    P.seed = seed; P.offset = offset;
+    int64_t blocks = (P.n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride: 16 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    if (HW % 4 == 0) hipLaunchKernelGGL(pod::k_bias_act<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k_bias_act<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
 
 extern "C" int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
     if (!x || n < 0 || !(p >= 0.0f && p < 1.0f) || (reinterpret_cast<uintptr_t>(x) & 15u) != 0) return POD_E_INVALID;

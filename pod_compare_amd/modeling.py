@@ -74,6 +74,55 @@ def fold_frozen_bn(module: nn.Module) -> int:
     return n
 
 
+def _plain_conv(m) -> Optional[nn.Conv2d]:
+    """The biased conv behind `m` if its element-wise tail can be fused: a Conv2d, or a folded (conv, Identity) pair."""
+    if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.Identity):
+        m = m[0]
+    return m if isinstance(m, nn.Conv2d) else None
+
+
+FUSE_CONV_TAIL = True     # GPU only: conv without bias + ONE pod_bias_act pass (bias, residual, ReLU, dropout)
+
+
+def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None, residual_module=None,
+                  residual_input: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """act(m(x) [+ residual]) with the element-wise tail in one HIP pass.
+
+    torch's conv on ROCm is MIOpen's kernel plus a separate bias `add_`; followed by clamp (and the bottleneck's add, and
+    dropout) that is 2-4 read+write passes over the activation.  Here the conv runs without its bias and pod_bias_act does
+    `dropout(relu((y + b[c]) + (r + rb[c])))` in place.  `residual_module(residual_input)` (a shortcut conv) is evaluated without
+    its bias too and folded into the same pass.  CPU tensors / unfolded BN / non-fp32 take the plain torch ops."""
+    conv = _plain_conv(m)
+    rconv = _plain_conv(residual_module) if residual_module is not None else None
+    fuse = (FUSE_CONV_TAIL and conv is not None and x.is_cuda and x.dtype == torch.float32 and
+            (residual_module is None or rconv is not None))
+    if not fuse:
+        y = m(x)
+        if residual_module is not None:
+            residual = residual_module(residual_input)
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = F.relu_(y)
+        return F.dropout(y, dropout_p, training=True) if dropout_p > 0.0 else y
+    from . import hip
+    lib = hip.load()
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    res_bias = None
+    if rconv is not None:
+        residual = F.conv2d(residual_input, rconv.weight, None, rconv.stride, rconv.padding, rconv.dilation, rconv.groups)
+        res_bias = rconv.bias
+    if not y.is_contiguous():
+        y = y.contiguous()
+    if residual is not None:
+        assert residual.shape == y.shape
+        residual = residual.contiguous()
+    C, HW = y.shape[1], y.shape[2] * y.shape[3]
+    hip.check(lib.pod_bias_act(y.data_ptr(), hip.ptr(conv.bias), hip.ptr(residual), hip.ptr(res_bias), y.numel(), C, HW,
+                               1 if relu else 0, float(dropout_p), seed, offset, hip.current_stream()), "pod_bias_act")
+    return y
+
+
 def _conv_bn(cin, cout, k, stride=1, padding=0):
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill
@@ -89,11 +138,11 @@ class Bottleneck(nn.Module):
         self.conv3 = _conv_bn(mid, cout, 1)
 
     def forward(self, x):
-        out = F.relu_(self.conv1(x))
-        out = F.relu_(self.conv2(out))
-        out = self.conv3(out)
-        sc = x if self.shortcut is None else self.shortcut(x)
-        return F.relu_(out + sc)
+        out = conv_bias_act(self.conv1, x, relu=True)
+        out = conv_bias_act(self.conv2, out, relu=True)
+        if self.shortcut is None:
+            return conv_bias_act(self.conv3, out, relu=True, residual=x)
+        return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x)
 
 
 class ResNet50(nn.Module):
@@ -113,7 +162,7 @@ class ResNet50(nn.Module):
         self.res2, self.res3, self.res4, self.res5 = stages
 
     def forward(self, x):
-        x = F.relu_(self.stem(x))
+        x = conv_bias_act(self.stem, x, relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         x = self.res2(x)
         c3 = self.res3(x)
@@ -179,14 +228,19 @@ class ProbabilisticRetinaNetHead(nn.Module):
     def _trunk(self, convs, feature, copies: int, dropout: bool):
         """`copies` independent evaluations of a subnet, batched on dim 0.  The first conv+ReLU is
         identical across copies (dropout only follows it) and is computed once."""
-        x = F.relu(convs[0](feature))
+        x = conv_bias_act(convs[0], feature, relu=True)
         if not dropout:
             for conv in convs[1:]:
-                x = F.relu(conv(x))
+                x = conv_bias_act(conv, x, relu=True)
             return x                                  # batch 1; shared by every copy
         x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
         for conv in convs[1:]:
-            x = self._relu_dropout(conv(x))
+            if self.fused_relu_dropout and x.is_cuda:
+                self._drop_calls += 1                 # distinct Philox counter block per call
+                x = conv_bias_act(conv, x, relu=True, dropout_p=self.dropout_rate, seed=self.dropout_seed,
+                                  offset=self._drop_calls << 34)
+            else:
+                x = self._relu_dropout(conv(x))
         return x
 
     def _relu_dropout(self, x: torch.Tensor) -> torch.Tensor:

@@ -178,3 +178,66 @@ def test_bn_folding_is_the_same_affine_map():
         out = net(x)
     for a, b in zip(out, ref):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 12, 20), (2, 7, 6, 11), (1, 5, 3, 3)])     # H*W % 4 == 0 / != 0 / numel % 4 != 0
+def test_bias_act_equals_the_torch_ops_it_replaces(shape):
+    """pod_bias_act == dropout(relu((x + b[c]) + (r + rb[c])), p), every stage optional; with neither bias nor residual and the
+    same counter offset it reproduces pod_relu_dropout's mask exactly."""
+    from pod_compare_amd import hip
+    lib = hip.load()
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x, r = torch.randn(shape, device="cuda", generator=g), torch.randn(shape, device="cuda", generator=g)
+    b, rb = torch.randn(shape[1], device="cuda", generator=g), torch.randn(shape[1], device="cuda", generator=g)
+    C, HW = shape[1], shape[2] * shape[3]
+
+    def run(bias, res, res_bias, relu, p, off=0):
+        y = x.clone()
+        hip.check(lib.pod_bias_act(y.data_ptr(), hip.ptr(bias), hip.ptr(res), hip.ptr(res_bias), y.numel(), C, HW, relu, p, 99, off,
+                                   hip.current_stream()), "pod_bias_act")
+        return y
+
+    v = lambda t: t.view(1, -1, 1, 1)
+    assert torch.equal(run(b, None, None, 0, 0.0), x + v(b))
+    assert torch.equal(run(b, None, None, 1, 0.0), torch.relu(x + v(b)))
+    assert torch.equal(run(b, r, None, 1, 0.0), torch.relu((x + v(b)) + r))
+    assert torch.equal(run(b, r, rb, 1, 0.0), torch.relu((x + v(b)) + (r + v(rb))))
+    assert torch.equal(run(None, r, None, 0, 0.0), x + r)
+    p = 0.25
+    y = run(b, r, rb, 1, p, off=5 << 34)
+    full = torch.relu((x + v(b)) + (r + v(rb)))
+    kept = y != 0
+    assert bool((y[full == 0] == 0).all())
+    assert torch.allclose(y[kept], full[kept] / (1 - p), rtol=1e-6, atol=0)
+    plain = x.clone()
+    hip.check(lib.pod_relu_dropout(plain.data_ptr(), plain.numel(), p, 99, 5 << 34, hip.current_stream()), "pod_relu_dropout")
+    assert torch.equal(run(None, None, None, 1, p, off=5 << 34), plain)
+    # argument validation
+    assert lib.pod_bias_act(x.data_ptr(), None, None, hip.ptr(rb), x.numel(), C, HW, 1, 0.0, 0, 0, hip.current_stream()) == -1
+    assert lib.pod_bias_act(x.data_ptr(), None, None, None, x.numel(), C + 1, HW, 1, 0.0, 0, 0, hip.current_stream()) == -1
+
+
+def test_fused_conv_tail_leaves_the_network_output_unchanged():
+    """conv without bias + one pod_bias_act pass (bias, shortcut, ReLU) against torch's conv + add_ + add + clamp:
+    the same head outputs through the whole folded ResNet-50-FPN without dropout, up to fp32 rounding (MIOpen may pick another
+    solver for a bias-free conv, and ~60 layers of random weights amplify the last bit)."""
+    from pod_compare_amd import modeling
+    torch.manual_seed(11)
+    net = modeling.ProbabilisticRetinaNet(num_classes=7, dropout_rate=0.2, cls_var_loss="loss_attenuation", bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    for mod in net.modules():
+        if isinstance(mod, modeling.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.2, 0.2)
+            mod.running_mean.uniform_(-0.1, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    assert modeling.fold_frozen_bn(net) > 40
+    img = torch.rand(3, 200, 264, device="cuda") * 255
+    outs = []
+    with torch.no_grad():
+        for fuse in (True, False):
+            modeling.FUSE_CONV_TAIL = fuse
+            try:
+                outs.append(net(img, num_mc_dropout_runs=-1))
+            finally:
+                modeling.FUSE_CONV_TAIL = True
+    for name in ("cls", "delta", "cls_var", "reg_var"):
+        for a, b in zip(getattr(outs[0], name), getattr(outs[1], name)):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), name
