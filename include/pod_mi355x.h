@@ -249,9 +249,17 @@ int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offse
  * x (N, C, H, W) fp32, in place:  x = dropout(relu((x + bias[c]) + (residual + res_bias[c])), p).
  * torch runs the conv bias as a separate add, then clamp, then dropout (2-4 passes over the activation); the
  * conv is called without bias and this is the only pass.  bias / residual / res_bias may be NULL, relu 0/1,
- * p = 0 disables dropout; Philox counters as pod_relu_dropout.  n = N*C*H*W, HW = H*W. */
+ * p = 0 disables dropout; Philox counters as pod_relu_dropout.  n = N*C*H*W, HW = H*W.
+ * A channels-last (NHWC) activation is the same call with HW = 1 (channel = element index mod C). */
 int pod_bias_act(float* x, const float* bias, const float* residual, const float* res_bias, int64_t n, int32_t C,
                  int64_t HW, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+
+/* ---- conv-net side: broadcast + dropout -------------------------------------------------------------
+ * Replaces: feeding the SAME first-conv activation to every MC run's `nn.Dropout(p)` (PR:104-106 replicates the feature
+ * lists N times; PR:403-424).  dst[c][i] = dropout(src[i], p), c < copies, independent masks; n % 4 == 0, flat arrays
+ * (any memory format shared by src and each copy). */
+int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, float p, uint64_t seed, uint64_t offset,
+                       pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

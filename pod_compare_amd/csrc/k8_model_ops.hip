@@ -57,7 +57,9 @@ __device__ __forceinline__ float bias_act_one(float v, float b, float r, int rel
     return keep ? v * scale : 0.0f;
 }
 
-template <bool ALIGNED_PLANES>
+// LAYOUT 0: NCHW planes, H*W % 4 == 0 (4 elements share a channel); 1: NHWC, C % 4 == 0 (4 consecutive channels:
+// one 16-byte bias load); 2: anything else (per-element channel).
+template <int LAYOUT>
 __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n4; i += stride) {
@@ -70,10 +72,20 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
         float4 res = float4{0.f, 0.f, 0.f, 0.f};
         if (P.residual) res = *reinterpret_cast<const float4*>(P.residual + i * 4);
         float b[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ALIGNED_PLANES) {   // H*W % 4 == 0: the four elements share a channel
+        if (LAYOUT == 0) {
             const int c = (int)(((i * 4) / P.HW) % P.C);
             if (P.bias) b[0] = b[1] = b[2] = b[3] = P.bias[c];
             if (P.res_bias) rb[0] = rb[1] = rb[2] = rb[3] = P.res_bias[c];
+        } else if (LAYOUT == 1) {
+            const int c = (int)((i * 4) % P.C);
+            if (P.bias) {
+                const float4 t = *reinterpret_cast<const float4*>(P.bias + c);
+                b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+            }
+            if (P.res_bias) {
+                const float4 t = *reinterpret_cast<const float4*>(P.res_bias + c);
+                rb[0] = t.x; rb[1] = t.y; rb[2] = t.z; rb[3] = t.w;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -103,7 +115,46 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
     }
 }
 
+// pod_expand_dropout: dst[c][i] = dropout(src[i], p) for c < copies, an independent mask per copy.  The first conv of a
+// head subnet sees the same input in every MC run, so it is evaluated once; this writes the `copies` dropout-perturbed
+// inputs of the second conv in one pass (torch: expand + fused_dropout, which also writes a mask tensor).  Flat arrays:
+// any memory format, as long as src and every dst copy use the same one.
+__global__ void __launch_bounds__(256) k_expand_dropout(const float* __restrict__ src, float* __restrict__ dst, int64_t n4, int32_t copies,
+                                                        uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        for (int c = 0; c < copies; ++c) {
+            const uint64_t ctr = offset + (uint64_t)c * (uint64_t)n4 + (uint64_t)i;
+            const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT}, (uint32_t)seed,
+                                          (uint32_t)(seed >> 32));
+            float4 o;
+            o.x = (r.x >= thresh) ? v.x * scale : 0.0f;
+            o.y = (r.y >= thresh) ? v.y * scale : 0.0f;
+            o.z = (r.z >= thresh) ? v.z * scale : 0.0f;
+            o.w = (r.w >= thresh) ? v.w * scale : 0.0f;
+            *reinterpret_cast<float4*>(dst + ((int64_t)c * n4 + i) * 4) = o;
+        }
+    }
+}
+
 }  // namespace pod
+
+extern "C" int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, float p, uint64_t seed, uint64_t offset,
+                                  pod_stream_t stream) {
+    if (!src || !dst || n < 0 || (n & 3) != 0 || copies < 1 || !(p >= 0.0f && p < 1.0f)) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return POD_E_INVALID;
+    if (n == 0) return POD_OK;
+    const int64_t n4 = n / 4;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const float scale = 1.0f / (1.0f - p);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pod::k_expand_dropout, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n4, copies, thresh, scale,
+                       seed, offset);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
 
 extern "C" int pod_bias_act(float* x, const float* bias, const float* residual, const float* res_bias, int64_t n, int32_t C,
                             int64_t HW, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
@@ -121,8 +172,10 @@ extern "C" int pod_bias_act(float* x, const float* bias, const float* residual, 
     int64_t blocks = (P.n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride: 16 workgroups per CU
     if (blocks < 1) blocks = 1;
-    if (HW % 4 == 0) hipLaunchKernelGGL(pod::k_bias_act<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(pod::k_bias_act<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    const bool bias16 = (reinterpret_cast<uintptr_t>(bias) & 15u) == 0 && (reinterpret_cast<uintptr_t>(res_bias) & 15u) == 0;
+    if (HW % 4 == 0) hipLaunchKernelGGL(pod::k_bias_act<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else if (HW == 1 && C % 4 == 0 && bias16) hipLaunchKernelGGL(pod::k_bias_act<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k_bias_act<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

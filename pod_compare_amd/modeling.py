@@ -107,20 +107,41 @@ def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[tor
         return F.dropout(y, dropout_p, training=True) if dropout_p > 0.0 else y
     from . import hip
     lib = hip.load()
-    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    nhwc = x.dim() == 4 and x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    y = F.conv2d(x, _weight_for(conv, nhwc), None, conv.stride, conv.padding, conv.dilation, conv.groups)
     res_bias = None
     if rconv is not None:
         residual = F.conv2d(residual_input, rconv.weight, None, rconv.stride, rconv.padding, rconv.dilation, rconv.groups)
         res_bias = rconv.bias
-    if not y.is_contiguous():
-        y = y.contiguous()
-    if residual is not None:
-        assert residual.shape == y.shape
-        residual = residual.contiguous()
     C, HW = y.shape[1], y.shape[2] * y.shape[3]
+    if nhwc and residual is None and y.is_contiguous(memory_format=torch.channels_last):
+        HW = 1                                  # NHWC: channel = flat index mod C (include/pod_mi355x.h)
+    else:
+        if not y.is_contiguous():
+            y = y.contiguous()
+        if residual is not None:
+            assert residual.shape == y.shape
+            residual = residual.contiguous()
     hip.check(lib.pod_bias_act(y.data_ptr(), hip.ptr(conv.bias), hip.ptr(residual), hip.ptr(res_bias), y.numel(), C, HW,
                                1 if relu else 0, float(dropout_p), seed, offset, hip.current_stream()), "pod_bias_act")
     return y
+
+
+def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
+    """conv.weight, or a cached channels-last copy of it (refreshed when the parameter is modified or moved)."""
+    w = conv.weight
+    if not channels_last:
+        return w
+    key = (w.data_ptr(), w._version)
+    cached = getattr(conv, "_pod_w_nhwc", None)
+    if cached is None or cached[0] != key:
+        cached = (key, w.detach().contiguous(memory_format=torch.channels_last))
+        conv._pod_w_nhwc = cached
+    return cached[1]
+
+
+NCHW_PREDICTORS = True
+NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run channels-last (p3 of a 768x1344 input: 16128)
 
 
 def _conv_bn(cin, cout, k, stride=1, padding=0):
@@ -227,15 +248,31 @@ class ProbabilisticRetinaNetHead(nn.Module):
 
     def _trunk(self, convs, feature, copies: int, dropout: bool):
         """`copies` independent evaluations of a subnet, batched on dim 0.  The first conv+ReLU is
-        identical across copies (dropout only follows it) and is computed once."""
+        identical across copies (dropout only follows it) and is computed once.
+
+        On the GPU the trunk of a large map runs channels-last: MIOpen's fp32 implicit-GEMM kernel for these shapes is an
+        NHWC kernel and otherwise transposes its input and output on every call (2 x 120 us per conv on p3, 19 copies)."""
+        fused = self.fused_relu_dropout and feature.is_cuda and feature.dtype == torch.float32 and FUSE_CONV_TAIL
+        nhwc = fused and dropout and feature.shape[-2] * feature.shape[-1] >= NHWC_TRUNK_MIN_CELLS
+        if nhwc:
+            feature = feature.contiguous(memory_format=torch.channels_last)
         x = conv_bias_act(convs[0], feature, relu=True)
         if not dropout:
             for conv in convs[1:]:
                 x = conv_bias_act(conv, x, relu=True)
             return x                                  # batch 1; shared by every copy
-        x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
+        if fused and x.numel() % 4 == 0:
+            from . import hip
+            src = x if (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)) else x.contiguous()
+            x = torch.empty((copies,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device,
+                            memory_format=torch.channels_last if (nhwc and not src.is_contiguous()) else torch.contiguous_format)
+            self._drop_calls += 1
+            hip.check(hip.load().pod_expand_dropout(src.data_ptr(), x.data_ptr(), src.numel(), copies, float(self.dropout_rate),
+                                                    self.dropout_seed, self._drop_calls << 34, hip.current_stream()), "pod_expand_dropout")
+        else:
+            x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
         for conv in convs[1:]:
-            if self.fused_relu_dropout and x.is_cuda:
+            if fused:
                 self._drop_calls += 1                 # distinct Philox counter block per call
                 x = conv_bias_act(conv, x, relu=True, dropout_p=self.dropout_rate, seed=self.dropout_seed,
                                   offset=self._drop_calls << 34)
@@ -269,9 +306,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
         skip = 1 if (skip_unused_last_run and dropout and n > 1) else 0
         m = n - skip                                               # runs whose cls / cls_var / reg_var are needed
 
-        def padded(t):                                            # (m, C, H, W) -> (n, C, H, W), last slab untouched
-            if m == n:
-                return t
+        def padded(t):                                            # (m, C, H, W) -> (n, C, H, W) NCHW planes (what K1 streams),
+            if m == n:                                            # last slab untouched; a channels-last trunk output is
+                return t.contiguous()                             # transposed by the same copy
             out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             out[:m].copy_(t)
             return out
@@ -283,12 +320,16 @@ class ProbabilisticRetinaNetHead(nn.Module):
             tc = self._trunk(self.cls_subnet, f, cls_copies, dropout)
             tb = self._trunk(self.bbox_subnet, f, box_copies, dropout)
             if dropout:
-                logits.append(padded(self.cls_score(tc[:m])))
-                deltas.append(self.bbox_pred(tb[:n]))
+                if not tc.is_contiguous() and NCHW_PREDICTORS:
+                    # the A*K / A*4-channel predictor convs are faster as NCHW (Winograd) calls than as NHWC implicit GEMMs,
+                    # by more than the one transposing copy of the trunk output costs
+                    tc, tb = tc.contiguous(), tb.contiguous()
+                logits.append(padded(conv_bias_act(self.cls_score, tc[:m])))
+                deltas.append(conv_bias_act(self.bbox_pred, tb[:n]).contiguous())
                 if self.compute_cls_var:
-                    logit_vars.append(padded(self.cls_var(tc[m:])))     # independent dropout draw (Q2)
+                    logit_vars.append(padded(conv_bias_act(self.cls_var, tc[m:])))     # independent dropout draw (Q2)
                 if self.compute_bbox_cov:
-                    delta_covs.append(padded(self.bbox_cov(tb[n:])))
+                    delta_covs.append(padded(conv_bias_act(self.bbox_cov, tb[n:])))
             else:
                 ex = (lambda t: t.expand(n, -1, -1, -1).contiguous()) if n > 1 else (lambda t: t)
                 logits.append(ex(self.cls_score(tc)))

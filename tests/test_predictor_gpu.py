@@ -241,3 +241,46 @@ def test_fused_conv_tail_leaves_the_network_output_unchanged():
     for name in ("cls", "delta", "cls_var", "reg_var"):
         for a, b in zip(getattr(outs[0], name), getattr(outs[1], name)):
             assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), name
+
+
+def test_expand_dropout_statistics_and_independent_copies():
+    from pod_compare_amd import hip
+    lib = hip.load()
+    src = torch.rand(1, 64, 24, 40, device="cuda") + 0.5
+    copies, p = 7, 0.2
+    dst = torch.empty((copies,) + tuple(src.shape[1:]), device="cuda")
+    hip.check(lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), src.numel(), copies, p, 5, 3 << 34, hip.current_stream()), "expand")
+    kept = dst != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 5e-3
+    assert torch.allclose(dst[kept], src.expand_as(dst)[kept] / (1 - p), rtol=1e-6, atol=0)
+    masks = kept.reshape(copies, -1).float()
+    c = torch.corrcoef(masks)
+    assert float((c - torch.eye(copies, device="cuda")).abs().max()) < 0.02          # every copy has its own mask
+    again = torch.empty_like(dst)
+    hip.check(lib.pod_expand_dropout(src.data_ptr(), again.data_ptr(), src.numel(), copies, p, 5, 3 << 34, hip.current_stream()), "expand")
+    assert torch.equal(dst, again)
+    assert lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), 6, 1, p, 0, 0, hip.current_stream()) == -1   # n % 4 != 0
+
+
+def test_channels_last_trunk_matches_the_nchw_trunk():
+    """Large maps run the head trunk channels-last (no MIOpen layout transposes); without dropout noise the outputs must be
+    the NCHW trunk's, and the returned tensors must be NCHW planes either way."""
+    from pod_compare_amd import modeling
+    torch.manual_seed(5)
+    head = modeling.ProbabilisticRetinaNetHead(256, 9, 7, 4, 0.01, 0.2, True, True, 4).cuda().eval()
+    for mod in list(head.cls_subnet) + list(head.bbox_subnet):
+        torch.nn.init.normal_(mod.weight, std=0.03); torch.nn.init.normal_(mod.bias, std=0.1)
+    feats = [torch.randn(1, 256, 96, 100, device="cuda"), torch.randn(1, 256, 13, 17, device="cuda")]
+    head.dropout_rate = 1e-9            # dropout path taken (MC mode), masks keep everything
+    outs = []
+    with torch.no_grad():
+        for thr in (1, 10 ** 9):        # every level channels-last / none
+            modeling.NHWC_TRUNK_MIN_CELLS = thr
+            try:
+                outs.append(head(feats, 3, mc_dropout=True))
+            finally:
+                modeling.NHWC_TRUNK_MIN_CELLS = 8192
+    for a_list, b_list in zip(outs[0], outs[1]):
+        for a, b in zip(a_list, b_list):
+            assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())   # different MIOpen solvers per layout (Winograd vs implicit GEMM)
