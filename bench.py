@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--images", type=int, default=4, help="distinct planted head-tensor sets kept in HBM")
     ap.add_argument("--synth", default="planted", choices=["planted", "worst"])
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
     ap.add_argument("--k1-traffic-bytes", type=float, default=None,
@@ -119,34 +121,30 @@ def main():
                                             with_reg_var=spec["reg_var"], mode=args.synth, device=dev) for i in range(n_img)]
     params = hotpath.PathParams()
     D = 4 if spec["reg_var"] else 0
-    hp = hotpath.HotPath(heads[0].shapes, heads[0].anchors, params, n_runs=N, has_cls_var=spec["cls_var"], cov_dims=D, device=dev)
+    # one workspace per stream: images are independent units (PI:86-111), so consecutive images go to different HIP streams
+    # and the low-occupancy stretches of one image's backbone overlap the other image's head convs
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    hps = [hotpath.HotPath(heads[0].shapes, heads[0].anchors, params, n_runs=N, has_cls_var=spec["cls_var"], cov_dims=D, device=dev)
+           for _ in range(n_streams)]
+    hp = hps[0]
     R = hp.R
 
-    ev_k1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_hp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i, timed_idx=None):
-        if not args.no_cnn:
-            img = modeling.resize_test_image(frames[i % n_img])
-            # conv net: run and timed; output discarded (see docstring).  The hot path runs with the reference's merge
-            # quirk, which never reads the last run's cls / cls_var / reg_var, so the head does not compute them.
-            if len(members) > 1:
-                for mm in members:                                 # PI:498-500: one full forward per ensemble member
-                    mm(img)
-            else:
-                model(img, num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk)
-        h = heads[i % n_img]
-        if timed_idx is not None:
-            ev_hp[timed_idx][0].record()
-            ev_k1[timed_idx][0].record()
-        lv = hp.candidates(h.cls, h.delta, h.cls_var, h.reg_var, None, True)
-        if timed_idx is not None:
-            ev_k1[timed_idx][1].record()   # brackets reset + K1 + K2 + K2b launches; K1 alone is timed below
-        hp.decode(lv, None)
-        det = hp.postprocess(spec["mode"], net_hw, FRAME_HW)
-        if timed_idx is not None:
-            ev_hp[timed_idx][1].record()
-        return det
+    def step(i):
+        s = i % n_streams
+        with torch.cuda.stream(streams[s]):
+            if not args.no_cnn:
+                img = modeling.resize_test_image(frames[i % n_img])
+                # conv net: run and timed; output discarded (see docstring).  The hot path runs with the reference's merge
+                # quirk, which never reads the last run's cls / cls_var / reg_var, so the head does not compute them.
+                if len(members) > 1:
+                    for mm in members:                                 # PI:498-500: one full forward per ensemble member
+                        mm(img)
+                else:
+                    model(img, num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk)
+            h = heads[i % n_img]
+            # K1 .. K7 of the image, enqueued by one C call (pod_run_image)
+            return hps[s].run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
 
     def barrier():
         if world > 1:
@@ -160,7 +158,9 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dets = [step(i, i) for i in range(args.steps)]
+        dets = [step(i) for i in range(args.steps)]
+        for st in streams[1:]:
+            streams[0].wait_stream(st)          # the flush below reads every stream's detections
         # the path's only collective: gather the fixed-stride detection records of this flush
         if world > 1:
             import torch.distributed as dist
@@ -180,7 +180,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_det_mean = float(torch.stack([d.n_det for d in dets]).float().mean().item())
-    hp_ms = sum(a.elapsed_time(b) for a, b in ev_hp) / args.steps
+
+    # ---- the hot path alone (no conv net, one stream): HIP events around each image -----------------------
+    hp_steps = max(20, min(args.steps, 200))
+    ev_hp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(hp_steps)]
+    with torch.no_grad():
+        for i in range(5):
+            h = heads[i % n_img]
+            hp.run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
+        torch.cuda.synchronize()
+        t_hp = time.perf_counter()
+        for i in range(hp_steps):
+            h = heads[i % n_img]
+            ev_hp[i][0].record()
+            hp.run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
+            ev_hp[i][1].record()
+        torch.cuda.synchronize()
+        hp_wall_ms = 1e3 * (time.perf_counter() - t_hp) / hp_steps
+    hp_ms = sum(a.elapsed_time(b) for a, b in ev_hp) / hp_steps
 
     # ---- K1 alone, HIP events on the launch stream, rotating over the distinct input sets ------------------
     k1_iters = max(20, args.steps)
@@ -256,8 +273,9 @@ def main():
         "dtype": "f32", "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
         "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
                    "classes": params.num_classes, "synthetic_mode": args.synth, "conv_net_in_timed_region": not args.no_cnn,
-                   "images_per_gpu_step": 1, "parallelism": "image-sharded dp%d" % world, "rng": "in-kernel Philox4x32-10"},
-        "hot_path_ms_per_image": hp_ms, "mean_detections": n_det_mean,
+                   "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
+                   "rng": "in-kernel Philox4x32-10"},
+        "hot_path_ms_per_image": hp_ms, "hot_path_wall_ms_per_image": hp_wall_ms, "mean_detections": n_det_mean,
         "roofline": {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None, "algorithmic_bytes": k1_bytes,
                      "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
@@ -296,7 +314,7 @@ def main():
                                "host_cpus": cores,
                                "sample": "%d images, post-processing only (head tensors given; conv net excluded), torch CPU "
                                          "oracle/pod_oracle.py, same planted tensors" % n_cpu,
-                               "gpu_hot_path_images_per_s": 1e3 / hp_ms}
+                               "gpu_hot_path_images_per_s": 1e3 / hp_wall_ms}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

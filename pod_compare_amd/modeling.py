@@ -136,6 +136,8 @@ def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
     cached = getattr(conv, "_pod_w_nhwc", None)
     if cached is None or cached[0] != key:
         cached = (key, w.detach().contiguous(memory_format=torch.channels_last))
+        if w.is_cuda:
+            torch.cuda.current_stream(w.device).synchronize()   # made once, then read from any stream
         conv._pod_w_nhwc = cached
     return cached[1]
 
@@ -384,6 +386,8 @@ class ProbabilisticRetinaNet(nn.Module):
         if padded_hw not in self._anchor_cache:
             shapes = _anchors.level_shapes(*padded_hw)
             self._anchor_cache[padded_hw] = _anchors.grid_anchors(shapes, device=self.device)
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()   # made once, then read from any stream
         return self._anchor_cache[padded_hw]
 
     @torch.no_grad()

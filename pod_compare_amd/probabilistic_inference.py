@@ -129,7 +129,10 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
     # -- helpers -----------------------------------------------------------------------------------
     def _path_for(self, ho: HeadOutputs) -> hotpath.HotPath:
         cov_dims = 0 if ho.reg_var is None else ho.reg_var[0].shape[1] // ho.num_anchors
-        key = (tuple(ho.shapes), ho.num_runs, ho.cls_var is not None, cov_dims, str(ho.cls[0].device))
+        dev = ho.cls[0].device
+        # one workspace per (geometry, stream): a driver may keep several images in flight on different HIP streams
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (tuple(ho.shapes), ho.num_runs, ho.cls_var is not None, cov_dims, str(dev), stream)
         if key not in self._paths:
             m = self.model
             params = hotpath.PathParams(

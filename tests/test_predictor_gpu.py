@@ -284,3 +284,31 @@ def test_channels_last_trunk_matches_the_nchw_trunk():
         for a, b in zip(a_list, b_list):
             assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
             assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())   # different MIOpen solvers per layout (Winograd vs implicit GEMM)
+
+
+def test_images_in_flight_on_several_streams_give_the_single_stream_results():
+    """The image-sharded driver keeps consecutive images on different HIP streams; the predictor holds one workspace per
+    stream.  Same head tensors, same Philox seeds: records must be bit-identical to the one-stream run."""
+    g = Golden(os.path.join(GOLDEN, "cfg3_bayes_od_mc10_s31.npz"))
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml")
+    n = g.spec["runs"]
+    cfg.PROBABILISTIC_INFERENCE.MC_DROPOUT.NUM_RUNS = n
+    ho = g.head_outputs().to("cuda")
+    pred = pinf.build_predictor(cfg, model=FakeModel(ho, list(range(n))))
+    pred.return_device = True                                   # native Philox draws (no eps_fn): the production mode
+    h, w = g.meta["image"]
+    input_im = [{"image": torch.zeros((3, h, w), device="cuda"), "height": g.meta["out"][0], "width": g.meta["out"][1], "image_id": 1}]
+    torch.cuda.synchronize()
+    ref = pred(input_im)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    dets = []
+    for j in range(9):
+        with torch.cuda.stream(streams[j % 3]):
+            dets.append(pred(input_im))
+    torch.cuda.synchronize()
+    assert len({d.buf.data_ptr() for d in dets}) == 9 and len(pred._paths) == 4        # default stream + 3
+    m = ref.count()
+    assert m > 0
+    for d in dets:
+        assert d.count() == m and torch.equal(d.records[:m], ref.records[:m])
