@@ -62,10 +62,15 @@ __device__ __forceinline__ float4 ld4(const float* p, int64_t i, int64_t n) {
     v.w = (i + 3 < n) ? p[i + 3] : 0.0f;
     return v;
 }
-template <bool VEC>
+template <bool VEC, bool NT = false>
 __device__ __forceinline__ void st4(float* p, int64_t i, int64_t n, float4 v) {
     if (VEC) {
-        *reinterpret_cast<float4*>(p + i) = v;
+        if (NT) {   // written once, re-read only sparsely (K1b): keep it out of the way of the streaming loads
+            const f32x4_t w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, reinterpret_cast<f32x4_t*>(p + i));
+        } else {
+            *reinterpret_cast<float4*>(p + i) = v;
+        }
         return;
     }
     if (i + 0 < n) p[i + 0] = v.x;
@@ -247,6 +252,15 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
 // K1b samples those.  With no max-over-classes left there is no LDS, no barrier and no class-per-wave shape: every
 // tensor is walked as a flat array, 256 threads x 16 B = 4 KiB contiguous per run per workgroup (the access
 // pattern of a plain streaming merge), logit and log-variance planes side by side.
+// OR over the 16 lanes of a DPP row (row_ror:8,4,2,1): every lane ends up with the row's OR, no LDS crossbar
+__device__ __forceinline__ uint32_t row_or16(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+    return v;
+}
+
 template <bool VEC, int BATCH>
 __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv, int l, int local_b, int HW) {
     const int K = P.K;
@@ -258,27 +272,26 @@ __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv,
     merge_runs4<VEC, 2, BATCH>(m, base, lv.run_stride_cls, i, n, P.n_runs, P.quirk);
     if (P.n_runs > 1) {
         const int64_t off = (int64_t)lv.anchor_base * K;
-        st4<VEC>(P.mean_cls + off, i, n, m[0]);
-        st4<VEC>(P.mean_cls_var + off, i, n, m[1]);
+        st4<VEC, true>(P.mean_cls + off, i, n, m[0]);
+        st4<VEC, true>(P.mean_cls_var + off, i, n, m[1]);
     }
     const float lg[4] = {m[0].x, m[0].y, m[0].z, m[0].w};
     const float vr[4] = {m[1].x, m[1].y, m[1].z, m[1].w};
     uint64_t* bits = P.maybe_bits + P.word_begin[l];
     if (VEC) {   // H*W % 4 == 0: the four elements are consecutive cells of one plane
-        const int plane = (int)(i / HW);
-        const int hw = (int)(i - (int64_t)plane * HW);
+        const uint32_t plane = (uint32_t)i / (uint32_t)HW;          // n < 2^31 (checked on the host)
+        const int hw = (int)((uint32_t)i - plane * (uint32_t)HW);
         unsigned nib = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit) nib |= 1u << j;
-        unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + (plane / K) * P.wpa[l] + (hw >> 6));
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + (plane / (uint32_t)K) * P.wpa[l] + (hw >> 6));
         if ((HW & 63) == 0) {
-            // planes are whole bitmap words and a wavefront starts on a 256-element boundary: 16 consecutive lanes
-            // own exactly one word -> OR-reduce their nibbles in registers, one atomic per non-zero word
-            unsigned long long w = (unsigned long long)nib << (hw & 63);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-            if ((threadIdx.x & 15) == 0 && w != 0ull) atomicOr(word, w);
+            // planes are whole bitmap words and a wavefront starts on a 256-element boundary: the 16 lanes of a DPP row
+            // own exactly one word -> OR-reduce their nibbles with row rotations (VALU only), one atomic per non-zero word
+            const unsigned long long w = (unsigned long long)nib << (hw & 63);
+            const uint32_t lo = row_or16((uint32_t)w), hi = row_or16((uint32_t)(w >> 32));
+            if ((threadIdx.x & 15) == 0 && (lo | hi) != 0u) atomicOr(word, ((unsigned long long)hi << 32) | lo);
         } else if (nib) {
             atomicOr(word, (unsigned long long)nib << (hw & 63));
         }
@@ -434,6 +447,7 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
         if (D > 0 && !lv.reg_var) return POD_E_INVALID;
         P.lv[l] = lv;
         const int64_t HW = (int64_t)lv.H * lv.W;
+        if ((int64_t)A * (K > 4 + D ? K : 4 + D) * HW >= (int64_t)1 << 31) return POD_E_INVALID;   // 32-bit plane arithmetic
         P.chunks[l] = (int32_t)((HW + 255) / 256);
         const bool hw4 = (HW % 4) == 0;
         P.vec_cls[l] = hw4 && aligned16(lv.cls) && (lv.run_stride_cls % 4 == 0) && (!cfg->has_cls_var || aligned16(lv.cls_var)) &&
