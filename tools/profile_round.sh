@@ -10,6 +10,9 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hotpath -o hp -- python bench.py --no-cnn --steps 40 --no-cpu-baseline > $OUT/bench_hotpath.json 2> $OUT/bench_hotpath.err
 # (2) the headline command (conv net in the timed region)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -o full -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_full.json 2> $OUT/bench_full.err
+# (2b) the same with one stream: per-kernel durations are only meaningful when kernels of different images do not overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full1 -o full1 -- python bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > $OUT/bench_full_streams1.json 2> $OUT/bench_full_streams1.err
+python tools/steady_state.py $OUT/full1/full1_kernel_trace.csv 8 6 > $OUT/steady_state.txt 2>&1
 # (3) HBM traffic of K1: separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python tools/k1_only.py 12 > /dev/null 2>&1

@@ -21,9 +21,9 @@ for name, title in (("hotpath/hp", "`rocprofv3 --kernel-trace --stats -- python 
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
     if any("naive_conv" in r["Name"] for r in rows[:22]):
-        lines += ["", "(`naive_conv_*` and most of the first rows are MIOpen's find pass on the first image -- every solver is tried once per",
-                  "conv shape, including the naive reference kernel -- not the steady state: the timed steps take ms_per_step in the bench",
-                  "line below, see `tools/cnn_profile.py` / DESIGN.md for the steady-state conv breakdown.)"]
+        lines += ["", "(`naive_conv_*` and most of the first rows are MIOpen's find pass on the first images -- every solver is tried once per",
+                  "conv shape and stream, including the naive reference kernel -- not the steady state; with 3 streams the durations of",
+                  "overlapping kernels also stretch.  The steady-state table below is the per-kernel breakdown.)"]
     lines.append("")
     out = os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name.split("/")[0]))
     with open(out, "w") as fo:
@@ -31,7 +31,11 @@ for name, title in (("hotpath/hp", "`rocprofv3 --kernel-trace --stats -- python 
         w.writerow(rows[0].keys())
         for r in rows[:40]:
             w.writerow([short(v) if k == "Name" else v for k, v in r.items()])
-for j in ("bench_hotpath.json", "bench_full.json"):
+ss = os.path.join(src, "steady_state.txt")
+if os.path.exists(ss):
+    lines += ["## steady state per image, one stream (`bench.py --steps 10 --warmup 3 --streams 1`, `tools/steady_state.py`)", ""]
+    lines += [l.rstrip() for l in open(ss) if "amdgpu" not in l] + [""]
+for j in ("bench_hotpath.json", "bench_full.json", "bench_full_streams1.json"):
     p = os.path.join(src, j)
     if os.path.exists(p):
         txt = [l for l in open(p) if l.startswith("{")]
