@@ -254,6 +254,12 @@ int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offse
 int pod_bias_act(float* x, const float* bias, const float* residual, const float* res_bias, int64_t n, int32_t C,
                  int64_t HW, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
 
+/* Same tail for a channels-last (N, H*W, C) conv output, written as NCHW planes: dst = dropout(relu(src + bias[c]), p)
+ * transposed through LDS tiles, so leaving the channels-last trunk costs no extra pass.  C % 4 == 0, HW % 4 == 0,
+ * src != dst; dropout counters are those of pod_bias_act on the NCHW result. */
+int pod_bias_act_to_nchw(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
+                         float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+
 /* ---- conv-net side: broadcast + dropout -------------------------------------------------------------
  * Replaces: feeding the SAME first-conv activation to every MC run's `nn.Dropout(p)` (PR:104-106 replicates the feature
  * lists N times; PR:403-424).  dst[c][i] = dropout(src[i], p), c < copies, independent masks; n % 4 == 0, flat arrays

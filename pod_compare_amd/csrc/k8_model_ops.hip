@@ -138,7 +138,76 @@ __global__ void __launch_bounds__(256) k_expand_dropout(const float* __restrict_
     }
 }
 
+// pod_bias_act_to_nchw: the same tail as pod_bias_act for a channels-last conv output, written as NCHW planes -- the
+// layout change rides on the element-wise pass that exists anyway (a separate transposing copy of the 300 MB p3 trunk
+// output costs 0.3 ms in torch).  Workgroup = one 64 (cells) x 64 (channels) tile through LDS: 16-byte loads along C,
+// 16-byte stores along H*W.  Dropout counters are those of pod_bias_act on the NCHW result (counter = offset + NCHW
+// float4 index), so the output equals "transpose, then pod_bias_act" bit for bit.
+__global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ bias,
+                                                          int32_t C, int64_t HW, int32_t relu, uint32_t thresh, float scale, uint64_t seed,
+                                                          uint64_t offset, int32_t tiles_hw, int32_t tiles_c) {
+    __shared__ float tile[64][65];   // [cell][channel], padded
+    const int tid = threadIdx.x;
+    int64_t t = blockIdx.x;
+    const int tc = (int)(t % tiles_c);
+    t /= tiles_c;
+    const int th = (int)(t % tiles_hw);
+    const int64_t n = t / tiles_hw;
+    const int64_t hw0 = (int64_t)th * 64;
+    const int c0 = tc * 64;
+    // load: thread -> (cell row = tid / 16 + 16 * it, 4 channels at (tid % 16) * 4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4;
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (hw0 + r < HW && c0 + c4 < C) {
+            v = *reinterpret_cast<const float4*>(src + ((n * HW + hw0 + r) * C + c0 + c4));
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + c0 + c4);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+        }
+        tile[r][c4 + 0] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    // store: thread -> (channel row = tid / 16 + 16 * it, 4 cells at (tid % 16) * 4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (tid >> 4) + 16 * it, h4 = (tid & 15) * 4;
+        if (c0 + c >= C || hw0 + h4 >= HW) continue;
+        const int64_t e = (n * C + c0 + c) * HW + hw0 + h4;   // NCHW element index, a multiple of 4
+        u32x4 r = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (thresh) {
+            const uint64_t ctr = offset + (uint64_t)(e >> 2);
+            r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT}, (uint32_t)seed, (uint32_t)(seed >> 32));
+        }
+        float4 v = float4{tile[h4 + 0][c], tile[h4 + 1][c], tile[h4 + 2][c], tile[h4 + 3][c]};
+        v.x = bias_act_one(v.x, 0.0f, 0.0f, relu, r.x >= thresh, scale);
+        v.y = bias_act_one(v.y, 0.0f, 0.0f, relu, r.y >= thresh, scale);
+        v.z = bias_act_one(v.z, 0.0f, 0.0f, relu, r.z >= thresh, scale);
+        v.w = bias_act_one(v.w, 0.0f, 0.0f, relu, r.w >= thresh, scale);
+        *reinterpret_cast<float4*>(dst + e) = v;
+    }
+}
+
 }  // namespace pod
+
+extern "C" int pod_bias_act_to_nchw(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
+                                    float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
+    if (!src || !dst || src == dst || N < 0 || C < 4 || (C & 3) != 0 || HW < 4 || (HW & 3) != 0 || !(p >= 0.0f && p < 1.0f)) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0 ||
+        (reinterpret_cast<uintptr_t>(bias) & 15u) != 0)
+        return POD_E_INVALID;
+    if (N == 0) return POD_OK;
+    const int64_t tiles_hw = (HW + 63) / 64, tiles_c = (C + 63) / 64;
+    const int64_t blocks = N * tiles_hw * tiles_c;
+    if (blocks > 0x7FFFFFFFLL || tiles_hw > 0x7FFFFFFFLL) return POD_E_INVALID;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(pod::k_bias_act_to_nchw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, bias, C, HW, relu, thresh,
+                       1.0f / (1.0f - p), seed, offset, (int32_t)tiles_hw, (int32_t)tiles_c);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
 
 extern "C" int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, float p, uint64_t seed, uint64_t offset,
                                   pod_stream_t stream) {

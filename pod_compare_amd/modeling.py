@@ -85,7 +85,8 @@ FUSE_CONV_TAIL = True     # GPU only: conv without bias + ONE pod_bias_act pass 
 
 
 def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None, residual_module=None,
-                  residual_input: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: int = 0, offset: int = 0) -> torch.Tensor:
+                  residual_input: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
+                  out_nchw: bool = False) -> torch.Tensor:
     """act(m(x) [+ residual]) with the element-wise tail in one HIP pass.
 
     torch's conv on ROCm is MIOpen's kernel plus a separate bias `add_`; followed by clamp (and the bottleneck's add, and
@@ -115,6 +116,12 @@ def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[tor
         res_bias = rconv.bias
     C, HW = y.shape[1], y.shape[2] * y.shape[3]
     if nhwc and residual is None and y.is_contiguous(memory_format=torch.channels_last):
+        if out_nchw and C % 4 == 0 and HW % 4 == 0:
+            # leave the channels-last trunk on the element-wise pass that exists anyway: NHWC in, NCHW planes out
+            out = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+            hip.check(lib.pod_bias_act_to_nchw(y.data_ptr(), out.data_ptr(), hip.ptr(conv.bias), y.shape[0], C, HW, 1 if relu else 0,
+                                               float(dropout_p), seed, offset, hip.current_stream()), "pod_bias_act_to_nchw")
+            return out
         HW = 1                                  # NHWC: channel = flat index mod C (include/pod_mi355x.h)
     else:
         if not y.is_contiguous():
@@ -142,7 +149,6 @@ def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
     return cached[1]
 
 
-NCHW_PREDICTORS = True
 NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run channels-last (p3 of a 768x1344 input: 16128)
 
 
@@ -277,7 +283,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
             if fused:
                 self._drop_calls += 1                 # distinct Philox counter block per call
                 x = conv_bias_act(conv, x, relu=True, dropout_p=self.dropout_rate, seed=self.dropout_seed,
-                                  offset=self._drop_calls << 34)
+                                  offset=self._drop_calls << 34, out_nchw=conv is convs[-1])
             else:
                 x = self._relu_dropout(conv(x))
         return x
@@ -322,10 +328,8 @@ class ProbabilisticRetinaNetHead(nn.Module):
             tc = self._trunk(self.cls_subnet, f, cls_copies, dropout)
             tb = self._trunk(self.bbox_subnet, f, box_copies, dropout)
             if dropout:
-                if not tc.is_contiguous() and NCHW_PREDICTORS:
-                    # the A*K / A*4-channel predictor convs are faster as NCHW (Winograd) calls than as NHWC implicit GEMMs,
-                    # by more than the one transposing copy of the trunk output costs
-                    tc, tb = tc.contiguous(), tb.contiguous()
+                # (a channels-last trunk hands its last activation over as NCHW planes: the A*K / A*4-channel predictor convs
+                #  are faster as NCHW Winograd calls than as NHWC implicit GEMMs)
                 logits.append(padded(conv_bias_act(self.cls_score, tc[:m])))
                 deltas.append(conv_bias_act(self.bbox_pred, tb[:n]).contiguous())
                 if self.compute_cls_var:

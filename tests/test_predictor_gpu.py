@@ -312,3 +312,22 @@ def test_images_in_flight_on_several_streams_give_the_single_stream_results():
     assert m > 0
     for d in dets:
         assert d.count() == m and torch.equal(d.records[:m], ref.records[:m])
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 12, 20), (2, 256, 7, 12), (1, 8, 2, 2), (2, 68, 9, 28)])     # full / partial tiles
+def test_bias_act_to_nchw_is_transpose_then_bias_act(shape):
+    from pod_compare_amd import hip
+    lib = hip.load()
+    N, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(N * C + H)
+    x = torch.randn(shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, device="cuda", generator=g)
+    for relu, p in ((1, 0.0), (0, 0.0), (1, 0.3)):
+        out = torch.full(shape, float("nan"), device="cuda")
+        hip.check(lib.pod_bias_act_to_nchw(x.data_ptr(), out.data_ptr(), b.data_ptr(), N, C, H * W, relu, p, 7, 2 << 34,
+                                           hip.current_stream()), "to_nchw")
+        ref = x.contiguous().clone()      # NCHW copy, then the in-place NCHW pass with the same counters
+        hip.check(lib.pod_bias_act(ref.data_ptr(), b.data_ptr(), None, None, ref.numel(), C, H * W, relu, p, 7, 2 << 34,
+                                   hip.current_stream()), "bias_act")
+        assert out.is_contiguous() and torch.equal(out, ref), (relu, p)
+    assert lib.pod_bias_act_to_nchw(x.data_ptr(), x.data_ptr(), None, N, C, H * W, 1, 0.0, 0, 0, hip.current_stream()) == -1
