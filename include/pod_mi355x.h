@@ -165,6 +165,15 @@ int pod_decode_cov(const PodConfig* cfg, const PodLevel* levels, const int32_t* 
                    const float* eps_prop, int32_t n_replay,
                    float* boxes, float* cov, pod_stream_t stream);
 
+/* ---- K2b + K3 in one launch (in-kernel draws only) ------------------------------------------------
+ * pod_gather_candidates followed by pod_decode_cov, same arguments, same outputs (the candidate arrays are still written
+ * for the later kernels), bit-identical results: the wavefront that gathered a candidate decodes it, handing the merged
+ * deltas / log-variances over in registers and the per-run deltas in LDS.  n_capacity = n_levels * topk. */
+int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float* anchors, const uint64_t* sel_keys,
+                      const int32_t* sel_count, int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score,
+                      int32_t* cand_class, float* cand_probs, float* cand_delta, float* cand_reg_var, float* cand_anchor,
+                      float* cand_run_delta, int32_t* n_total, float* boxes, float* cov, pod_stream_t stream);
+
 /* ---- K4  nms_cluster -----------------------------------------------------------------------
  * Replaces: detectron2 batched_nms -> torchvision coordinate-trick NMS (call sites PI:554-560,
  * IU:31-36, IU:83-89): boxes + class*(max_coord+1), stable descending-score order, suppress
@@ -288,7 +297,7 @@ int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t 
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
  * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence
- *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_candidates -> pod_decode_cov
+ *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_decode (= pod_gather_candidates + pod_decode_cov)
  *   -> pod_nms_cluster -> {pod_bayes_fuse | pod_anchor_stats_merge | -} -> pod_finalize
  * enqueued from C on `stream`, in-kernel Philox draws (levels[].eps_cls must be NULL: the eps-replay parity
  * mode needs the host between launches and uses the individual entry points).  Nothing here

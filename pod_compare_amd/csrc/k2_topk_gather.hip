@@ -11,7 +11,7 @@
 // K2b: one thread per selected candidate re-derives the class probabilities with K1's own device
 // function (bit-identical), and gathers merged deltas / log-variances, the anchor and every run's
 // raw delta into the level-concatenated candidate arrays.
-#include "pod_device.h"
+#include "pod_candidate.h"
 
 namespace pod {
 
@@ -150,121 +150,9 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     if (tid == 0) P.sel_count[l] = k;
 }
 
-struct K2bParams {
-    PodLevel lv[POD_MAX_LEVELS];
-    int32_t n_levels, n_runs, A, K, D, has_cls_var, quirk, cls_samples, topk;
-    uint64_t seed;
-    const float* anchors;
-    const uint64_t* sel_keys;
-    const int32_t* sel_count;
-    int32_t* cand_anchor_idx;
-    int32_t* cand_level;
-    float* cand_score;
-    int32_t* cand_class;
-    float* cand_probs;
-    float* cand_delta;
-    float* cand_reg_var;
-    float* cand_anchor;
-    float* cand_run_delta;
-    int32_t* n_total;
-};
-
-// Merged value of one element (plane-layout offset `e` inside a run) in the reference order; all N
-// loads of a batch are issued before the first add.  Optionally hands every run's raw value to `sink`.
-template <class Sink>
-__device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int64_t e, int n_runs, int quirk, Sink sink) {
-    float acc = 0.0f;
-    float x0 = 0.0f;
-    for (int r0 = 0; r0 < n_runs; r0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (r0 + j < n_runs) v[j] = base[(int64_t)(r0 + j) * rs + e];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int run = r0 + j;
-            if (run < n_runs) {
-                sink(run, v[j]);
-                if (run == 0) {
-                    x0 = v[j];
-                    acc = (quirk && n_runs > 1) ? x0 + x0 : x0;   // term 0 (+ term 1 = run 0 again, PI:216-219)
-                } else if (!quirk || run < n_runs - 1) {
-                    acc = acc + v[j];                             // quirk: the last run is never added
-                }
-            }
-        }
-    }
-    return n_runs == 1 ? acc : __fdiv_rn(acc, (float)n_runs);
-}
-
-// One wavefront per selected candidate.  Lane c < C = 2K+4+D owns channel c of the anchor
-// ([0,K) logits, [K,2K) log-variances, then 4 deltas, then D reg_var entries): it loads that
-// channel of all N runs (independent loads), merges them in the reference order, and the K logit
-// lanes then re-derive the class probabilities with K1's device function (bit-identical).
 __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
-    const int slot = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int L = P.n_levels;
-    const int l = slot / P.topk;
-    const int j = slot - l * P.topk;
-    if (slot == 0 && lane == 0) {
-        int total = 0;
-        for (int i = 0; i < L; ++i) total += P.sel_count[i];
-        *P.n_total = total;
-    }
-    if (l >= L || j >= P.sel_count[l]) return;
-    int dst = j;
-    for (int i = 0; i < l; ++i) dst += P.sel_count[i];
-    const PodLevel& lv = P.lv[l];
-    const uint64_t key = P.sel_keys[(int64_t)l * P.topk + j];
-    const int r = key_index(key);
-    const int A = P.A, K = P.K, D = P.D, N = P.n_runs;
-    const int hw = r / A;
-    const int a = r - hw * A;
-    const int64_t HW = (int64_t)lv.H * lv.W;
-    const bool has_var = P.has_cls_var != 0;
-    const int nvar = has_var ? K : 0;
-    const int C = K + nvar + 4 + D;
-    float merged = 0.0f;
-    if (lane < K) {
-        merged = merge_scalar(lv.cls, lv.run_stride_cls, (int64_t)(a * K + lane) * HW + hw, N, P.quirk, [](int, float) {});
-    } else if (lane < K + nvar) {
-        merged = merge_scalar(lv.cls_var, lv.run_stride_cls, (int64_t)(a * K + lane - K) * HW + hw, N, P.quirk, [](int, float) {});
-    } else if (lane < K + nvar + 4) {
-        const int c = lane - K - nvar;
-        float* rd = P.cand_run_delta;
-        merged = merge_scalar(lv.delta, lv.run_stride_delta, (int64_t)(a * 4 + c) * HW + hw, N, P.quirk,
-                              [=](int run, float v) { if (rd) rd[((int64_t)dst * N + run) * 4 + c] = v; });
-        P.cand_delta[(int64_t)dst * 4 + c] = merged;
-    } else if (lane < C) {
-        const int c = lane - K - nvar - 4;
-        merged = merge_scalar(lv.reg_var, lv.run_stride_reg, (int64_t)(a * D + c) * HW + hw, N, P.quirk, [](int, float) {});
-        P.cand_reg_var[(int64_t)dst * D + c] = merged;
-    }
-    const float lvar = has_var ? __shfl(merged, (lane < K ? lane : 0) + K, 64) : 0.0f;
-    float p = -1.0f;
-    if (lane < K) {
-        p = class_prob_cell(merged, lvar, has_var, P.cls_samples, lv.eps_cls, HW * A, K, A, l, hw, a, lane, P.seed);
-        P.cand_probs[(int64_t)dst * K + lane] = p;
-    }
-    // max / first argmax over the K class lanes
-    float best = __shfl(p, 0, 64);
-    int best_k = 0;
-    for (int k = 1; k < K; ++k) {
-        const float v = __shfl(p, k, 64);
-        if (v > best) {
-            best = v;
-            best_k = k;
-        }
-    }
-    if (lane == 0) {
-        P.cand_score[dst] = best;            // == key_score(key) by construction
-        P.cand_class[dst] = best_k;
-        P.cand_anchor_idx[dst] = r;
-        P.cand_level[dst] = l;
-        const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
-        *reinterpret_cast<float4*>(P.cand_anchor + (int64_t)dst * 4) = anc;
-    }
+    GatheredCandidate g;
+    gather_candidate(P, blockIdx.x, threadIdx.x, nullptr, g);
 }
 
 }  // namespace pod

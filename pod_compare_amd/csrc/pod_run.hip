@@ -39,13 +39,10 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     if (prune)
         POD_TRY(pod_score_maybe(cfg, levels, ws->mean_cls, ws->mean_cls_var, ws->maybe_bits, ws->cand_keys, ws->cand_count, stream));
     POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, stream));
-    POD_TRY(pod_gather_candidates(cfg, levels, ws->anchors, ws->sel_keys, ws->sel_count, ws->cand_anchor_idx, ws->cand_level,
-                                  ws->cand_score, ws->cand_class, ws->cand_probs, ws->cand_delta,
-                                  cfg->cov_dims > 0 ? ws->cand_reg_var : nullptr, ws->cand_anchor, ws->cand_run_delta,
-                                  ws->n_total, stream));
-    POD_TRY(pod_decode_cov(cfg, levels, ws->n_total, ws->n_capacity, ws->cand_delta, cfg->cov_dims > 0 ? ws->cand_reg_var : nullptr,
-                           ws->cand_anchor, ws->cand_run_delta, ws->cand_anchor_idx, ws->cand_level, nullptr, 0, ws->boxes,
-                           ws->cov, stream));
+    POD_TRY(pod_gather_decode(cfg, levels, ws->anchors, ws->sel_keys, ws->sel_count, ws->cand_anchor_idx, ws->cand_level,
+                              ws->cand_score, ws->cand_class, ws->cand_probs, ws->cand_delta,
+                              cfg->cov_dims > 0 ? ws->cand_reg_var : nullptr, ws->cand_anchor, ws->cand_run_delta, ws->n_total,
+                              ws->boxes, ws->cov, stream));
     POD_TRY(pod_nms_cluster(cfg, ws->n_total, ws->n_capacity, ws->boxes, ws->cand_score, ws->cand_class, ws->keep, ws->n_keep,
                             ws->nms_scratch, stream));
     const float* cov_in = has_cov ? ws->cov : nullptr;

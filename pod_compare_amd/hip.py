@@ -24,7 +24,7 @@ POD_MAX_CLS_SAMPLES = 64
 POD_MAX_CANDIDATES = 8192
 POD_MAX_DETECTIONS = 128
 
-EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates",
+EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates", "pod_gather_decode",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image")
@@ -94,6 +94,7 @@ def load() -> ctypes.CDLL:
     lib.pod_score_maybe.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P]
     lib.pod_level_topk.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P]
     lib.pod_gather_candidates.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 14
+    lib.pod_gather_decode.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 17
     lib.pod_decode_cov.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, c_int32, P, P, P, P, P, P, P, c_int32, P, P, P]
     lib.pod_nms_cluster.argtypes = [POINTER(PodConfig), P, c_int32, P, P, P, P, P, P, P]
     lib.pod_bayes_fuse.argtypes = [POINTER(PodConfig), P, P, P, P, P, P, P, P, c_int32, c_int32, P, P, P, P, P, P]
