@@ -28,10 +28,12 @@ def shard_indices(num_images: int, rank: int, world: int) -> List[int]:
 
 
 def gather_records(local_ids: Sequence[int], local_counts: torch.Tensor, local_records: torch.Tensor, num_images: int,
-                   world: int) -> Tuple[List[int], torch.Tensor, torch.Tensor]:
+                   world: int, per_rank: Optional[int] = None) -> Tuple[List[int], torch.Tensor, torch.Tensor]:
     """One flush: every rank contributes (n_local, max_det, width) records + (n_local,) counts, padded to the
-    common per-rank maximum so a single all_gather moves them.  Returns (image ids, counts, records) in image order."""
-    per_rank = -(-num_images // world)
+    common per-rank maximum (`per_rank`, default ceil(num_images / world)) so a single all_gather moves them.
+    Returns (image ids, counts, records) in image order."""
+    if per_rank is None:
+        per_rank = -(-num_images // world)
     n_local = len(local_ids)
     dev = local_records.device
     ids = torch.full((per_rank,), -1, dtype=torch.int64, device=dev)
@@ -123,6 +125,8 @@ def main(argv=None):
     ap.add_argument("--output", default="coco_instances_results.json")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU; consecutive images of a rank go to different streams (batch 1 per stream, AN:35)")
+    ap.add_argument("--flush-every", type=int, default=64,
+                    help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="BASELINE config 5: rank s < M runs ensemble member s, dense pre-NMS tensors meet on a rotating merge rank")
     args = ap.parse_args(argv)
@@ -147,23 +151,53 @@ def main(argv=None):
     # images are independent units: keep a few in flight on separate HIP streams so one image's low-occupancy backbone
     # stretches overlap another image's head convs (+12 % images/s on one MI355X); the predictor keeps a workspace per stream
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(1, args.streams) - 1)]
-    with torch.no_grad():
-        for j, i in enumerate(mine if predictor is not None else []):
-            with torch.cuda.stream(streams[j % len(streams)]):
-                frame = synthetic.synthetic_frame(i, device=cfg.MODEL.DEVICE)
-                image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
-                input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
-                det = predictor(input_im)
-                recs.append(det.records)
-                cnts.append(det.n_det)
-            if os.environ.get("POD_SYNC_EACH_IMAGE") == "1":    # debugging aid: serialise the streams
-                torch.cuda.synchronize()
-    for st in streams[1:]:
-        streams[0].wait_stream(st)          # the gather below reads every stream's records
     width = record_width(K)
-    rec = torch.stack(recs) if recs else torch.zeros((0, 128, width), device=cfg.MODEL.DEVICE)
-    cnt = torch.stack(cnts) if cnts else torch.zeros((0,), dtype=torch.int32, device=cfg.MODEL.DEVICE)
-    ids, cnt, rec = gather_records(mine, cnt, rec, args.num_images, world)
+    dev = cfg.MODEL.DEVICE
+    F = max(1, args.flush_every)
+    n_mine = len(shard_indices(args.num_images, 0, world))          # rank 0 owns the most images: every rank flushes as often
+    all_ids: List[int] = []
+    all_cnt, all_rec = [], []
+
+    def flush(chunk_ids, recs, cnts):
+        """ONE collective: this chunk's records of every rank, image order restored (device memory stays bounded)."""
+        for st in streams[1:]:
+            streams[0].wait_stream(st)          # the gather reads every stream's records
+        rec = torch.stack(recs) if recs else torch.zeros((0, 128, width), device=dev)
+        cnt = torch.stack(cnts) if cnts else torch.zeros((0,), dtype=torch.int32, device=dev)
+        ids, cnt, rec = gather_records(chunk_ids, cnt, rec, args.num_images, world, per_rank=F)
+        all_ids.extend(ids)
+        all_cnt.append(cnt.cpu())
+        all_rec.append(rec.cpu())
+
+    if args.ensemble_per_gpu:
+        flush_ids = list(mine)
+        for a in range(0, max(n_mine, 1), F):
+            flush(flush_ids[a:a + F], recs[a:a + F], cnts[a:a + F])
+    else:
+        chunk_ids: List[int] = []
+        recs, cnts = [], []
+        with torch.no_grad():
+            for j in range(n_mine):
+                if j < len(mine):
+                    i = mine[j]
+                    with torch.cuda.stream(streams[j % len(streams)]):
+                        frame = synthetic.synthetic_frame(i, device=dev)
+                        image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+                        input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
+                        det = predictor(input_im)
+                        chunk_ids.append(i)
+                        recs.append(det.records)
+                        cnts.append(det.n_det)
+                    if os.environ.get("POD_SYNC_EACH_IMAGE") == "1":    # debugging aid: serialise the streams
+                        torch.cuda.synchronize()
+                if (j + 1) % F == 0 or j + 1 == n_mine:
+                    flush(chunk_ids, recs, cnts)
+                    chunk_ids, recs, cnts = [], [], []
+    ids = all_ids
+    order = sorted(range(len(ids)), key=lambda q: ids[q])
+    ids = [ids[q] for q in order]
+    cnt = torch.cat(all_cnt)[order] if all_cnt else torch.zeros((0,), dtype=torch.int32)
+    rec = torch.cat(all_rec)[order] if all_rec else torch.zeros((0, 128, width))
     if rank == 0:
         with open(args.output, "w") as fp:
             json.dump(results_json(ids, cnt, rec, K, BDD_CAT_MAP), fp, indent=4, separators=(",", ": "))

@@ -99,7 +99,7 @@ def test_shard_indices_cover_all_images_once():
         assert seen == list(range(21))
 
 
-def _gather_worker(rank, world, port, num_images, tmp):
+def _gather_worker(rank, world, port, num_images, tmp, flush_every=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     K, md = 7, 4
@@ -113,7 +113,18 @@ def _gather_worker(rank, world, port, num_images, tmp):
             rec[j, d, :4] = torch.tensor([i, d, 10.0, 20.0])
             rec[j, d, 4] = 1.0 / (1 + d)
             rec[j, d, 5] = (i + d) % K
-    ids, c, r = apply_net.gather_records(mine, cnt, rec, num_images, world)
+    if flush_every is None:
+        ids, c, r = apply_net.gather_records(mine, cnt, rec, num_images, world)
+    else:   # the driver's periodic flush: every rank joins every collective, chunks of `flush_every` images per rank
+        n_flush = len(apply_net.shard_indices(num_images, 0, world))
+        ids, cs, rs = [], [], []
+        for a in range(0, n_flush, flush_every):
+            i2, c2, r2 = apply_net.gather_records(mine[a:a + flush_every], cnt[a:a + flush_every], rec[a:a + flush_every], num_images,
+                                                  world, per_rank=flush_every)
+            ids.extend(i2); cs.append(c2); rs.append(r2)
+        order = sorted(range(len(ids)), key=lambda q: ids[q])
+        ids = [ids[q] for q in order]
+        c, r = torch.cat(cs)[order], torch.cat(rs)[order]
     if rank == 0:
         js = apply_net.results_json(ids, c, r, K, apply_net.BDD_CAT_MAP)
         with open(os.path.join(tmp, "out.json"), "w") as f:
@@ -122,11 +133,12 @@ def _gather_worker(rank, world, port, num_images, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_images", [7, 8])
-def test_two_rank_gather_restores_image_order(tmp_path, num_images):
-    """world_size-2 gloo run of the sharding + all_gather + re-ordering logic (ragged shards when num_images is odd)."""
-    port = 29500 + (os.getpid() % 2000) + num_images
-    mp.spawn(_gather_worker, args=(2, port, num_images, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("num_images,flush_every", [(7, None), (8, None), (7, 2), (9, 3)])
+def test_two_rank_gather_restores_image_order(tmp_path, num_images, flush_every):
+    """world_size-2 gloo run of the sharding + all_gather + re-ordering logic (ragged shards when num_images is odd), in one
+    gather or in the driver's periodic flushes."""
+    port = 29500 + (os.getpid() % 2000) + num_images + 10 * (flush_every or 0)
+    mp.spawn(_gather_worker, args=(2, port, num_images, str(tmp_path), flush_every), nprocs=2, join=True)
     out = json.load(open(tmp_path / "out.json"))
     assert out["ids"] == list(range(num_images))
     assert out["counts"] == [i % 5 for i in range(num_images)]
