@@ -4,8 +4,9 @@
         --config-file <model.yaml> --inference-config <inference.yaml> --num-images 64 --output results.json
 
 The reference pins inference to one process (AN:113-114).  Here rank r handles images r, r+world, ...
-(independent units, batch 1 as AN:35); each rank keeps its detections as fixed-stride records in HBM
-(K7) and ONE collective per flush gathers counts + records to every rank (`all_gather`; backend "nccl" =
+(independent units, batch 1 as AN:35, a few of them in flight on separate HIP streams); each rank keeps its detections
+as fixed-stride records in HBM (K7) and ONE collective per flush (every --flush-every images per rank) gathers counts +
+records to every rank (`all_gather`; backend "nccl" =
 RCCL over xGMI on GPUs, "gloo" in the CPU tests of this sharding/re-ordering logic).  Rank 0 restores the
 image order and writes `coco_instances_results.json` (AN:100-102 format).
 """
