@@ -104,8 +104,8 @@ int pod_abi_version(void);
  *     key = (float_bits(score) << 32) | (0xFFFFFFFF - r)      (descending key = score desc, r asc)
  * mean_* : dev, level-concatenated plane layout: level l starts at anchor_base_l * C elements.
  * cand_keys : dev uint64[R_total], level l's list starts at anchor_base_l.
- * cand_count: dev int32[n_levels], MUST be zero on entry (pod_reset_counters once after allocation;
- *             pod_level_topk leaves it zeroed again).
+ * cand_count: dev int32[2 * n_levels] (counts, then pod_level_topk's tickets), MUST be zero on entry
+ *             (pod_reset_counters once after allocation; pod_level_topk leaves it zeroed again).
  * HBM-bound; algorithmic bytes per image = 4 * R * (2K + 4 + D) * (N + 1)  (SURVEY 8d). */
 int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
                        float* mean_cls, float* mean_cls_var, float* mean_delta, float* mean_reg_var,
@@ -129,12 +129,14 @@ int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
 /* ---- K2  level_topk ------------------------------------------------------------------------
  * Replaces: `predicted_prob.topk(num_topk)` + `> test_score_thresh` filter PI:300-308, per level.
  * Exact top-`topk` of each level's candidate list, sorted by descending key (ties: lower anchor
- * index first).  One workgroup per level: LDS bitonic sort, preceded by an 8-pass radix select
- * when a level has more than POD_MAX_TOPK candidates.
+ * index first).  A level with at most POD_MAX_TOPK candidates: one workgroup, LDS bitonic sort.
+ * A bigger level: 16 workgroups select the top-k of one slice each (MSB radix select + sort), the
+ * last one to finish selects the final top-k from their survivors (no spinning).
  * sel_keys : dev uint64[n_levels * topk];  sel_count : dev int32[n_levels] (written).
- * cand_count is consumed: every level's counter is left at ZERO, ready for the next image's
- * pod_mc_merge_score (no pod_reset_counters between images). */
-int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
+ * cand_keys and cand_count are CONSUMED: big levels are compacted in place, every counter is left at
+ * ZERO, ready for the next image's pod_mc_merge_score (no pod_reset_counters between images).
+ * cand_count : dev int32[2 * n_levels]: the counts, then n_levels ticket words (zero on entry, left zero). */
+int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, uint64_t* cand_keys,
                    int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream);
 
 /* ---- K2b gather_candidates -----------------------------------------------------------------

@@ -18,80 +18,106 @@ namespace pod {
 constexpr int TOPK_THREADS = 1024;
 constexpr int SORT_CAP = POD_MAX_TOPK;   // 2048 keys = 16 KiB LDS
 
+// Descending bitonic sort of s[0 .. n_pow2), n_pow2 <= 2 * TOPK_THREADS, by TOPK_THREADS threads.  Thread t keeps elements t and
+// t + 1024 in registers.  Of the (log n)(log n + 1)/2 compare-exchange steps only those with a partner distance of 64..512 go
+// through LDS (two barriers each); distances below 64 are wavefront shuffles and distance 1024 is the thread's own pair, so a
+// 2048-key sort pays 14 LDS rounds instead of 66 (27 us -> 9 us on one CU).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, mask, 64), hi = __shfl_xor((uint32_t)(v >> 32), mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t bitonic_pick(uint64_t own, uint64_t other, int i, int j, int k) {
+    const bool desc = (i & k) == 0, lower = (i & j) == 0;           // lower index of the pair takes the larger key in a desc block
+    const uint64_t hi = own > other ? own : other, lo = own > other ? other : own;
+    return (desc == lower) ? hi : lo;
+}
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n_pow2, int tid, int nthreads) {
+    const bool two = n_pow2 > TOPK_THREADS;
+    uint64_t e0 = tid < n_pow2 ? s[tid] : 0ull, e1 = two ? s[tid + TOPK_THREADS] : 0ull;
+    const int i0 = tid, i1 = tid + TOPK_THREADS;
     for (int k = 2; k <= n_pow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n_pow2; i += nthreads) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t a = s[i], b = s[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < b) : (a > b)) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
-                }
+            if (j >= TOPK_THREADS) {                 // k = 2048, j = 1024: the thread's own pair (desc block, i0 is the lower index)
+                const uint64_t hi = e0 > e1 ? e0 : e1, lo = e0 > e1 ? e1 : e0;
+                e0 = hi;
+                e1 = lo;
+            } else if (j >= 64) {
+                __syncthreads();
+                if (tid < n_pow2) s[i0] = e0;
+                if (two) s[i1] = e1;
+                __syncthreads();
+                if (tid < n_pow2) e0 = bitonic_pick(e0, s[i0 ^ j], i0, j, k);
+                if (two) e1 = bitonic_pick(e1, s[i1 ^ j], i1, j, k);
+            } else {
+                e0 = bitonic_pick(e0, shfl_xor_u64(e0, j), i0, j, k);
+                if (two) e1 = bitonic_pick(e1, shfl_xor_u64(e1, j), i1, j, k);
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
+    if (tid < n_pow2) s[i0] = e0;
+    if (two) s[i1] = e1;
+    __syncthreads();
 }
 
 struct K2Params {
     int32_t anchor_base[POD_MAX_LEVELS];
     int32_t topk;
-    const uint64_t* cand_keys;
-    int32_t* cand_count;
+    uint64_t* cand_keys;      // consumed: a big level's slices are compacted in place
+    int32_t* cand_count;      // [n_levels] counts, then [n_levels] tickets (zero on entry, left zero)
+    int32_t n_levels;
     uint64_t* sel_keys;
     int32_t* sel_count;
 };
 
-__global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) {
-    __shared__ uint64_t s_keys[SORT_CAP];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint64_t s_prefix;
-    __shared__ int32_t s_remaining, s_fill, s_bucket;
-    const int l = blockIdx.x;
+constexpr int TOPK_SLICES = 16;   // workgroups per level; only a level with more than SORT_CAP candidates uses more than one
+
+struct TopkLds {
+    uint64_t keys[SORT_CAP];
+    uint32_t hist[256];
+    uint64_t prefix;
+    uint32_t wtot[4];
+    int32_t remaining, fill, bucket, ticket, pick, pick_rem;
+};
+
+// The `want` largest of the `count` keys fetch(0..count-1) (all distinct, or 0 = absent), sorted descending in S.keys[0..want).
+// count <= SORT_CAP: straight into the LDS bitonic network.  Otherwise an MSB radix select (LDS histograms, from the top byte
+// down) runs until the keys that can still be in the top `want` fit the sort buffer: after a pass the candidates are {keys
+// above the chosen bucket} + {the bucket}; typically 2-4 passes.  8 independent fetches per thread per step.
+template <class Fetch>
+__device__ void topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
     const int tid = threadIdx.x;
-    const uint64_t* keys = P.cand_keys + P.anchor_base[l];
-    const int C = P.cand_count[l];
-    __syncthreads();
-    if (tid == 0) P.cand_count[l] = 0;   // consumed: the next image's K1 appends from zero (no reset launch per image)
-    const int k = min(P.topk, C);
     int n_sort;
-    if (C <= SORT_CAP) {
+    if (count <= SORT_CAP) {
         n_sort = 1;
-        while (n_sort < C) n_sort <<= 1;
-        for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = (i < C) ? keys[i] : 0ull;
+        while (n_sort < count) n_sort <<= 1;
+        for (int i = tid; i < n_sort; i += TOPK_THREADS) S.keys[i] = (i < count) ? fetch(i) : 0ull;
         __syncthreads();
     } else {
-        // Radix select from the top byte down, until the keys that can still be in the top-k fit the LDS sort buffer:
-        // after a pass the candidates are {keys above the chosen bucket} + {the bucket}; typically 2-4 passes.
-        // 8 independent 8-byte loads per thread per step (a lone load per iteration made every pass latency-bound).
         if (tid == 0) {
-            s_prefix = 0ull;
-            s_remaining = k;
-            s_fill = 0;
+            S.prefix = 0ull;
+            S.remaining = want;
+            S.fill = 0;
         }
         __syncthreads();
-        uint64_t lower_bound = 0ull;     // every key >= lower_bound is still a top-k candidate; there are <= SORT_CAP of them at exit
+        uint64_t lower_bound = 0ull;     // every key >= lower_bound is still a candidate; there are <= SORT_CAP of them at exit
         for (int pass = 7; pass >= 0; --pass) {
             const int shift = pass * 8;
-            if (tid < 256) s_hist[tid] = 0u;
+            if (tid < 256) S.hist[tid] = 0u;
             __syncthreads();
-            const uint64_t prefix = s_prefix;
+            const uint64_t prefix = S.prefix;
             const uint64_t himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
-            for (int i0 = 0; i0 < C; i0 += TOPK_THREADS * 8) {
+            for (int i0 = 0; i0 < count; i0 += TOPK_THREADS * 8) {
                 uint64_t kk[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u * TOPK_THREADS + tid;
-                    kk[u] = (i < C) ? keys[i] : 0ull;
+                    kk[u] = (i < count) ? fetch(i) : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u * TOPK_THREADS + tid;
-                    const bool live = i < C && (kk[u] & himask) == prefix;
+                    const bool live = i < count && (kk[u] & himask) == prefix;
                     // top digits of score keys are heavily skewed: one LDS atomic when the whole wavefront agrees
                     const uint32_t digit = (uint32_t)(kk[u] >> shift) & 255u;
                     const unsigned long long lm = __ballot(live);
@@ -99,55 +125,138 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
                         const int leader = __ffsll((long long)lm) - 1;
                         const uint32_t d0 = __shfl(digit, leader, 64);
                         if (__ballot(live && digit == d0) == lm) {
-                            if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[d0], (uint32_t)__popcll(lm));
+                            if ((threadIdx.x & 63) == leader) atomicAdd(&S.hist[d0], (uint32_t)__popcll(lm));
                         } else if (live) {
-                            atomicAdd(&s_hist[digit], 1u);
+                            atomicAdd(&S.hist[digit], 1u);
                         }
                     }
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining;
-                int d = 255;
-                for (; d > 0; --d) {
-                    const int c = (int)s_hist[d];
-                    if (c >= rem) break;
-                    rem -= c;
+            // bucket holding the `remaining`-th largest live key: the largest d with sum_{j >= d} hist[j] >= remaining.  Suffix sums by
+            // wavefront scans (a single thread walking the 256 bins through LDS cost ~7 us per pass)
+            uint32_t cnt = 0, incl = 0;
+            if (tid < 256) {
+                cnt = S.hist[tid];
+                incl = cnt;
+                const int ln = tid & 63;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_down(incl, o, 64);
+                    if (ln + o < 64) incl += up;
                 }
-                s_remaining = rem;                                  // still needed from bucket d
-                s_prefix = prefix | ((uint64_t)d << shift);
-                s_bucket = (int)s_hist[d];
+                if (ln == 0) S.wtot[tid >> 6] = incl;
             }
             __syncthreads();
-            lower_bound = s_prefix;
-            // candidates = (k - remaining) keys above the bucket + the bucket itself
-            if ((k - s_remaining) + s_bucket <= SORT_CAP) break;
+            if (tid < 256) {
+                for (int w = (tid >> 6) + 1; w < 4; ++w) incl += S.wtot[w];
+                const uint32_t excl = incl - cnt;                   // live keys in the buckets above this one
+                const uint32_t rem = (uint32_t)S.remaining;
+                // exactly one bucket qualifies; bucket 0 takes what no higher bucket covers (as a walk from the top would)
+                const bool chosen = tid == 0 ? excl < rem : (excl < rem && rem <= incl);
+                if (chosen) {
+                    S.pick = tid;
+                    S.pick_rem = (int)(rem - excl);
+                    S.bucket = (int)cnt;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                S.remaining = S.pick_rem;                            // still needed from bucket `pick`
+                S.prefix = prefix | ((uint64_t)S.pick << shift);
+            }
+            __syncthreads();
+            lower_bound = S.prefix;
+            // candidates = (want - remaining) keys above the bucket + the bucket itself
+            if ((want - S.remaining) + S.bucket <= SORT_CAP) break;
         }
-        const int n_cand = (k - s_remaining) + s_bucket;            // exact count of keys >= lower_bound
+        const int n_cand = (want - S.remaining) + S.bucket;         // exact count of keys >= lower_bound
         n_sort = 1;
         while (n_sort < n_cand) n_sort <<= 1;
-        for (int i = tid; i < n_sort; i += TOPK_THREADS) s_keys[i] = 0ull;
+        for (int i = tid; i < n_sort; i += TOPK_THREADS) S.keys[i] = 0ull;
         __syncthreads();
-        for (int i0 = 0; i0 < C; i0 += TOPK_THREADS * 8) {
+        for (int i0 = 0; i0 < count; i0 += TOPK_THREADS * 8) {
             uint64_t kk[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * TOPK_THREADS + tid;
-                kk[u] = (i < C) ? keys[i] : 0ull;
+                kk[u] = (i < count) ? fetch(i) : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * TOPK_THREADS + tid;
-                if (i < C && kk[u] >= lower_bound) s_keys[atomicAdd(&s_fill, 1)] = kk[u];
+                // one returning LDS atomic per wavefront and step, not per key (2048 same-address returning atomics: ~40 us)
+                const bool sel = i < count && kk[u] >= lower_bound && kk[u] != 0ull;
+                const unsigned long long sm = __ballot(sel);
+                if (sm != 0ull) {
+                    const int ln = threadIdx.x & 63, leader = __ffsll((long long)sm) - 1;
+                    int at = 0;
+                    if (ln == leader) at = atomicAdd(&S.fill, __popcll(sm));
+                    at = __shfl(at, leader, 64);
+                    if (sel) S.keys[at + __popcll(sm & ((1ull << ln) - 1ull))] = kk[u];
+                }
             }
         }
         __syncthreads();
     }
-    bitonic_sort_desc(s_keys, n_sort, tid, TOPK_THREADS);
+    bitonic_sort_desc(S.keys, n_sort, tid, TOPK_THREADS);
+}
+
+// Grid = n_levels x TOPK_SLICES workgroups.  A level with <= SORT_CAP candidates (every level of a typical image) is sorted by
+// its slice-0 workgroup alone.  A bigger level is cut into TOPK_SLICES slices: the global top-k is contained in the union of the
+// slices' top-k, so every workgroup selects its slice's top-k (16x shorter scans, on 16 CUs), writes it back over the head of its
+// own slice and takes a ticket; the workgroup that draws the last ticket selects the final top-k from the <= 16k survivors.
+// No spinning: the others simply exit.
+__global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) {
+    __shared__ TopkLds S;
+    const int l = blockIdx.x / TOPK_SLICES, b = blockIdx.x % TOPK_SLICES;
+    const int tid = threadIdx.x;
+    uint64_t* keys = P.cand_keys + P.anchor_base[l];
+    int32_t* ticket = P.cand_count + P.n_levels + l;
+    const int C = P.cand_count[l];           // stays put until the last workgroup of the level resets it
+    const int k = min(P.topk, C);
     uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
-    for (int i = tid; i < k; i += TOPK_THREADS) out[i] = s_keys[i];
-    if (tid == 0) P.sel_count[l] = k;
+    if (C <= SORT_CAP) {
+        if (b != 0) return;
+        topk_into_lds(S, [=](int i) { return keys[i]; }, C, k);
+        for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
+        if (tid == 0) {
+            P.sel_count[l] = k;
+            P.cand_count[l] = 0;   // consumed: the next image's K1 appends from zero (no reset launch per image)
+        }
+        return;
+    }
+    const int slice = ((C + TOPK_SLICES - 1) / TOPK_SLICES + 7) & ~7;      // keys per slice
+    const int begin = b * slice;
+    const int len = max(0, min(slice, C - begin));
+    const int kb = min(k, len);                                            // this slice's survivors
+    if (len > 0) {
+        const uint64_t* mine = keys + begin;
+        topk_into_lds(S, [=](int i) { return mine[i]; }, len, kb);
+        for (int i = tid; i < kb; i += TOPK_THREADS) keys[begin + i] = S.keys[i];   // in place: only this workgroup touches the slice
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) S.ticket = atomicAdd(ticket, 1);
+    __syncthreads();
+    if (S.ticket != TOPK_SLICES - 1) return;
+    __threadfence();
+    // last workgroup of the level: virtual list j -> survivor (j % k) of slice (j / k); 0 where a slice has fewer
+    const int kk = k;
+    auto survivors = [=](int j) -> uint64_t {
+        const int sb = j / kk, r = j - sb * kk;
+        const int sbegin = sb * slice;
+        const int slen = max(0, min(slice, C - sbegin));
+        // device-scope load: this CU's L1 may still hold the line from before the other workgroup compacted its slice
+        return r < min(kk, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    };
+    topk_into_lds(S, survivors, TOPK_SLICES * kk, kk);
+    for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
+    if (tid == 0) {
+        P.sel_count[l] = k;
+        P.cand_count[l] = 0;
+        *ticket = 0;
+    }
 }
 
 __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
@@ -157,14 +266,15 @@ __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
 
 }  // namespace pod
 
-extern "C" int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cand_keys,
+extern "C" int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, uint64_t* cand_keys,
                               int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream) {
     if (!cfg || !levels || !cand_keys || !cand_count || !sel_keys || !sel_count) return POD_E_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS || cfg->topk < 1 || cfg->topk > POD_MAX_TOPK) return POD_E_INVALID;
     pod::K2Params P;
     for (int l = 0; l < cfg->n_levels; ++l) P.anchor_base[l] = levels[l].anchor_base;
-    P.topk = cfg->topk; P.cand_keys = cand_keys; P.cand_count = cand_count; P.sel_keys = sel_keys; P.sel_count = sel_count;
-    hipLaunchKernelGGL(pod::k2_level_topk, dim3(cfg->n_levels), dim3(pod::TOPK_THREADS), 0, (hipStream_t)stream, P);
+    P.topk = cfg->topk; P.cand_keys = cand_keys; P.cand_count = cand_count; P.n_levels = cfg->n_levels; P.sel_keys = sel_keys;
+    P.sel_count = sel_count;
+    hipLaunchKernelGGL(pod::k2_level_topk, dim3(cfg->n_levels * pod::TOPK_SLICES), dim3(pod::TOPK_THREADS), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

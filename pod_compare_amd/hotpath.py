@@ -132,7 +132,7 @@ class HotPath:
         self.mean_delta = f32(self.R * 4) if merged and dense_box_merge else None
         self.mean_reg_var = f32(self.R * D) if merged and D > 0 and dense_box_merge else None
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
-        self.counters = torch.zeros(hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count
+        self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count, [L:2L] K2's tickets
         self.cand_count = self.counters[: self.L]
         n_words = sum(A * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words()
         self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None

@@ -1,0 +1,55 @@
+"""pod_level_topk through the C ABI against torch.sort: exact top-k of every level's key list, sorted descending, for the
+single-workgroup path (<= 2048 candidates), the sliced path (16 workgroups + last-one-merges) and its corner sizes;
+counters and tickets left zeroed."""
+import pytest
+import torch
+
+from pod_compare_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+
+def make_keys(C, seed, skew):
+    g = torch.Generator().manual_seed(seed)
+    if skew:      # scores piled up in a narrow band: many keys share their top bytes (what a radix select finds hardest)
+        scores = 0.7 + 1e-4 * torch.rand(C, generator=g)
+    else:
+        scores = torch.rand(C, generator=g) * 0.95 + 0.05
+    idx = torch.randperm(C, generator=g)
+    return (scores.view(torch.int32).to(torch.int64) << 32) | (0xFFFFFFFF - idx.to(torch.int64))
+
+
+@pytest.mark.parametrize("skew", [False, True])
+@pytest.mark.parametrize("counts", [[1, 0, 5], [63, 64, 65], [700, 1024, 1500], [2048, 2049, 5000], [20000, 2268, 594], [145152, 36288, 9072, 2268, 594]])
+def test_level_topk_equals_sorted_prefix(counts, skew):
+    lib, P = hip.load(), hip.ptr
+    L, topk = len(counts), 1000
+    cfg = hip.PodConfig()
+    cfg.n_levels, cfg.topk = L, topk
+    lv = (hip.PodLevel * L)()
+    base, bases = 0, []
+    for l, c in enumerate(counts):
+        lv[l].anchor_base = base
+        bases.append(base)
+        base += c + 3                      # odd gaps: level lists need not be 16-byte aligned
+    keys = torch.zeros(base, dtype=torch.int64)
+    refs = []
+    for l, c in enumerate(counts):
+        kk = make_keys(c, 10 * l + c, skew)
+        keys[bases[l]:bases[l] + c] = kk
+        refs.append(torch.sort(kk, descending=True)[0][:topk])
+    dk = keys.cuda()
+    cnt = torch.zeros(2 * L, dtype=torch.int32, device="cuda")
+    cnt[:L] = torch.tensor(counts, dtype=torch.int32)
+    sel = torch.full((L * topk,), -1, dtype=torch.int64, device="cuda")
+    sc = torch.full((L,), -1, dtype=torch.int32, device="cuda")
+    for _ in range(2):                     # second round on the consumed counters: every level must come out empty
+        hip.check(lib.pod_level_topk(cfg, lv, P(dk), P(cnt), P(sel), P(sc), hip.current_stream()), "pod_level_topk")
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0
+        if _ == 0:
+            assert sc.cpu().tolist() == [min(topk, c) for c in counts]
+            for l in range(L):
+                assert torch.equal(sel[l * topk:l * topk + len(refs[l])].cpu(), refs[l]), l
+        else:
+            assert sc.cpu().tolist() == [0] * L
