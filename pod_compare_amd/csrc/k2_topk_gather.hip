@@ -84,8 +84,10 @@ struct TopkLds {
 // count <= SORT_CAP: straight into the LDS bitonic network.  Otherwise an MSB radix select (LDS histograms, from the top byte
 // down) runs until the keys that can still be in the top `want` fit the sort buffer: after a pass the candidates are {keys
 // above the chosen bucket} + {the bucket}; typically 2-4 passes.  8 independent fetches per thread per step.
-template <class Fetch>
-__device__ void topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
+// SORT = false stops before the sort: S.keys[0 .. returned size) then holds an unordered SUPERSET of the top `want` (at most
+// SORT_CAP keys, zero-padded), which is all a slice has to hand to the final selection.
+template <bool SORT, class Fetch>
+__device__ int topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
     const int tid = threadIdx.x;
     int n_sort;
     if (count <= SORT_CAP) {
@@ -199,13 +201,15 @@ __device__ void topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
         }
         __syncthreads();
     }
-    bitonic_sort_desc(S.keys, n_sort, tid, TOPK_THREADS);
+    if (SORT) bitonic_sort_desc(S.keys, n_sort, tid, TOPK_THREADS);
+    return n_sort;
 }
 
 // Grid = n_levels x TOPK_SLICES workgroups.  A level with <= SORT_CAP candidates (every level of a typical image) is sorted by
 // its slice-0 workgroup alone.  A bigger level is cut into TOPK_SLICES slices: the global top-k is contained in the union of the
-// slices' top-k, so every workgroup selects its slice's top-k (16x shorter scans, on 16 CUs), writes it back over the head of its
-// own slice and takes a ticket; the workgroup that draws the last ticket selects the final top-k from the <= 16k survivors.
+// slices' top-k, so every workgroup narrows its slice down to <= 2048 candidates containing the slice's top-k (16x shorter scans,
+// on 16 CUs), writes them back over the head of its own slice and takes a ticket; the workgroup that draws the last ticket selects
+// and sorts the final top-k from the <= 32k survivors.
 // No spinning: the others simply exit.
 __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) {
     __shared__ TopkLds S;
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
     if (C <= SORT_CAP) {
         if (b != 0) return;
-        topk_into_lds(S, [=](int i) { return keys[i]; }, C, k);
+        topk_into_lds<true>(S, [=](int i) { return keys[i]; }, C, k);
         for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
         if (tid == 0) {
             P.sel_count[l] = k;
@@ -229,11 +233,12 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     const int slice = ((C + TOPK_SLICES - 1) / TOPK_SLICES + 7) & ~7;      // keys per slice
     const int begin = b * slice;
     const int len = max(0, min(slice, C - begin));
-    const int kb = min(k, len);                                            // this slice's survivors
-    if (len > 0) {
+    // survivors of a slice = an unordered superset of its top-k, at most SORT_CAP keys, written over the head of the slice and
+    // zero-padded to min(len, SORT_CAP); a slice that short is its own survivor list.  Sorting here would only be redone below.
+    if (len > SORT_CAP) {
         const uint64_t* mine = keys + begin;
-        topk_into_lds(S, [=](int i) { return mine[i]; }, len, kb);
-        for (int i = tid; i < kb; i += TOPK_THREADS) keys[begin + i] = S.keys[i];   // in place: only this workgroup touches the slice
+        const int n_out = topk_into_lds<false>(S, [=](int i) { return mine[i]; }, len, min(k, len));
+        for (int i = tid; i < SORT_CAP; i += TOPK_THREADS) keys[begin + i] = i < n_out ? S.keys[i] : 0ull;   // only this workgroup touches the slice
     }
     __threadfence();
     __syncthreads();
@@ -241,16 +246,15 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     __syncthreads();
     if (S.ticket != TOPK_SLICES - 1) return;
     __threadfence();
-    // last workgroup of the level: virtual list j -> survivor (j % k) of slice (j / k); 0 where a slice has fewer
-    const int kk = k;
+    // last workgroup of the level: virtual list j -> entry (j % SORT_CAP) of slice (j / SORT_CAP)'s survivor list; 0 = no key
     auto survivors = [=](int j) -> uint64_t {
-        const int sb = j / kk, r = j - sb * kk;
+        const int sb = j / SORT_CAP, r = j - sb * SORT_CAP;
         const int sbegin = sb * slice;
         const int slen = max(0, min(slice, C - sbegin));
         // device-scope load: this CU's L1 may still hold the line from before the other workgroup compacted its slice
-        return r < min(kk, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        return r < min(SORT_CAP, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     };
-    topk_into_lds(S, survivors, TOPK_SLICES * kk, kk);
+    topk_into_lds<true>(S, survivors, TOPK_SLICES * SORT_CAP, k);
     for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
     if (tid == 0) {
         P.sel_count[l] = k;
