@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
         for (int r = 0; r < 4; ++r) acc[16 + r] += pr.a[r * 4 + 0] * mu[0] + pr.a[r * 4 + 1] * mu[1] + pr.a[r * 4 + 2] * mu[2] + pr.a[r * 4 + 3] * mu[3];
         acc[20] += 1.0;
     }
-    block_sum<22 + POD_MAX_CLASSES>(acc, s_red);
+    // the class-probability sums are only needed (and only accumulated) in cls_mode 1: 22 instead of 38 fp64 butterflies otherwise
+    if (P.cls_mode == 1) block_sum<22 + POD_MAX_CLASSES>(acc, s_red);
+    else block_sum<22>(acc, s_red);
     const double m_same = acc[20];
     M4 total;
 #pragma unroll
