@@ -5,21 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one image through predictor(input_im): ResNet-50-FPN + probabilistic RetinaNet head on
-PyTorch-ROCm (MC-dropout runs batched), then the hand-written HIP hot path K1..K7 in native-RNG mode
-(in-kernel Philox).  Frames (uint8 1280x720) and the planted head tensors are resident in HBM before
-the timed region.  Random-init weights give p ~= 0.01 < 0.05, i.e. no detections, so --
-as SURVEY 8(d) prescribes -- the conv net is run and timed on the frame and the hot path consumes seeded
-planted-object head tensors of the same shape (rotated over `--images` distinct sets, 170 MB each at
-N = 10, so consecutive steps never re-read a cache-resident buffer).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this script under torch.distributed.run with N
+ranks (one per GPU); inside a launch, WORLD_SIZE must equal --gpus (a mismatch is an error, never a silent 1-rank run).
 
-Images shard over ranks (rank r takes images r, r+world, ...: weak scaling, per-GPU work fixed); the
-only collective is one RCCL all_gather of the fixed-stride detection records at the end of the timed
-region.  Rank 0 prints ONE JSON line.
+A "step" is one image through predictor(input_im): ResNet-50-FPN + probabilistic RetinaNet head on PyTorch-ROCm
+(MC-dropout runs batched), then the hand-written HIP hot path K1..K7 in native-RNG mode (in-kernel Philox).  Frames
+(uint8 1280x720) and the planted head tensors are resident in HBM before the timed region.  Random-init weights give
+p ~= 0.01 < 0.05, i.e. no detections, so -- as SURVEY 8(d) prescribes -- the conv net is run and timed on
+the frame, its output is discarded, and the hot path consumes seeded planted-object head tensors of the same shape
+(rotated over `--images` distinct sets, 170 MB each at N = 10, so consecutive steps never re-read a cache-resident
+buffer).
+
+Images shard over ranks (rank r takes images r, r+world, ...: weak scaling, per-GPU work fixed); the only collective is
+one RCCL all_gather of the fixed-stride detection records at the end of the timed region.  `--config cfg5
+--ensemble-per-gpu` is BASELINE configs[4] in its 8-GPU topology instead: one ensemble member per rank, the dense
+pre-NMS tensors exchanged point-to-point onto a rotating merge rank (pod_compare_amd.ensemble_dist.MemberPipeline).
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,19 +40,21 @@ from pod_compare_amd import anchors as A  # noqa: E402
 from pod_compare_amd import hotpath, modeling, synthetic  # noqa: E402
 
 CONFIGS = {
-    # BASELINE.json configs[1..3]; configs[0] (CPU plumbing) and [4] (5-seed ensemble) are parity-test cases
+    # BASELINE.json configs[1..4]; configs[0] (CPU plumbing) is a parity-test case
     "cfg2": dict(name="retinanet_R_50_FPN_1x_reg_cls_var + bayes_od.yaml", mode="bayes_od", runs=1, cls_var=True, reg_var=True,
-                 dropout=0.0),
+                 dropout=0.0, yaml=("retinanet_R_50_FPN_1x_reg_cls_var.yaml", "bayes_od.yaml")),
     "cfg3": dict(name="retinanet_R_50_FPN_1x_reg_cls_var_dropout + bayes_od_mc_dropout.yaml (N=10 MC samples)",
-                 mode="bayes_od", runs=10, cls_var=True, reg_var=True, dropout=0.2),
+                 mode="bayes_od", runs=10, cls_var=True, reg_var=True, dropout=0.2,
+                 yaml=("retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", "bayes_od_mc_dropout.yaml")),
     "cfg4": dict(name="retinanet_R_50_FPN_1x + anchor_statistics.yaml", mode="anchor_statistics", runs=1, cls_var=False,
-                 reg_var=False, dropout=0.0),
-    # BASELINE configs[4] with all 5 members on ONE GPU (the one-seed-per-GPU topology is apply_net --ensemble-per-gpu)
-    "cfg5": dict(name="5-seed ensembles_pre_nms.yaml (reg_cls_var), members stacked on one GPU", mode="ensembles", runs=5,
-                 cls_var=True, reg_var=True, dropout=0.0, members=5),
+                 reg_var=False, dropout=0.0, yaml=("retinanet_R_50_FPN_1x.yaml", "anchor_statistics.yaml")),
+    # BASELINE configs[4]: all 5 members on ONE GPU by default; --ensemble-per-gpu = one member per rank (>= 5 ranks)
+    "cfg5": dict(name="5-seed ensembles_pre_nms.yaml (reg_cls_var)", mode="ensembles", runs=5,
+                 cls_var=True, reg_var=True, dropout=0.0, members=5, yaml=("retinanet_R_50_FPN_1x_reg_cls_var.yaml", "ensembles_pre_nms.yaml")),
 }
 FRAME_HW = (720, 1280)
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 / tf32 on gfx950)
 
 
 def k1_algorithmic_bytes(R, K, D, N, has_cls_var, quirk, dense_box=True):
@@ -60,36 +70,133 @@ def k1_algorithmic_bytes(R, K, D, N, has_cls_var, quirk, dense_box=True):
     return 4 * R * C * (reads + 1)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--images", type=int, default=4, help="distinct planted head-tensor sets kept in HBM")
     ap.add_argument("--synth", default="planted", choices=["planted", "worst"])
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
+    ap.add_argument("--ensemble-per-gpu", action="store_true",
+                    help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the K1 / conv / NLL / worst-case legs after the timed region")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
     ap.add_argument("--k1-traffic-bytes", type=float, default=None,
                     help="HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): 2*FETCH_SIZE + WRITE_SIZE")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def relaunch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (torch.distributed.run, one per GPU)."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("POD_BENCH_SHARE_GPU") != "1":
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s) (POD_BENCH_SHARE_GPU=1 + POD_BENCH_BACKEND=gloo runs "
+                         "all ranks on cuda:0 as a functional check only)" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def conv_census(model, img, N, quirk, dev):
+    """FLOPs of one image's conv net from the layer shapes it actually runs, and the time of every conv call on ONE
+    stream (HIP events around each F.conv2d): the part of a step that is MIOpen's, priced against the fp32 MFMA peak.
+    Categories: the NHWC trunk of large maps (MIOpen implicit GEMM), the other 3x3 convs (Winograd), 1x1 (GEMM), stem."""
+    import torch.nn.functional as F
+    real = F.conv2d
+    calls = []
+
+    def probe(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real(x, w, b, stride, padding, dilation, groups)
+        e1.record()
+        kh, kw = int(w.shape[2]), int(w.shape[3])
+        flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3] * (w.shape[1]) * kh * kw
+        nhwc = x.dim() == 4 and x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        cat = "stem_7x7" if kh == 7 else ("1x1" if kh == 1 else ("3x3_nhwc_trunk" if nhwc else "3x3_nchw"))
+        calls.append((cat, flops, e0, e1))
+        return y
+
+    reps = 3
+    F.conv2d = probe
+    try:
+        with torch.no_grad():
+            for _ in range(reps):
+                model(img, num_mc_dropout_runs=N, skip_unused_last_run=quirk)
+        torch.cuda.synchronize()
+    finally:
+        F.conv2d = real
+    out = {}
+    for cat, flops, e0, e1 in calls:
+        d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
+        d["calls"] += 1
+        d["gflop"] += flops / 1e9
+        d["ms"] += e0.elapsed_time(e1)
+    for d in out.values():
+        d["calls"] //= reps
+        d["gflop"] /= reps
+        d["ms"] /= reps
+        d["tflops"] = d["gflop"] / d["ms"] if d["ms"] > 0 else None
+    return out
+
+
+def run_ensemble_per_gpu(args, spec, world, rank, dev):
+    """cfg5 in its BASELINE topology (one seed per GPU): K timed images through apply_net.EnsemblePerGpu."""
+    import torch.distributed as dist
+    from pod_compare_amd import apply_net, config
+    cfgdir = os.path.join(ROOT, "pod_compare_amd", "configs")
+    cfg = config.setup_config(os.path.join(cfgdir, "BDD-Detection/retinanet", spec["yaml"][0]), os.path.join(cfgdir, "Inference", spec["yaml"][1]))
+    cfg.MODEL.WEIGHTS, cfg.OUTPUT_DIR = "", ""          # synthetic run: seeded random-init members
+    cfg.MODEL.DEVICE = str(dev)
+    runner = apply_net.EnsemblePerGpu(cfg, rank, world, FRAME_HW)
+    n_img = max(1, args.images)
+    frames = [synthetic.synthetic_frame(i, *FRAME_HW, device=dev) for i in range(n_img)]
+    with torch.no_grad():
+        runner.run(max(2 * world, args.warmup), lambda i: frames[i % n_img])
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids, recs, cnts = runner.run(args.steps, lambda i: frames[i % n_img])
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dt, len(ids)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
-    # POD_BENCH_BACKEND=gloo + POD_BENCH_SHARE_GPU=1: debugging aid to exercise the multi-rank code path on a box with
-    # a single GPU (all ranks on cuda:0, collectives staged through the host).  The real path is nccl = RCCL over xGMI.
+    # POD_BENCH_BACKEND=gloo + POD_BENCH_SHARE_GPU=1: functional check of the multi-rank code path on a box with a single
+    # GPU (all ranks on cuda:0, collectives staged through the host).  The real path is nccl = RCCL over xGMI.
     backend = os.environ.get("POD_BENCH_BACKEND", "nccl")
-    if os.environ.get("POD_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("POD_BENCH_SHARE_GPU") == "1"
+    if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -99,6 +206,26 @@ def main():
     stage = (lambda t: t.cpu()) if backend != "nccl" else (lambda t: t)
     spec = CONFIGS[args.config]
     N = spec["runs"]
+
+    if args.ensemble_per_gpu:
+        if args.config != "cfg5" or world < spec["members"]:
+            raise SystemExit("--ensemble-per-gpu is BASELINE configs[4]: --config cfg5 and --gpus >= %d" % spec["members"])
+        if backend != "nccl":
+            raise SystemExit("--ensemble-per-gpu exchanges device buffers point-to-point: needs the nccl (RCCL) backend")
+        dt, merged_here = run_ensemble_per_gpu(args, spec, world, rank, dev)
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({
+                "metric": "images/sec (ensembles pre-NMS, one seed per GPU, 1280x720)", "value": args.steps / dt, "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                "higher_is_better": True, "scaling": "fixed: 5 member ranks, the other ranks only merge", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (seeded 1280x720 uint8 frames; random-init members seeded 0,1000,..; detections of the members' own outputs)",
+                "config": {"workload": spec["name"] + ", one seed per GPU", "parallelism": "5 member ranks + rotating merge rank, RCCL p2p",
+                           "rccl_ranks": world, "images_in_flight": 2, "conv_net_in_timed_region": True}}))
+        dist.destroy_process_group()
+        return
 
     # ---- model (random init, seed 0) and resident inputs ------------------------------------------------
     torch.manual_seed(0)
@@ -129,6 +256,7 @@ def main():
            for _ in range(n_streams)]
     hp = hps[0]
     R = hp.R
+    mc = N > 1 and spec["dropout"] > 0.0
 
     def step(i):
         s = i % n_streams
@@ -143,12 +271,11 @@ def main():
                 else:
                     model(img, num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk)
             h = heads[i % n_img]
-            # K1 .. K7 of the image, enqueued by one C call (pod_run_image)
+            # K1 .. K7 of the image, enqueued by one C call (pod_run_image); fresh Philox draws per image
             return hps[s].run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
 
     with torch.no_grad():
@@ -166,52 +293,103 @@ def main():
         dets = [step(i) for i in range(args.steps)]
         for st in streams[1:]:
             streams[0].wait_stream(st)          # the flush below reads every stream's detections
+        flush_ms = 0.0
         # the path's only collective: gather the fixed-stride detection records of this flush
         if world > 1:
-            import torch.distributed as dist
+            torch.cuda.synchronize()
+            t_images = time.perf_counter() - t0
+            tf = time.perf_counter()
             rec = stage(torch.stack([d.records for d in dets]))
             cnt = stage(torch.stack([d.n_det for d in dets]))
             all_rec = [torch.empty_like(rec) for _ in range(world)]
             all_cnt = [torch.empty_like(cnt) for _ in range(world)]
             dist.all_gather(all_rec, rec)
             dist.all_gather(all_cnt, cnt)
+            torch.cuda.synchronize()
+            flush_ms = 1e3 * (time.perf_counter() - tf)
         torch.cuda.synchronize()
+        if world == 1:
+            t_images = time.perf_counter() - t0
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    per_rank = [args.steps / t_images]
     if world > 1:
-        import torch.distributed as dist
-        t = stage(torch.tensor([dt], device=dev, dtype=torch.float64))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = stage(torch.tensor([dt, flush_ms, t_images], device=dev, dtype=torch.float64))
+        tl = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(tl, t)
+        dt = max(float(x[0]) for x in tl)
+        flush_ms = max(float(x[1]) for x in tl)
+        per_rank = [args.steps / float(x[2]) for x in tl]
     n_det_mean = float(torch.stack([d.n_det for d in dets]).float().mean().item())
 
-    # ---- the hot path alone (no conv net, one stream): HIP events around each image -----------------------
-    hp_steps = max(20, min(args.steps, 200))
-    ev_hp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(hp_steps)]
-    with torch.no_grad():
+    out = {
+        "metric": "images/sec (BayesOD+MC-dropout, 1280x720)" if args.config == "cfg3" else "images/sec (%s, 1280x720)" % spec["mode"],
+        "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
+        "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
+                   "classes": params.num_classes, "synthetic_mode": args.synth, "conv_net_in_timed_region": not args.no_cnn,
+                   "conv_net_output": "computed and timed, then discarded: the hot path consumes planted head tensors (random-init "
+                                      "weights give no detections, SURVEY 8d)",
+                   "skip_unused_last_run": bool(mc and params.merge_quirk),
+                   "skip_unused_last_run_note": "the reference's merge (PI:216-222) never reads run N-1 of cls / cls_var / reg_var; "
+                                                "the head does not compute those 3 of its 4N subnet evaluations",
+                   "members_on_this_gpu": len(members),
+                   "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
+                   "rccl_ranks": world, "collective_backend": backend if world > 1 else None,
+                   "ranks_share_one_gpu": bool(share and world > 1),
+                   "rng": "in-kernel Philox4x32-10, fresh key per image"},
+        "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if world > 1 else None,
+        "mean_detections": n_det_mean,
+    }
+    if rank == 0 and not args.no_diagnostics:
+        diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev, R, N, D, mc)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev, R, N, D, mc):
+    """Everything measured outside the timed region, on rank 0: the hot path alone, K1 against the HBM roofline, the conv
+    net against the fp32 MFMA peak, NLL of the detections against the planted ground truth, worst-case inputs, and the
+    CPU baseline (the oracle on the host cores)."""
+    hp, n_img = hps[0], len(heads)
+    run = lambda h, **kw: hp.run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW, **kw)
+
+    def time_hot_path(hs, iters):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for i in range(5):
-            h = heads[i % n_img]
-            hp.run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
+            run(hs[i % len(hs)])
         torch.cuda.synchronize()
-        t_hp = time.perf_counter()
-        for i in range(hp_steps):
-            h = heads[i % n_img]
-            ev_hp[i][0].record()
-            hp.run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
-            ev_hp[i][1].record()
+        t = time.perf_counter()
+        for i in range(iters):
+            ev[i][0].record()
+            run(hs[i % len(hs)])
+            ev[i][1].record()
         torch.cuda.synchronize()
-        hp_wall_ms = 1e3 * (time.perf_counter() - t_hp) / hp_steps
-    hp_ms = sum(a.elapsed_time(b) for a, b in ev_hp) / hp_steps
+        wall = 1e3 * (time.perf_counter() - t) / iters
+        return sum(a.elapsed_time(b) for a, b in ev) / iters, wall
+
+    # ---- the hot path alone (no conv net, one stream): HIP events around each image -----------------------
+    with torch.no_grad():
+        hp_ms, hp_wall_ms = time_hot_path(heads, max(20, min(args.steps, 200)))
+        out["hot_path_ms_per_image"], out["hot_path_wall_ms_per_image"] = hp_ms, hp_wall_ms
+        if args.synth == "planted":
+            # adversarial inputs: (almost) every anchor passes the threshold on every level, n = 4 594 candidates
+            worst = synthetic.planted_head_outputs(A.padded_size(*net_hw), N, seed=4242, num_boxes=24, with_cls_var=spec["cls_var"],
+                                                   with_reg_var=spec["reg_var"], mode="worst", device=dev)
+            out["hot_path_worst_ms"], _ = time_hot_path([worst], 20)
+            del worst
 
     # ---- K1 alone, HIP events on the launch stream, rotating over the distinct input sets ------------------
-    k1_iters = max(20, args.steps)
+    k1_iters = max(20, min(args.steps, 200))
     lib, P = hp.lib, hotpath.hip.ptr
     lvs = [hp._levels(h.cls, h.delta, h.cls_var, h.reg_var, None) for h in heads]
     st = hotpath.hip.current_stream()
-
     prune = spec["cls_var"]   # native RNG + variance head: K1 runs in prune mode, exactly as in the timed steps
-
     # the product path merges box_delta / box_reg_var at the candidates (K2b); the dense variant also writes their merged
     # planes for every anchor, as PI:243-270 does (HotPath(dense_box_merge=True)).  Both are timed; `roofline` is the
     # product path's launch, `roofline_dense_merge` the reference-shaped dense merge of all 2K+4+D channels.
@@ -247,19 +425,20 @@ def main():
                 k1_call(bidx * K1B + j)
             evs[bidx][1].record()
         torch.cuda.synchronize()
+        lib.pod_reset_counters(P(hp.counters), int(hp.counters.numel()), st)
         if prune:
             hp.maybe_bits.zero_()
         ms = sorted(a.elapsed_time(b) / K1B for a, b in evs)
         return sum(ms) / len(ms), ms[0]
 
+    K = params.num_classes
     k1_avg_ms, k1_min_ms = time_k1(hp.mean_delta, hp.mean_reg_var)
-    k1_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk, dense_box=hp.dense_box_merge)
+    k1_bytes = k1_algorithmic_bytes(R, K, D, N, spec["cls_var"], params.merge_quirk, dense_box=hp.dense_box_merge)
     kd_avg_ms, kd_min_ms = time_k1(dense_delta, dense_reg)
-    kd_bytes = k1_algorithmic_bytes(R, params.num_classes, D, N, spec["cls_var"], params.merge_quirk, dense_box=True)
+    kd_bytes = k1_algorithmic_bytes(R, K, D, N, spec["cls_var"], params.merge_quirk, dense_box=True)
     # HBM traffic of K1 comes from separate rocprofv3 --pmc passes (a counter run cannot share a process with this timing
     # run); the committed summary of the latest pass is read back when it was taken on this very workload.
     traffic, traffic_src, traffic_dense = args.k1_traffic_bytes, "--k1-traffic-bytes", None
-    import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k1_traffic.json")), reverse=True):
         t = json.load(open(path))
         w = t.get("workload", {})
@@ -270,32 +449,48 @@ def main():
             traffic_dense = t.get("k1_dense_traffic_bytes")
             break
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
+    out["roofline"] = {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)",
+                       "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                       "algorithmic_bytes": k1_bytes, "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
+                       "channels_streamed": "2K class channels (box_delta / box_reg_var are merged at the candidates by K2b)"
+                                            if not hp.dense_box_merge else "2K+4+D"}
+    # the same kernel asked for the reference-shaped dense merge of every channel (PI:211-270), for comparison
+    out["roofline_dense_merge"] = {"kernel": "pod_mc_merge_score, mean_delta / mean_reg_var requested", "bound": "hbm",
+                                   "achieved": kd_bytes / (kd_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": kd_bytes / (kd_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_dense,
+                                   "algorithmic_bytes": kd_bytes, "avg_launch_us": 1e3 * kd_avg_ms, "min_launch_us": 1e3 * kd_min_ms,
+                                   "survey_bytes_4RC(N+1)": 4 * R * (K * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)}
 
-    out = {
-        "metric": "images/sec (BayesOD+MC-dropout, 1280x720)" if args.config == "cfg3" else "images/sec (%s, 1280x720)" % spec["mode"],
-        "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
-        "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
-                   "classes": params.num_classes, "synthetic_mode": args.synth, "conv_net_in_timed_region": not args.no_cnn,
-                   "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
-                   "rng": "in-kernel Philox4x32-10"},
-        "hot_path_ms_per_image": hp_ms, "hot_path_wall_ms_per_image": hp_wall_ms, "mean_detections": n_det_mean,
-        "roofline": {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None, "algorithmic_bytes": k1_bytes,
-                     "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
-                     "channels_streamed": "2K class channels (box_delta / box_reg_var are merged at the candidates by K2b)"
-                                          if not hp.dense_box_merge else "2K+4+D"},
-        # the same kernel asked for the reference-shaped dense merge of every channel (PI:211-270), for comparison
-        "roofline_dense_merge": {"kernel": "pod_mc_merge_score, mean_delta / mean_reg_var requested", "bound": "hbm",
-                                 "achieved": kd_bytes / (kd_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": kd_bytes / (kd_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_dense,
-                                 "algorithmic_bytes": kd_bytes, "avg_launch_us": 1e3 * kd_avg_ms, "min_launch_us": 1e3 * kd_min_ms,
-                                 "survey_bytes_4RC(N+1)": 4 * R * (params.num_classes * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)},
-    }
+    # ---- the other 99 % of a step: MIOpen's convs against the fp32 MFMA peak ---------------------------------
+    if not args.no_cnn and spec.get("members", 1) == 1:
+        census = conv_census(model, modeling.resize_test_image(frames[0]), N, params.merge_quirk, dev)
+        gflop = sum(d["gflop"] for d in census.values())
+        conv_ms = sum(d["ms"] for d in census.values())
+        step_tf = gflop / out["ms_per_step"]     # GFLOP / ms = TFLOP/s, whole step (all streams overlapped, hot path included)
+        out["conv_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TF, "dtype": "f32",
+                                "gflop_per_image": gflop, "achieved": step_tf, "frac": step_tf / FP32_MFMA_PEAK_TF,
+                                "basis": "conv FLOPs of one image (2*N*Cout*Hout*Wout*Cin*kh*kw of every F.conv2d call) / ms_per_step",
+                                "conv_ms_per_image_one_stream": conv_ms,
+                                "one_stream_frac": gflop / conv_ms / FP32_MFMA_PEAK_TF if conv_ms > 0 else None,
+                                "by_kind": census}
+
+    # ---- NLL of the detections against the planted ground truth (the "NLL parity" half of the metric) ---------
+    if spec["reg_var"] or N > 1:
+        from pod_compare_amd import evaluation_utils as ev
+        n_nll = min(2, n_img)
+        with torch.no_grad():
+            nat = [run(heads[i], draw_id=i) for i in range(n_nll)]
+            rep = [run(heads[i], eps_fn=synthetic.SeededNormals(90000 + i)) for i in range(n_nll)]
+        gts = [heads[i] for i in range(n_nll)]
+        nll_nat = ev.score_against_planted(nat, gts, net_hw, FRAME_HW)
+        nll_rep = ev.score_against_planted(rep, gts, net_hw, FRAME_HW)
+        out["nll"] = {"rule": "mean over true positives of -log N(gt; mean, cov + 1e-2 I) (scoring_rules.py:68-74), "
+                              "matching evaluation_utils.py:191-367 (IoU >= 0.7), planted boxes as ground truth",
+                      "images": n_nll, "hip_native_rng": nll_nat, "hip_eps_replay": nll_rep}
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on this host's cores, rank 0, N=1 ----------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if out["n_gpus"] == 1 and not args.no_cpu_baseline:
         from oracle import pod_oracle as po
         cores = os.cpu_count() or 1
         threads = min(cores, 32)   # the reference pins torch.set_num_threads(32), apply_net.py:33-40
@@ -320,11 +515,17 @@ def main():
                                "sample": "%d images, post-processing only (head tensors given; conv net excluded), torch CPU "
                                          "oracle/pod_oracle.py, same planted tensors" % n_cpu,
                                "gpu_hot_path_images_per_s": 1e3 / hp_wall_ms}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        if "nll" in out:
+            # the same eps-replay images through the CPU oracle and the oracle's scoring rule: the other backend's NLL
+            vals = []
+            for i in range(out["nll"]["images"]):
+                ref = po.predict(spec["mode"], op, net_hw, FRAME_HW, outputs=cpu_sets[i][0] if N == 1 else None,
+                                 run_outputs=cpu_sets[i] if N > 1 else None, eps_fn=synthetic.SeededNormals(90000 + i))
+                vals.append((ref.pred_boxes, ref.pred_cls_probs, ref.pred_boxes_covariance))
+            cpu_nll = po.score_against_planted(vals, [heads[i].to("cpu") for i in range(out["nll"]["images"])], net_hw, FRAME_HW)
+            out["nll"]["cpu_oracle_eps_replay"] = cpu_nll
+            a, b = out["nll"]["hip_eps_replay"]["nll"], cpu_nll["nll"]
+            out["nll"]["abs_delta_hip_vs_cpu"] = abs(a - b) if a is not None and b is not None else None
 
 
 if __name__ == "__main__":

@@ -296,6 +296,17 @@ int pod_match_groundtruth(const float* det_boxes, const float* det_probs, const 
  * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */
 int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t n, float* nll, pod_stream_t stream);
 
+/* ---- test support: the native-RNG draws, written out ---------------------------------------------
+ * The in-kernel Philox draws that replace Normal(...).rsample((cls_samples,)) PI:291-294 and
+ * MultivariateNormal(...).rsample((1000,)) PI:351-356 are never stored by the product path.  These two entry points
+ * evaluate the same counter -> normal maps for the Philox key in cfg->philox_seed and write them in the reference's
+ * tensor layouts, so a test can feed the CPU oracle exactly the draws pod_run_image used:
+ *   pod_dump_cls_normals: eps_cls dev (cls_samples, H_l*W_l*A, K) of level `level`;
+ *   pod_dump_box_normals: eps_prop dev (prop_samples, n, 4), row i = the draws of global anchor id
+ *                         global_anchor_ids[i] (= anchor_base_l + index inside the level). */
+int pod_dump_cls_normals(const PodConfig* cfg, const PodLevel* levels, int32_t level, float* eps_cls, pod_stream_t stream);
+int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids, int32_t n, float* eps_prop, pod_stream_t stream);
+
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
  * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence

@@ -67,49 +67,69 @@ def results_json(ids: Sequence[int], counts: torch.Tensor, records: torch.Tensor
     return out
 
 
+class EnsemblePerGpu:
+    """Config 5 (`ensembles_pre_nms.yaml`) on one node: ensemble member s lives on rank s < M, every member rank runs the
+    conv net on the SAME image, the dense pre-NMS head tensors meet on the image's merge rank (= the rank that owns the
+    image in the sharded order) through `ensemble_dist.MemberPipeline` (two images in flight), K1..K7 run there
+    (PI:495-505).  Ranks >= M only merge; they never build a model: the predictor reads the model's test-time
+    attributes from `model_test_attributes(cfg)` and the level geometry comes from the anchor generator."""
+
+    def __init__(self, cfg, rank: int, world: int, frame_hw=(720, 1280)):
+        from . import anchors, ensemble_dist, modeling
+        from .probabilistic_inference import RetinaNetProbabilisticPredictor, build_model, ensemble_member_dir, model_test_attributes
+        from .synthetic import HeadOutputs
+        seeds = list(cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.RANDOM_SEED_NUMS)
+        self.M, self.rank, self.world, self.cfg = len(seeds), rank, world, cfg
+        if world < self.M:
+            raise SystemExit("one ensemble member per rank needs at least %d ranks, got %d" % (self.M, world))
+        self.dev = torch.device(cfg.MODEL.DEVICE)
+        self.model = None
+        if rank < self.M:
+            state = torch.random.get_rng_state()
+            torch.manual_seed(int(seeds[rank]))          # a member without a checkpoint is a random-init model seeded with its number
+            self.model = build_model(cfg, save_dir=ensemble_member_dir(cfg, seeds[rank]))      # PI:59-77
+            torch.random.set_rng_state(state)
+        cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.BOX_MERGE_MODE = "pre_nms"
+        self.predictor = RetinaNetProbabilisticPredictor(cfg, model=self.model if self.model is not None else model_test_attributes(cfg),
+                                                         model_list=[object()] * self.M)
+        self.predictor.return_device = True
+        self.frame_hw = tuple(frame_hw)
+        self.net_hw = anchors.resize_shortest_edge(frame_hw[0], frame_hw[1], cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+        padded = anchors.padded_size(*self.net_hw)
+        shapes = anchors.level_shapes(*padded)
+        pm = cfg.MODEL.PROBABILISTIC_MODELING
+        A, K = len(anchors.ANCHOR_SIZES[0]) * len(anchors.ASPECT_RATIOS), cfg.MODEL.RETINANET.NUM_CLASSES
+        D = 0 if pm.BBOX_COV_LOSS.NAME == "none" else (4 if pm.BBOX_COV_LOSS.COVARIANCE_TYPE == "diagonal" else 10)
+        self.layout = ensemble_dist.MemberLayout(shapes, A, K, D, pm.CLS_VAR_LOSS.NAME != "none")
+        self.like = HeadOutputs(None, None, None, None, anchors.grid_anchors(shapes, device=self.dev), shapes, A, K, self.net_hw)
+        self.pipe = ensemble_dist.MemberPipeline(self.layout, self.M, rank, world, self.dev)
+        self._resize = lambda frame: modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+
+    def run(self, num_images: int, frame_of, on_detections=None):
+        """`frame_of(i)` -> uint8 (3, H, W) frame of image i (every rank sees the same frames).  Returns this rank's
+        ([image ids], [records], [counts]) -- device tensors, no host sync."""
+        ids, recs, cnts = [], [], []
+        h, w = self.frame_hw
+        shape_only = torch.empty((3,) + tuple(self.net_hw), device="meta")     # the path only reads the network-input size (IU:39-41)
+
+        def forward(i):
+            return self.model(self._resize(frame_of(i)))
+
+        def merge(i, stacked):
+            input_im = [{"image": shape_only, "height": h, "width": w, "image_id": i}]
+            det = self.predictor._run("standard_nms", input_im, self.layout.views(stacked, self.like))     # PI:502-505
+            ids.append(i); recs.append(det.records); cnts.append(det.n_det)
+            if on_detections is not None:
+                on_detections(i, det)
+
+        self.pipe.run(num_images, forward, merge)
+        return ids, recs, cnts
+
+
 def _run_ensemble_per_gpu(cfg, args, rank, world):
-    """Config 5 (`ensembles_pre_nms.yaml`): one ensemble member per rank, point-to-point exchange of the dense head
-    tensors onto the image's merge rank (= the rank that owns the image in the sharded order), K1..K7 there."""
-    from . import anchors, ensemble_dist, modeling, synthetic
-    from .probabilistic_inference import RetinaNetProbabilisticPredictor, build_model
-    seeds = list(cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.RANDOM_SEED_NUMS)
-    M = len(seeds)
-    if world < M:
-        raise SystemExit("--ensemble-per-gpu needs at least %d ranks (one per ensemble member), got %d" % (M, world))
-    model = None
-    if rank < M:
-        torch.manual_seed(int(seeds[rank]))          # PI:59-77 loads random_seed_<s> checkpoints; random-init stands in
-        model = build_model(cfg)
-    cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.BOX_MERGE_MODE = "pre_nms"
-    predictor = RetinaNetProbabilisticPredictor(cfg, model=model if model is not None else object(), model_list=[object()] * M)
-    if model is None:
-        # merge-only rank: the predictor only needs the model's test-time attributes
-        predictor.model = build_model(cfg)
-    dev = torch.device(cfg.MODEL.DEVICE)
-    net_hw = anchors.resize_shortest_edge(720, 1280, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
-    recs, cnts = [], []
-    layout = stacked = like = None
-    with torch.no_grad():
-        for i in range(args.num_images):
-            dst = ensemble_dist.merge_rank(i, world)
-            frame = synthetic.synthetic_frame(i, device=dev)
-            image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
-            packed = None
-            ho = None
-            if rank < M:
-                ho = model(image)
-            if layout is None:
-                like = ho if ho is not None else predictor.model(image)
-                layout = ensemble_dist.MemberLayout.of(like)
-                stacked = torch.empty((M, layout.total), dtype=torch.float32, device=dev)
-            if rank < M:
-                packed = layout.pack(ho)
-            ensemble_dist.exchange_members(packed, stacked if rank == dst else None, M, dst, rank)
-            if rank == dst:
-                input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
-                predictor._run("standard_nms", input_im, layout.views(stacked, like))     # PI:502-505
-                recs.append(predictor.last_detections.records)
-                cnts.append(predictor.last_detections.n_det)
+    from . import synthetic
+    runner = EnsemblePerGpu(cfg, rank, world)
+    _, recs, cnts = runner.run(args.num_images, lambda i: synthetic.synthetic_frame(i, device=runner.dev))
     return recs, cnts
 
 
@@ -130,6 +150,11 @@ def main(argv=None):
                     help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="BASELINE config 5: rank s < M runs ensemble member s, dense pre-NMS tensors meet on a rotating merge rank")
+    ap.add_argument("--data-dir", default="", help="the reference's core.data_dir(): OUTPUT_DIR = <data-dir>/<dataset>/<family>/<config>/"
+                                                   "random_seed_<seed>, whose last_checkpoint is loaded (CS:170-182, PI:59-84)")
+    ap.add_argument("--weights", default=None, help="overrides MODEL.WEIGHTS (a local .pth / .pkl with detectron2 names)")
+    ap.add_argument("--random-init", action="store_true",
+                    help="synthetic runs: clear MODEL.WEIGHTS / OUTPUT_DIR and keep the seeded random initialisation")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +162,11 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    cfg = setup_config(args.config_file, args.inference_config, args.random_seed)
+    cfg = setup_config(args.config_file, args.inference_config, args.random_seed, data_dir=args.data_dir, is_testing=bool(args.data_dir))
+    if args.weights is not None:
+        cfg.MODEL.WEIGHTS = args.weights
+    if args.random_init:
+        cfg.MODEL.WEIGHTS, cfg.OUTPUT_DIR = "", ""
     cfg.MODEL.DEVICE = "cuda:%d" % local_rank
     K = cfg.MODEL.RETINANET.NUM_CLASSES
     from . import modeling

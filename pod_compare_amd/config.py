@@ -133,13 +133,27 @@ def get_cfg() -> CfgNode:
     })
 
 
-def setup_config(config_file: str, inference_config: str = "", random_seed: int = 0, opts=()) -> CfgNode:
-    """core/setup.py:136-212 minus dataset registration / logging: model YAML, then inference YAML."""
+def setup_config(config_file: str, inference_config: str = "", random_seed: int = 0, opts=(), data_dir: str = "",
+                 is_testing: bool = False) -> CfgNode:
+    """core/setup.py:136-212 minus dataset registration / logging: model YAML, then inference YAML.
+
+    data_dir: the reference's `core.data_dir()`; when given, OUTPUT_DIR becomes
+    `<data_dir>/<dataset>/<model family>/<config name>/random_seed_<seed>` (CS:170-176) -- the directory whose
+    `last_checkpoint` the predictor loads (PI:78-84) -- and, with is_testing, a missing directory raises
+    NotADirectoryError (CS:178-182)."""
     cfg = get_cfg()
     cfg.merge_from_file(config_file)
     if inference_config:
         cfg.merge_from_file(inference_config)
     if opts:
         cfg.merge_from_list(list(opts))
+    if data_dir:
+        model_dir = os.path.dirname(os.path.abspath(config_file))
+        model_name = os.path.basename(model_dir)
+        dataset_name = os.path.basename(os.path.dirname(model_dir))
+        cfg.OUTPUT_DIR = os.path.join(data_dir, dataset_name, model_name, os.path.basename(config_file)[:-5],
+                                      "random_seed_" + str(random_seed))
+        if is_testing and not os.path.isdir(cfg.OUTPUT_DIR):
+            raise NotADirectoryError("Checkpoint directory {} does not exist.".format(cfg.OUTPUT_DIR))
     cfg.SEED = random_seed
     return cfg

@@ -238,7 +238,10 @@ __global__ void __launch_bounds__(1024) k1_mc_merge_score(const K1Params P) {
                 int base = 0;
                 if (mylane == 0) base = atomicAdd(&P.cand_count[l], total);
                 base = __shfl(base, 0, 64);
-                if (pass) P.cand_keys[(int64_t)lv.anchor_base + base + __popcll(m & ((1ull << mylane) - 1ull))] = make_key(best, hw * P.A + a);
+                const int at = base + __popcll(m & ((1ull << mylane) - 1ull));
+                // (at < level size always holds when cand_count was zero on entry; the bound keeps a stale counter from
+                //  writing into the next level's slots)
+                if (pass && at < HW * P.A) P.cand_keys[(int64_t)lv.anchor_base + at] = make_key(best, hw * P.A + a);
             }
         }
     }
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
             int pos = 0;
             if (lane == 0) pos = atomicAdd(&P.cand_count[l], parked);
             pos = __shfl(pos, 0, 64);
-            if (lane < parked) P.cand_keys[(int64_t)lv.anchor_base + pos + lane] = park[lane];   // same wave wrote park[]
+            if (lane < parked && (int64_t)pos + lane < HW * A) P.cand_keys[(int64_t)lv.anchor_base + pos + lane] = park[lane];   // same wave wrote park[]
         }
     }
 }

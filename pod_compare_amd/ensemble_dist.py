@@ -10,7 +10,10 @@ tensors (17 MB per member at BASELINE size) meet on a merge rank before K1:
     SURVEY 5/8e); the merge rank's own member (if any) is a local copy;
   * `MemberLayout.views` exposes that buffer as per-level `(M, A*C, H, W)` tensors whose run stride is the packed
     size -- exactly what K1 streams (`PodLevel.run_stride_*`), so there is no re-layout after the exchange;
-  * the merge rank rotates with the image index so consecutive images pipeline across GPUs.
+  * the merge rank rotates with the image index so consecutive images pipeline across GPUs;
+  * `MemberPipeline` keeps two images in flight: image i's rows travel (on the collective library's own stream) while the
+    member ranks already run the conv net on image i+1, and the merge rank only runs K1..K7 of image i after it has
+    enqueued its own forward of image i+1 (`exchange_members` is the one-image-at-a-time form of the same exchange).
 
 The exchange logic is backend-agnostic ("nccl" on GPUs, "gloo" in the CPU tests).
 """
@@ -91,3 +94,80 @@ def exchange_members(packed: Optional[torch.Tensor], stacked: Optional[torch.Ten
         reqs.append(dist.isend(packed, dst=dst))
     for r in reqs:
         r.wait()
+
+
+class MemberPipeline:
+    """Double-buffered, software-pipelined form of `exchange_members` (replaces the sequential member loop PI:495-505).
+
+    Every rank calls `post(i, member_outputs)` for every image i, in image order ("round" i):
+      member rank s != dst(i): packs its head tensors into send slot i % depth and posts one `isend` to dst(i);
+      dst(i): posts one `irecv` per other member into row s of `stacked[i % depth]` (its own member row is a local copy);
+      other ranks: nothing.
+    A round's operations are issued as ONE group (`batch_isend_irecv`: one fused RCCL kernel on the library's stream, so
+    sends and receives of a round cannot block each other) and all ranks issue rounds in the same order, which makes the
+    schedule deadlock-free.  Nothing here waits on the host with RCCL: `wait()` only orders streams.  `collect(i)` on
+    dst(i) returns the `(M, packed)` buffer of image i once its rows have landed; call it after the NEXT image's forward
+    has been enqueued (see `run`), then the transfer of image i overlaps that forward.  A slot is reused `depth` rounds
+    later, after the work that last touched it has been waited for."""
+
+    def __init__(self, layout: MemberLayout, n_members: int, rank: int, world: int, device, depth: int = 2):
+        assert depth >= 2 and world >= 1 and n_members >= 1
+        self.layout, self.M, self.rank, self.world, self.depth = layout, int(n_members), int(rank), int(world), int(depth)
+        self.device = torch.device(device)
+        self.packed = [torch.empty(layout.total, dtype=torch.float32, device=self.device) for _ in range(depth)] if rank < n_members else None
+        self.stacked: List[Optional[torch.Tensor]] = [None] * depth        # allocated on first use as a merge rank
+        self._send: List[list] = [[] for _ in range(depth)]
+        self._recv = {}
+
+    def post(self, image_index: int, member_outputs: Optional[HeadOutputs]) -> None:
+        dst, slot = merge_rank(image_index, self.world), image_index % self.depth
+        ops = []
+        if self.rank < self.M:
+            for w in self._send[slot]:
+                w.wait()                                   # the send that last used this slot (image_index - depth)
+            self._send[slot] = []
+            self.layout.pack(member_outputs, out=self.packed[slot])
+        if self.rank == dst:
+            if self.stacked[slot] is None:
+                self.stacked[slot] = torch.empty((self.M, self.layout.total), dtype=torch.float32, device=self.device)
+            for s in range(self.M):
+                if s == self.rank:
+                    self.stacked[slot][s].copy_(self.packed[slot])
+                else:
+                    ops.append(dist.P2POp(dist.irecv, self.stacked[slot][s], s))
+        elif self.rank < self.M:
+            ops.append(dist.P2POp(dist.isend, self.packed[slot], dst))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if self.rank == dst:
+            self._recv[image_index] = works
+        elif self.rank < self.M:
+            self._send[slot] = works
+
+    def collect(self, image_index: int) -> torch.Tensor:
+        """(M, packed) buffer of image `image_index` on its merge rank (valid until round image_index + depth is posted)."""
+        for w in self._recv.pop(image_index):
+            w.wait()
+        return self.stacked[image_index % self.depth]
+
+    def drain(self) -> None:
+        for works in self._send:
+            for w in works:
+                w.wait()
+        self._send = [[] for _ in range(self.depth)]
+
+    def run(self, num_images: int, forward, merge) -> None:
+        """The pipelined loop: `forward(i)` -> this rank's member HeadOutputs of image i (member ranks only; called for
+        every image), `merge(i, stacked)` -> K1..K7 of image i on its merge rank.  Image i is merged after image i+1's
+        forward has been enqueued, so its rows travel underneath that forward."""
+        pending = None
+        for i in range(num_images):
+            ho = forward(i) if self.rank < self.M else None
+            self.post(i, ho)
+            if pending is not None:
+                merge(pending, self.collect(pending))
+                pending = None
+            if merge_rank(i, self.world) == self.rank:
+                pending = i
+        if pending is not None:
+            merge(pending, self.collect(pending))
+        self.drain()

@@ -139,3 +139,33 @@ def eval_gt_preprocess(gt_instances, device="cpu"):
         boxes[image_id] = b.to(torch.float32).to(device)
         cats[image_id] = torch.tensor([[g["category_id"]] for g in gs], dtype=torch.float32, device=device)
     return {"gt_boxes": boxes, "gt_cat_idxs": cats}
+
+
+def planted_ground_truth(planted_boxes: torch.Tensor, planted_classes: torch.Tensor, image_size, out_size):
+    """Planted boxes (network-input pixels, synthetic.planted_head_outputs) as ground truth at the output resolution:
+    scaled like the detections (IU:394-403) and clipped to the frame; category ids are class + 1 (BDD ids 1..7)."""
+    sx, sy = out_size[1] / image_size[1], out_size[0] / image_size[0]
+    b = planted_boxes.to(torch.float32) * torch.tensor([sx, sy, sx, sy], dtype=torch.float32, device=planted_boxes.device)
+    b[:, 0::2] = b[:, 0::2].clamp(0.0, float(out_size[1]))
+    b[:, 1::2] = b[:, 1::2].clamp(0.0, float(out_size[0]))
+    return b, (planted_classes.to(torch.float32) + 1.0).reshape(-1, 1)
+
+
+def score_against_planted(detections, heads, image_size, out_size, iou_min: float = 0.1, iou_correct: float = 0.7, device="cuda") -> Dict:
+    """End-to-end "NLL parity" number of the metric: detections of the path (`DeviceDetections`, one per image) matched to
+    the planted ground truth of their inputs (EU:191-367, the offline evaluation's defaults iou_min 0.1 / iou_correct 0.7),
+    then SR:68-74 on the true positives.  Returns {"nll", "mse", true_positives, duplicates, false_positives,
+    false_negatives}."""
+    pb, pp, pc, gb, gc = {}, {}, {}, {}, {}
+    for i, (det, h) in enumerate(zip(detections, heads)):
+        m = det.count()
+        pb[i], pp[i], pc[i] = det.boxes[:m], det.probs[:m], det.cov[:m]
+        gb[i], gc[i] = planted_ground_truth(h.planted_boxes, h.planted_classes, image_size, out_size)
+    res = match_predictions_to_groundtruth(pb, pp, pc, gb, gc, iou_min, iou_correct, device=device)
+    tp = res["true_positives"]
+    valid = torch.ones(tp["predicted_box_means"].shape[0], dtype=torch.bool, device=tp["predicted_box_means"].device)
+    reg = compute_reg_scores(tp, valid)
+    return {"nll": reg["ignorance_score_mean"], "mse": reg["mean_squared_error"],
+            "true_positives": int(tp["predicted_box_means"].shape[0]), "duplicates": int(res["duplicates"]["predicted_box_means"].shape[0]),
+            "false_positives": int(res["false_positives"]["predicted_box_means"].shape[0]),
+            "false_negatives": int(res["false_negatives"]["gt_box_means"].shape[0])}

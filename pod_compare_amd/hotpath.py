@@ -171,6 +171,8 @@ class HotPath:
             setattr(ws, name, hip.ptr(t))
         ws.n_capacity = self.n_cap
         self.ws = ws
+        self._draws = 0          # native-RNG calls served so far (default Philox key stream, see _begin_draw)
+        self._dirty = False      # an enqueue failed half way: counters / bitmap may be non-zero, reset before the next image
 
     # ------------------------------------------------------------------------------------------
     def _make_cfg(self) -> hip.PodConfig:
@@ -184,6 +186,30 @@ class HotPath:
             c.box_weights[i] = p.box_weights[i]
         c.philox_seed = p.philox_seed
         return c
+
+    def _begin_draw(self, draw_id: Optional[int]) -> None:
+        """Philox key of the next image's in-kernel draws: (seed, draw id).  The reference draws FRESH normals on every
+        call (PI:291-294, PI:351-356); with a constant key every image -- and every member of a post-NMS ensemble --
+        would see the same eps at the same (level, anchor, class, sample).  draw_id=None takes the next value of this
+        workspace's own counter; pass an explicit id (e.g. the image id) for reproducible draws.  K1, K1b and K2b/K3 of
+        one image read the key from the same PodConfig, so they still re-derive identical draws."""
+        if draw_id is None:
+            draw_id = self._draws
+            self._draws += 1
+        seed = int(self.p.philox_seed)
+        lo = (seed ^ (seed >> 32)) & 0xFFFFFFFF
+        self.cfg.philox_seed = lo | ((int(draw_id) & 0xFFFFFFFF) << 32)
+
+    def _clean(self) -> None:
+        """Workspace invariants (cand_count / tickets / maybe_bits all zero between images) are restored by the kernels
+        themselves (K2 consumes the counters, K1b the bitmap).  If an enqueue raised half way they are re-established
+        here, before the next image appends at a stale count."""
+        if self._dirty:
+            hip.check(self.lib.pod_reset_counters(hip.ptr(self.counters), int(self.counters.numel()), hip.current_stream()),
+                      "pod_reset_counters")
+            if self.maybe_bits is not None:
+                self.maybe_bits.zero_()
+            self._dirty = False
 
     def _run_strided(self, name, l, t, c):
         """A level tensor (n_runs, A*c, H, W): every run a contiguous NCHW slab; the run stride is free (batched MC
@@ -220,8 +246,17 @@ class HotPath:
         return arr
 
     # ------------------------------------------------------------------------------------------
-    def candidates(self, cls, delta, cls_var=None, reg_var=None, eps_cls=None, write_merged: bool = True):
+    def candidates(self, cls, delta, cls_var=None, reg_var=None, eps_cls=None, write_merged: bool = True,
+                   draw_id: Optional[int] = None):
         """K1 + K2 + K2b: dense tensors -> level-concatenated candidate arrays (device-resident)."""
+        self._clean()
+        self._begin_draw(draw_id)
+        self._dirty = True
+        lv = self._candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged)
+        self._dirty = False
+        return lv
+
+    def _candidates(self, cls, delta, cls_var, reg_var, eps_cls, write_merged):
         lib, cfg, st = self.lib, self.cfg, hip.current_stream()
         lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
         self._lv_keepalive = (lv, eps_cls)
@@ -246,6 +281,30 @@ class HotPath:
                                             P(self.cand_anchor), P(self.cand_run_delta), P(self.n_total), st),
                   "pod_gather_candidates")
         return lv
+
+    # -- test support: the native-RNG draws of one draw id, in the reference's tensor layouts ----------------------
+    def dump_cls_normals(self, draw_id: int) -> List[torch.Tensor]:
+        """Per level, the (cls_samples, H*W*A, K) normals K1b / K2b use for `draw_id` (PI:291-294's rsample)."""
+        self._begin_draw(int(draw_id))
+        A, K, S = self.p.num_anchors, self.p.num_classes, self.p.cls_var_num_samples
+        lv = self._levels_t()
+        for l, (h, w) in enumerate(self.shapes):
+            lv[l].H, lv[l].W, lv[l].anchor_base = h, w, self.anchor_base[l]
+        out = []
+        for l, (h, w) in enumerate(self.shapes):
+            t = torch.empty((S, h * w * A, K), dtype=torch.float32, device=self.device)
+            hip.check(self.lib.pod_dump_cls_normals(self.cfg, lv, l, hip.ptr(t), hip.current_stream()), "pod_dump_cls_normals")
+            out.append(t)
+        return out
+
+    def dump_box_normals(self, draw_id: int, global_anchor_ids: torch.Tensor) -> torch.Tensor:
+        """(prop_samples, n, 4) normals K3 uses for `draw_id` at the given anchors (PI:351-356's rsample);
+        global id = anchor_base[level] + index inside the level."""
+        self._begin_draw(int(draw_id))
+        g = global_anchor_ids.to(self.device, torch.int32).contiguous()
+        t = torch.empty((self.p.prop_num_samples, int(g.numel()), 4), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.pod_dump_box_normals(self.cfg, hip.ptr(g), int(g.numel()), hip.ptr(t), hip.current_stream()), "pod_dump_box_normals")
+        return t
 
     def decode(self, lv, eps_prop: Optional[torch.Tensor] = None):
         """K3: candidate boxes + covariances."""
@@ -324,12 +383,15 @@ class HotPath:
                 "anchor_statistics": hip.POD_MODE_ANCHOR_STATISTICS}
 
     def run_image(self, mode: str, cls, delta, cls_var, reg_var, image_size, out_size,
-                  box_merge_mode: str = "bayesian_inference", cls_merge_mode: str = "max_score") -> DeviceDetections:
+                  box_merge_mode: str = "bayesian_inference", cls_merge_mode: str = "max_score",
+                  draw_id: Optional[int] = None) -> DeviceDetections:
         """pod_run_image: K1 .. K7 of one image enqueued by one C call (native Philox draws)."""
         if mode not in MODES:
             raise ValueError("Invalid inference mode {}.".format(mode))   # PI:100-103
         if mode == "bayes_od" and not self.has_covariance:
             raise hip.PodError("bayes_od needs box covariances (a reg_var head or MC runs)")
+        self._clean()
+        self._begin_draw(draw_id)
         lv = self._levels(cls, delta, cls_var, reg_var, None)
         self._lv_keepalive = (lv, None)
         out = self.new_detections(out_size)
@@ -337,26 +399,30 @@ class HotPath:
                               out.ptr("records"), out.ptr("n_det"))
         bm = {"bayesian_inference": 0, "covariance_intersection": 1}[box_merge_mode]
         cm = {"max_score": 0, "bayesian_inference": 1}[cls_merge_mode]
+        self._dirty = True       # a failure between K1 and K2 leaves counters / bitmap non-zero
         hip.check(self.lib.pod_run_image(self.cfg, lv, self.ws, self._MODE_ID[mode], bm, cm, int(image_size[0]), int(image_size[1]),
                                          int(out_size[0]), int(out_size[1]), d, hip.current_stream()), "pod_run_image")
+        self._dirty = False
         return out
 
     def run(self, mode: str, cls, delta, cls_var=None, reg_var=None, *, image_size, out_size,
             eps_fn: Optional[Callable] = None, box_merge_mode: str = "bayesian_inference",
-            cls_merge_mode: str = "max_score", write_merged: bool = True, one_call: bool = True) -> DeviceDetections:
+            cls_merge_mode: str = "max_score", write_merged: bool = True, one_call: bool = True,
+            draw_id: Optional[int] = None) -> DeviceDetections:
         """predictor(input_im) minus the conv net: dense head tensors -> detections.
 
         eps_fn=None  : native mode, in-kernel Philox4x32-10, fully asynchronous; with one_call the whole launch
           sequence is enqueued by ONE C call (pod_run_image) instead of one ctypes call per kernel.
         eps_fn=callable(shape)->CPU tensor : eps-replay parity mode; draws are requested in the
-          reference's order (one (S_cls, R_l, K) tensor per level, then one (1000, n, 4))."""
+          reference's order (one (S_cls, R_l, K) tensor per level, then one (1000, n, 4)).
+        draw_id (native mode): Philox key of this call's draws, see _begin_draw; None = fresh draws on every call."""
         if eps_fn is None and one_call and write_merged:
-            return self.run_image(mode, cls, delta, cls_var, reg_var, image_size, out_size, box_merge_mode, cls_merge_mode)
+            return self.run_image(mode, cls, delta, cls_var, reg_var, image_size, out_size, box_merge_mode, cls_merge_mode, draw_id)
         eps_cls = eps_prop = None
         if eps_fn is not None and self.has_cls_var:
             A, K = self.p.num_anchors, self.p.num_classes
             eps_cls = [eps_fn((self.p.cls_var_num_samples, h * w * A, K)).to(self.device).contiguous() for h, w in self.shapes]
-        lv = self.candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged)
+        lv = self.candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged, draw_id)
         if eps_fn is not None and self.cov_dims > 0:
             n = int(self.n_total.item())
             if n > 0:
@@ -387,16 +453,20 @@ class PostNmsEnsemble:
         self.keep, self.n_keep = i32(hip.POD_MAX_DETECTIONS), i32(1)
         self.scratch = torch.empty(hp.lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device=dev)
 
-    def run(self, members, *, image_size, out_size, eps_fn: Optional[Callable] = None) -> DeviceDetections:
-        """members: iterable of (cls, delta, cls_var, reg_var) per-level tensor lists with N = 1."""
+    def run(self, members, *, image_size, out_size, eps_fn: Optional[Callable] = None,
+            draw_id: Optional[int] = None) -> DeviceDetections:
+        """members: iterable of (cls, delta, cls_var, reg_var) per-level tensor lists with N = 1.
+        draw_id (native mode): member j draws with Philox key (seed, draw_id * n_members + j): independent normals per
+        member, as the reference's per-call sampling (PI:291-294, 351-356); None = the workspace's running counter."""
         hp, P, st = self.hp, hip.ptr, hip.current_stream()
         self.total.zero_()
-        for cls, delta, cls_var, reg_var in members:
+        for j, (cls, delta, cls_var, reg_var) in enumerate(members):
             eps_cls = eps_prop = None
             if eps_fn is not None and hp.has_cls_var:
                 A, K = hp.p.num_anchors, hp.p.num_classes
                 eps_cls = [eps_fn((hp.p.cls_var_num_samples, h * w * A, K)).to(hp.device).contiguous() for h, w in hp.shapes]
-            lv = hp.candidates(cls, delta, cls_var, reg_var, eps_cls)
+            lv = hp.candidates(cls, delta, cls_var, reg_var, eps_cls,
+                               draw_id=None if draw_id is None else int(draw_id) * self.n_members + j)
             if eps_fn is not None and hp.cov_dims > 0:
                 n = int(hp.n_total.item())
                 if n > 0:

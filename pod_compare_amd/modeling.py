@@ -307,7 +307,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         skip_unused_last_run: the reference's merge (PI:216-222) never reads run N-1 of box_cls,
         box_cls_var and box_reg_var (only box_delta's last run is used, by the epistemic covariance PI:325-331).
         With the flag set those three evaluations of the last run are not computed (their slab in the returned
-        tensors is left uninitialised): 3 of the 4N subnet evaluations, 7.5 % of the head at N = 10.  Only valid
+        tensors is zero): 3 of the 4N subnet evaluations, 7.5 % of the head at N = 10.  Only valid
         together with `merge_quirk=True` in the hot path."""
         dropout = mc_dropout and self.dropout_rate > 0.0
         n = num_runs
@@ -319,7 +319,8 @@ class ProbabilisticRetinaNetHead(nn.Module):
                 return t.contiguous()                             # transposed by the same copy
             out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             out[:m].copy_(t)
-            return out
+            out[m:].zero_()                                       # never hand out uninitialised memory (a consumer without
+            return out                                            # the quirk merge would read it); 1/n of one small tensor
 
         logits, deltas, logit_vars, delta_covs = [], [], [], []
         for f in features:
@@ -395,18 +396,24 @@ class ProbabilisticRetinaNet(nn.Module):
         return self._anchor_cache[padded_hw]
 
     @torch.no_grad()
-    def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False) -> HeadOutputs:
+    def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False,
+                mc_dropout: Optional[bool] = None) -> HeadOutputs:
         """Raw anchor-wise output (`return_anchorwise_output=True`, PR:352-361) in NCHW plane layout.
-        num_mc_dropout_runs > 1 batches that many dropout-perturbed head evaluations (PR:103-108)."""
+        num_mc_dropout_runs > 1 batches that many dropout-perturbed head evaluations (PR:103-108).
+        mc_dropout: dropout active in the head subnets -- the reference's `model.train()` (PI:53-56), which it sets
+        whenever MC_DROPOUT.ENABLE is true, also for a single run; default: active iff several runs are requested."""
         x = self.preprocess_image(image)
         feats = self.fpn(self.bottom_up(x))
         n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
-        cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=n > 1 and self.use_dropout,
+        if mc_dropout is None:
+            mc_dropout = n > 1
+        cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
                                                  skip_unused_last_run=skip_unused_last_run)
         padded = tuple(x.shape[-2:])
         shapes = [tuple(f.shape[-2:]) for f in feats]
+        skipped = skip_unused_last_run and n > 1 and bool(mc_dropout) and self.use_dropout
         return HeadOutputs(cls, delta, cls_var, reg_var, self.anchors_for(padded), shapes, self.num_anchors,
-                           self.num_classes, tuple(image.shape[-2:]))
+                           self.num_classes, tuple(image.shape[-2:]), last_run_valid=not skipped)
 
 
 def resize_test_image(image: torch.Tensor, min_size: int = 800, max_size: int = 1333) -> torch.Tensor:

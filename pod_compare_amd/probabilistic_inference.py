@@ -22,18 +22,24 @@ CPU fallback.  Differences from the reference, all documented in DESIGN.md:
   * post-NMS ensemble merges (PI:444-481, PI:506-534) run every member through the N = 1 path, then the HIP
     restatement of general_black_box_ensembles_post_processing (IU:165-289).
 """
+import os
 from abc import ABC, abstractmethod
 from typing import Callable, List, Optional
 
 import torch
 
-from . import hotpath, modeling
+from . import checkpoint, hotpath, modeling
 from .structures import Boxes, Instances
 from .synthetic import HeadOutputs
 
 
-def build_model(cfg) -> modeling.ProbabilisticRetinaNet:
-    """detectron2 `build_model(cfg)` for META_ARCHITECTURE == ProbabilisticRetinaNet (PR:25-65)."""
+def build_model(cfg, save_dir: Optional[str] = "", load_weights: bool = True) -> modeling.ProbabilisticRetinaNet:
+    """detectron2 `build_model(cfg)` for META_ARCHITECTURE == ProbabilisticRetinaNet (PR:25-65), followed by the
+    reference's `DetectionCheckpointer(model, save_dir).resume_or_load(cfg.MODEL.WEIGHTS, resume=True)` (PI:59-84):
+    `<save_dir>/last_checkpoint` wins over cfg.MODEL.WEIGHTS, an empty path keeps the random initialisation, a path
+    that cannot be read raises (checkpoint.CheckpointError) -- never a silent random-init run.  save_dir "" means
+    cfg.OUTPUT_DIR, None means "no directory" (only cfg.MODEL.WEIGHTS is considered).  FrozenBN is folded into the conv
+    weights AFTER loading."""
     pm = cfg.MODEL.PROBABILISTIC_MODELING
     model = modeling.ProbabilisticRetinaNet(
         num_classes=cfg.MODEL.RETINANET.NUM_CLASSES, dropout_rate=pm.DROPOUT_RATE, cls_var_loss=pm.CLS_VAR_LOSS.NAME,
@@ -42,11 +48,31 @@ def build_model(cfg) -> modeling.ProbabilisticRetinaNet:
         test_topk_candidates=cfg.MODEL.RETINANET.TOPK_CANDIDATES_TEST, test_nms_thresh=cfg.MODEL.RETINANET.NMS_THRESH_TEST,
         max_detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, min_size_test=cfg.INPUT.MIN_SIZE_TEST,
         max_size_test=cfg.INPUT.MAX_SIZE_TEST)
+    model.loaded_from = ""
+    if load_weights:
+        if save_dir == "":
+            save_dir = cfg.get("OUTPUT_DIR", None)
+        model.loaded_from = checkpoint.load_model_weights(model, save_dir, cfg.MODEL.get("WEIGHTS", ""))
     model = model.to(torch.device(cfg.MODEL.DEVICE)).eval()
-    # NB: call modeling.fold_frozen_bn(model) AFTER loading weights (inference-only algebraic folding of FrozenBN);
-    # for the random-init models used here the statistics are the identity, so it is applied right away.
-    modeling.fold_frozen_bn(model)
+    modeling.fold_frozen_bn(model)      # inference-only algebra: the same affine map, one biased conv per (conv, FrozenBN) pair
     return model
+
+
+def model_test_attributes(cfg):
+    """The model attributes the predictor reads (test_topk_candidates PI:300, test_score_thresh PI:304,
+    test_nms_thresh, max_detections_per_image PI:407, cls_var_num_samples PI:294) without building a model: what a
+    merge-only rank of the one-seed-per-GPU ensemble needs."""
+    from types import SimpleNamespace
+    return SimpleNamespace(test_topk_candidates=cfg.MODEL.RETINANET.TOPK_CANDIDATES_TEST,
+                           test_score_thresh=cfg.MODEL.RETINANET.SCORE_THRESH_TEST,
+                           test_nms_thresh=cfg.MODEL.RETINANET.NMS_THRESH_TEST,
+                           max_detections_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+                           cls_var_num_samples=cfg.MODEL.PROBABILISTIC_MODELING.CLS_VAR_LOSS.NUM_SAMPLES)
+
+
+def ensemble_member_dir(cfg, random_seed) -> str:
+    """PI:66-71: `<parent of OUTPUT_DIR>/random_seed_<s>`."""
+    return os.path.join(os.path.split(cfg.OUTPUT_DIR)[0], "random_seed_" + str(random_seed))
 
 
 def build_predictor(cfg, model=None, model_list=None):
@@ -62,19 +88,21 @@ class ProbabilisticPredictor(ABC):
 
     def __init__(self, cfg, model=None, model_list=None):
         self.cfg = cfg.clone()
-        self.model = model if model is not None else build_model(self.cfg)
-        self.model_list = list(model_list) if model_list is not None else []
         pi = self.cfg.PROBABILISTIC_INFERENCE
         self.inference_mode = pi.INFERENCE_MODE
+        # PI:58-84: in ensembles mode only the members are loaded, self.model stays as built
+        self.model = model if model is not None else build_model(self.cfg, load_weights=self.inference_mode != "ensembles")
+        self.model_list = list(model_list) if model_list is not None else []
         self.mc_dropout_enabled = pi.MC_DROPOUT.ENABLE
         self.num_mc_dropout_runs = pi.MC_DROPOUT.NUM_RUNS
         if self.inference_mode == "ensembles" and not self.model_list:
-            # PI:59-77 builds one model per RANDOM_SEED_NUMS entry and loads its checkpoint; without
-            # checkpoints the members are random-init models seeded with those numbers.
+            # PI:59-77: one model per RANDOM_SEED_NUMS entry, each loaded from its sibling `random_seed_<s>` directory.
+            # A member without any checkpoint (no last_checkpoint there, empty MODEL.WEIGHTS) is a random-init model
+            # seeded with its number (synthetic runs).
             state = torch.random.get_rng_state()
             for seed in pi.ENSEMBLES.RANDOM_SEED_NUMS:
                 torch.manual_seed(int(seed))
-                self.model_list.append(build_model(self.cfg))
+                self.model_list.append(build_model(self.cfg, save_dir=ensemble_member_dir(self.cfg, seed)))
             torch.random.set_rng_state(state)
 
     def __call__(self, input_im):
@@ -151,13 +179,25 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         if ensemble_inference:
             return stack_members(outputs_list)
         image = input_im[0]["image"]
+        own = isinstance(self.model, modeling.ProbabilisticRetinaNet)
         if self.mc_dropout_enabled and self.num_mc_dropout_runs > 1:
-            if isinstance(self.model, modeling.ProbabilisticRetinaNet):
+            if own:
                 # the quirky merge (PI:216-222) never reads the last run's cls / cls_var / reg_var: do not compute them
-                return self.model(image, num_mc_dropout_runs=self.num_mc_dropout_runs,
+                return self.model(image, num_mc_dropout_runs=self.num_mc_dropout_runs, mc_dropout=True,
                                   skip_unused_last_run=self.merge_quirk and not need_all_runs)
             return self.model(image, num_mc_dropout_runs=self.num_mc_dropout_runs)      # PI:203-206
+        if own:
+            # PI:53-56 puts the model in train() whenever MC_DROPOUT.ENABLE is set: a single pass (NUM_RUNS = 1) then
+            # still runs with dropout active
+            return self.model(image, mc_dropout=bool(self.mc_dropout_enabled))
         return self.model(image)                                                          # PI:273
+
+    @staticmethod
+    def _draw_id(input_im) -> Optional[int]:
+        """Philox key of the image's in-kernel draws: its image_id when it is an integer (reproducible per image,
+        independent across images), else the workspace's running counter."""
+        i = input_im[0].get("image_id", None)
+        return int(i) if isinstance(i, int) and not isinstance(i, bool) else None
 
     def _sizes(self, input_im, ho: HeadOutputs):
         image_size = tuple(input_im[0]["image"].shape[1:])                                 # IU:39-41, PI:604-606
@@ -169,8 +209,11 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         self.last_path = hp
         image_size, out = self._sizes(input_im, ho)
         bo = self.cfg.PROBABILISTIC_INFERENCE.BAYES_OD
+        if not ho.last_run_valid and not self.merge_quirk:
+            raise hotpath.hip.PodError("the last MC run's cls / cls_var / reg_var were not computed (skip_unused_last_run); "
+                                       "only the reference's quirky merge (PI:216-222) may consume these outputs")
         det = hp.run(mode, ho.cls, ho.delta, ho.cls_var, ho.reg_var, image_size=image_size, out_size=out, eps_fn=self.eps_fn,
-                     box_merge_mode=bo.BOX_MERGE_MODE, cls_merge_mode=bo.CLS_MERGE_MODE)
+                     box_merge_mode=bo.BOX_MERGE_MODE, cls_merge_mode=bo.CLS_MERGE_MODE, draw_id=self._draw_id(input_im))
         self.last_detections = det
         return det if self.return_device else detections_to_instances(det)
 
@@ -183,7 +226,7 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
             self._paths[key] = hotpath.PostNmsEnsemble(hp, len(members))
         image_size, out = self._sizes(input_im, members[0])
         det = self._paths[key].run([(m.cls, m.delta, m.cls_var, m.reg_var) for m in members], image_size=image_size, out_size=out,
-                                   eps_fn=self.eps_fn)
+                                   eps_fn=self.eps_fn, draw_id=self._draw_id(input_im))
         self.last_detections = det
         return det if self.return_device else detections_to_instances(det)
 
@@ -230,6 +273,8 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
 
 def run_slice(ho: HeadOutputs, run: int) -> HeadOutputs:
     """Run `run` of a batched HeadOutputs as an N = 1 HeadOutputs (views, no copy: runs are contiguous slabs)."""
+    if not ho.last_run_valid and run == ho.num_runs - 1:
+        raise hotpath.hip.PodError("run {} was skipped by skip_unused_last_run: request all runs from the model".format(run))
     sel = lambda lst: None if lst is None else [t[run:run + 1] for t in lst]
     return HeadOutputs(sel(ho.cls), sel(ho.delta), sel(ho.cls_var), sel(ho.reg_var), ho.anchors, ho.shapes, ho.num_anchors,
                        ho.num_classes, ho.image_size)

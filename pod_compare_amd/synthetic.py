@@ -40,6 +40,7 @@ class HeadOutputs:
     image_size: Tuple[int, int]
     planted_boxes: Optional[torch.Tensor] = None
     planted_classes: Optional[torch.Tensor] = None
+    last_run_valid: bool = True      # False: run N-1 of cls / cls_var / reg_var was not computed (modeling: skip_unused_last_run)
 
     @property
     def num_runs(self) -> int:
@@ -50,7 +51,7 @@ class HeadOutputs:
         return HeadOutputs(mv(self.cls), mv(self.delta), mv(self.cls_var), mv(self.reg_var), mv(self.anchors),
                            self.shapes, self.num_anchors, self.num_classes, self.image_size,
                            None if self.planted_boxes is None else self.planted_boxes.to(device),
-                           None if self.planted_classes is None else self.planted_classes.to(device))
+                           None if self.planted_classes is None else self.planted_classes.to(device), self.last_run_valid)
 
 
 def nchw_from_anchor_major(x: torch.Tensor, h: int, w: int, a: int) -> torch.Tensor:

@@ -74,7 +74,7 @@ def assert_close(a, b, what="", rtol=RTOL, atol=ATOL):
     if a.numel() == 0:
         return
     err = (a - b).abs()
-    bound = atol + rtol * b.abs()
+    bound = torch.clamp(rtol * b.abs(), min=atol)      # defaults: 1e-4 * max(1, |b|), the bar DESIGN.md and smoke() state
     bad = err > bound
     assert not bool(bad.any()), "{}: {} of {} elements off; worst |d|={:.3e} at ref={:.6g}".format(
         what, int(bad.sum()), a.numel(), float(err.max()), float(b.reshape(-1)[err.reshape(-1).argmax()]))

@@ -192,3 +192,60 @@ def test_ensemble_exchange_three_ranks_two_members(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_exchange_worker, args=(3, port, 2, str(tmp_path)), nprocs=3, join=True)
     assert [open(tmp_path / ("ok_%d" % r)).read() for r in range(3)] == ["1", "1", "1"]
+
+
+def _pipeline_worker(rank, world, port, n_members, num_images, tmp):
+    from pod_compare_amd import ensemble_dist, synthetic
+    from pod_compare_amd.probabilistic_inference import run_slice
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ho = synthetic.planted_head_outputs((96, 128), n_members, seed=9, num_boxes=4)      # run s plays member s
+    lay = ensemble_dist.MemberLayout.of(ho)
+    pipe = ensemble_dist.MemberPipeline(lay, n_members, rank, world, "cpu")
+    log, ok = [], True
+
+    def forward(i):
+        log.append(("forward", i))
+        m = run_slice(ho, rank)
+        add = lambda lst: [t + float(i) for t in lst]
+        return synthetic.HeadOutputs(add(m.cls), add(m.delta), add(m.cls_var), add(m.reg_var), m.anchors, m.shapes, m.num_anchors,
+                                     m.num_classes, m.image_size)
+
+    def merge(i, stacked):
+        nonlocal ok
+        log.append(("merge", i))
+        v = lay.views(stacked, ho)                      # the strided (members, A*C, H, W) views K1 streams
+        for name in ("cls", "delta", "cls_var", "reg_var"):
+            for a, b in zip(getattr(v, name), getattr(ho, name)):
+                ok = ok and a.stride(0) == lay.total and torch.equal(a, b + float(i))
+
+    pipe.run(num_images, forward, merge)
+    with open(os.path.join(tmp, "log_%d.json" % rank), "w") as f:
+        json.dump({"ok": ok, "log": log}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_members,num_images", [(3, 2, 7), (2, 2, 5)])
+def test_member_pipeline_keeps_two_images_in_flight(tmp_path, world, n_members, num_images):
+    """The pipelined config-5 exchange (PI:495-505 replaced): every merge sees exactly its image's member rows through the
+    strided views, every image is merged once on its rotating merge rank, and a member rank enqueues the forward of image
+    i+1 BEFORE it merges image i (so image i's rows travel underneath that forward)."""
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_pipeline_worker, args=(world, port, n_members, num_images, str(tmp_path)), nprocs=world, join=True)
+    merged = []
+    for r in range(world):
+        out = json.load(open(tmp_path / ("log_%d.json" % r)))
+        assert out["ok"]
+        log = [tuple(e) for e in out["log"]]
+        mine = [i for kind, i in log if kind == "merge"]
+        assert mine == [i for i in range(num_images) if i % world == r]
+        merged += mine
+        if r < n_members:
+            assert [i for kind, i in log if kind == "forward"] == list(range(num_images))
+            for i in mine:
+                if i + 1 < num_images:
+                    assert log.index(("forward", i + 1)) < log.index(("merge", i))
+        else:
+            assert all(kind == "merge" for kind, _ in log)
+    assert sorted(merged) == list(range(num_images))

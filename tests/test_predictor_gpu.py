@@ -104,6 +104,7 @@ def test_end_to_end_with_the_torch_model():
     Instances (random-init weights give few or no detections)."""
     cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml")
     cfg.PROBABILISTIC_INFERENCE.MC_DROPOUT.NUM_RUNS = 3
+    cfg.MODEL.WEIGHTS, cfg.OUTPUT_DIR = "", ""          # explicit random init (the yaml's ImageNet URL cannot be fetched)
     torch.manual_seed(0)
     pred = pinf.build_predictor(cfg)
     img = torch.randint(0, 256, (3, 180, 250), dtype=torch.uint8, device="cuda")
@@ -114,6 +115,87 @@ def test_end_to_end_with_the_torch_model():
     assert res.pred_cls_probs.shape == (m, 7) and res.pred_classes.dtype == torch.int64
     assert bool(torch.isfinite(res.pred_boxes.tensor).all())
     inference_utils.instances_to_json(res, 5, {i: i + 1 for i in range(7)})
+
+
+def _calibrated_checkpoint(tmp_path, seed):
+    """A detectron2-named checkpoint whose FrozenBN statistics are the actual activation statistics of one frame (what
+    training leaves behind): every BN output is ~N(0, 1), so -- unlike identity statistics on random-init convs, which let
+    activations explode through ResNet-50 -- the head sees bounded features and emits its prior (p ~ 0.01, PR:454-455)."""
+    from pod_compare_amd import checkpoint, modeling
+    torch.manual_seed(seed)
+    src = modeling.ProbabilisticRetinaNet(dropout_rate=0.2, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                          bbox_cov_loss="negative_log_likelihood").eval()
+
+    def calibrate(bn, inputs):
+        x = inputs[0]
+        bn.running_mean.copy_(x.mean(dim=(0, 2, 3)))
+        bn.running_var.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))
+
+    hooks = [m.register_forward_pre_hook(calibrate) for m in src.modules() if isinstance(m, modeling.FrozenBatchNorm2d)]
+    frame = torch.randint(0, 256, (3, 96, 160), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    src(frame)
+    for h in hooks:
+        h.remove()
+    out_dir = str(tmp_path / "BDD-Detection" / "retinanet" / "retinanet_R_50_FPN_1x_reg_cls_var_dropout" / "random_seed_0")
+    os.makedirs(out_dir)
+    torch.save({"model": checkpoint.to_detectron2_state_dict(src), "iteration": 89999}, os.path.join(out_dir, "model_final.pth"))
+    with open(os.path.join(out_dir, "last_checkpoint"), "w") as f:
+        f.write("model_final.pth")
+    return src, frame
+
+
+def test_loaded_checkpoint_gives_prior_scores_and_matches_the_cpu_model(tmp_path):
+    """PI:78-84 on the GPU: build_predictor(cfg) loads `<OUTPUT_DIR>/last_checkpoint` (detectron2 names), folds the
+    non-identity FrozenBN statistics, and the MIOpen forward of the loaded model equals the CPU forward of the source model
+    (unfolded conv -> BN) -- the numeric pin of row a1.  With sane statistics the scores are the head's prior, not 1.0."""
+    src, frame = _calibrated_checkpoint(tmp_path, 21)
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml", random_seed=0,
+                              data_dir=str(tmp_path), is_testing=True)
+    pred = pinf.build_predictor(cfg)
+    assert pred.model.loaded_from.endswith("random_seed_0/model_final.pth")
+    want = src(frame)                                             # CPU, eval (no dropout), unfolded
+    got = pred.model(frame.cuda())                                # GPU, folded, fused conv tails
+    for name in ("cls", "delta", "cls_var", "reg_var"):
+        for a, b in zip(getattr(want, name), getattr(got, name)):
+            scale = max(1.0, float(a.abs().max()))
+            assert float((a - b.cpu()).abs().max()) <= 2e-3 * scale, name      # different conv algorithms (MIOpen vs mkldnn), fp32
+    p = torch.sigmoid(torch.cat([t.reshape(-1) for t in got.cls]))
+    assert 0.002 < float(p.min()) and float(p.max()) < 0.05 and abs(float(p.median()) - 0.01) < 0.003
+    assert abs(float(torch.cat([t.reshape(-1) for t in got.cls_var]).median()) + 10.0) < 0.5          # PR:458-470 bias -10
+    res = pred([{"image": frame.cuda(), "height": 96, "width": 160, "image_id": 3}])                # MC dropout, N = 10
+    assert len(res) == 0                                          # every score is below 0.05: an empty, well-formed Instances
+    assert res.pred_boxes_covariance.shape == (0, 4, 4)
+
+
+def test_eval_mode_trunk_sharing_on_the_gpu():
+    """SURVEY f-4 on the GPU: without dropout the mean and variance branches of a subnet see the same trunk activation, so
+    the head evaluates each trunk once (PR:518-523 runs it twice); the outputs equal two separate evaluations."""
+    from pod_compare_amd import modeling
+    torch.manual_seed(5)
+    model = modeling.ProbabilisticRetinaNet(dropout_rate=0.0, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                            bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    modeling.fold_frozen_bn(model)
+    feats = [torch.randn(1, 256, h, w, device="cuda") for h, w in ((24, 32), (12, 16), (6, 8))]
+    calls = {"n": 0}
+    real = model.head._trunk
+
+    def counting(convs, feature, copies, dropout):
+        calls["n"] += 1
+        return real(convs, feature, copies, dropout)
+
+    model.head._trunk = counting
+    cls, delta, cls_var, reg_var = model.head(feats, 1, mc_dropout=False)
+    assert calls["n"] == 2 * len(feats)                           # one cls trunk + one box trunk per level, not four
+    model.head._trunk = real
+    for l, f in enumerate(feats):
+        tc, tb = f, f
+        for conv in model.head.cls_subnet:
+            tc = torch.relu(conv(tc))
+        for conv in model.head.bbox_subnet:
+            tb = torch.relu(conv(tb))
+        for got, want in ((cls[l], model.head.cls_score(tc)), (cls_var[l], model.head.cls_var(tc)),
+                          (delta[l], model.head.bbox_pred(tb)), (reg_var[l], model.head.bbox_cov(tb))):
+            assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
 def test_ensemble_members_in_packed_strided_buffer_match_reference():

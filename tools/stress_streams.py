@@ -19,7 +19,7 @@ for i in range(n):
     h = heads[i % 3]
     mode = ("bayes_od", "standard_nms", "anchor_statistics")[(i // 3) % 3]
     with torch.cuda.stream(streams[i % S]):
-        dets.append((i % 3, mode, hps[i % S].run(mode, h.cls, h.delta, h.cls_var, h.reg_var, image_size=(750, 1333), out_size=(720, 1280))))
+        dets.append((i % 3, mode, hps[i % S].run(mode, h.cls, h.delta, h.cls_var, h.reg_var, image_size=(750, 1333), out_size=(720, 1280), draw_id=i % 3)))
 torch.cuda.synchronize()
 first, bad = {}, 0
 for k, mode, d in dets:
