@@ -203,7 +203,7 @@ def test_native_mode_is_deterministic_and_close_to_replay():
     ho = g.head_outputs()
     hp = make_path(ho)
     hd = ho.to("cuda")
-    kw = dict(image_size=tuple(g.meta["image"]), out_size=tuple(g.meta["out"]), draw_id=3)      # same Philox key: same draws
+    kw = dict(image_size=tuple(g.meta["image"]), out_size=tuple(g.meta["out"]), draw_id=0)      # same Philox key: same draws
     d1 = hp.run("bayes_od", hd.cls, hd.delta, hd.cls_var, hd.reg_var, **kw)
     b1, c1, m1 = d1.boxes.clone(), d1.cov.clone(), d1.count()
     d2 = hp.run("bayes_od", hd.cls, hd.delta, hd.cls_var, hd.reg_var, **kw)

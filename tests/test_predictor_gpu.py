@@ -175,6 +175,8 @@ def test_eval_mode_trunk_sharing_on_the_gpu():
     model = modeling.ProbabilisticRetinaNet(dropout_rate=0.0, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
                                             bbox_cov_loss="negative_log_likelihood").cuda().eval()
     modeling.fold_frozen_bn(model)
+    for q in model.parameters():
+        q.requires_grad_(False)
     feats = [torch.randn(1, 256, h, w, device="cuda") for h, w in ((24, 32), (12, 16), (6, 8))]
     calls = {"n": 0}
     real = model.head._trunk
