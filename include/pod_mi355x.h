@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 2
+#define POD_ABI_VERSION 3
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -120,8 +120,10 @@ int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
  * mean_s sigmoid(logit + eps_s*sigma) (PI:289-295) for those only, appending the keys of the anchors
  * above the threshold to `cand_keys` / `cand_count` exactly as K1 does otherwise. */
 int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels);
+/* probs_dense : dev float (R_total, K) in level-concatenated anchor order, or NULL: the K class probabilities of every anchor
+ *               emitted here are stored at its row, so that the gather kernel does not evaluate them a second time. */
 int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
-                    uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream);
+                    uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, float* probs_dense, pod_stream_t stream);
 
 /* Zeroes `n` int32 device words on the stream (graph-capturable memset node). */
 int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
@@ -133,11 +135,15 @@ int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
  * A bigger level: 16 workgroups select the top-k of one slice each (MSB radix select + sort), the
  * last one to finish selects the final top-k from their survivors (no spinning).
  * sel_keys : dev uint64[n_levels * topk];  sel_count : dev int32[n_levels] (written).
- * cand_keys and cand_count are CONSUMED: big levels are compacted in place, every counter is left at
- * ZERO, ready for the next image's pod_mc_merge_score (no pod_reset_counters between images).
- * cand_count : dev int32[2 * n_levels]: the counts, then n_levels ticket words (zero on entry, left zero). */
+ * cat_keys / cat_level / n_total (all three or none): the same selection level-concatenated -- row offset_l + i of cat_keys
+ *   = sel_keys[l][i], cat_level its level, n_total = number of rows -- dev uint64 / int32 [n_levels * topk] / int32.  This is
+ *   what the gather kernels read: one workgroup per row finds its key, its level and the row count with three independent loads.
+ * cand_keys is CONSUMED (big levels are compacted in place); cand_count is only READ here -- pod_gather_candidates /
+ * pod_gather_decode consume it (leave it ZERO, ready for the next image's pod_mc_merge_score; no pod_reset_counters between
+ * images).  cand_count : dev int32[2 * n_levels]: the counts, then n_levels ticket words (zero on entry, left zero). */
 int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, uint64_t* cand_keys,
-                   int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream);
+                   int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count,
+                   uint64_t* cat_keys, int32_t* cat_level, int32_t* n_total, pod_stream_t stream);
 
 /* ---- K2b gather_candidates -----------------------------------------------------------------
  * Replaces: the index gathers PI:305-338 and the level concatenation PI:341-342, 387-388.
@@ -145,13 +151,16 @@ int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, uint64_t* cand_
  * score, class, K probabilities (recomputed bit-identically to K1), merged delta, merged
  * reg_var (D values), its anchor box and every run's raw delta (for the epistemic term).
  * anchors : dev (R_total, 4) level-concatenated XYXY anchors (PR:101).
- * n_total : dev int32 (written) = number of candidates n. */
+ * cat_keys / cat_level / n_total : pod_level_topk's level-concatenated selection (read).
+ * cand_count : the counters pod_mc_merge_score / pod_score_maybe appended with; ZEROED here (consumed).
+ * probs_dense : the array pod_score_maybe filled (native draws + variance head), or NULL = evaluate the probabilities here. */
 int pod_gather_candidates(const PodConfig* cfg, const PodLevel* levels, const float* anchors,
-                          const uint64_t* sel_keys, const int32_t* sel_count,
+                          const uint64_t* cat_keys, const int32_t* cat_level, const int32_t* n_total,
+                          int32_t* cand_count, const float* probs_dense,
                           int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score, int32_t* cand_class,
                           float* cand_probs, float* cand_delta, float* cand_reg_var, float* cand_anchor,
                           float* cand_run_delta /* (n, n_runs, 4) or NULL when n_runs == 1 */,
-                          int32_t* n_total, pod_stream_t stream);
+                          pod_stream_t stream);
 
 /* ---- K3  decode_cov ------------------------------------------------------------------------
  * Replaces: covariance_output_to_cholesky MU:4-22, the 1000-sample propagation PI:344-368
@@ -169,12 +178,14 @@ int pod_decode_cov(const PodConfig* cfg, const PodLevel* levels, const int32_t* 
 
 /* ---- K2b + K3 in one launch (in-kernel draws only) ------------------------------------------------
  * pod_gather_candidates followed by pod_decode_cov, same arguments, same outputs (the candidate arrays are still written
- * for the later kernels), bit-identical results: the wavefront that gathered a candidate decodes it, handing the merged
- * deltas / log-variances over in registers and the per-run deltas in LDS.  n_capacity = n_levels * topk. */
-int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float* anchors, const uint64_t* sel_keys,
-                      const int32_t* sel_count, int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score,
+ * for the later kernels), bit-identical results: one 256-thread workgroup per candidate -- wavefront 0 gathers, all four draw
+ * and decode the 1000 samples into LDS, wavefront 0 forms the moments in the reference's summation order; merged deltas /
+ * log-variances / per-run deltas never leave LDS.  n_capacity = n_levels * topk. */
+int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float* anchors, const uint64_t* cat_keys,
+                      const int32_t* cat_level, const int32_t* n_total, int32_t* cand_count, const float* probs_dense,
+                      int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score,
                       int32_t* cand_class, float* cand_probs, float* cand_delta, float* cand_reg_var, float* cand_anchor,
-                      float* cand_run_delta, int32_t* n_total, float* boxes, float* cov, pod_stream_t stream);
+                      float* cand_run_delta, float* boxes, float* cov, pod_stream_t stream);
 
 /* ---- K4  nms_cluster -----------------------------------------------------------------------
  * Replaces: detectron2 batched_nms -> torchvision coordinate-trick NMS (call sites PI:554-560,
@@ -182,8 +193,10 @@ int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float*
  * iff IoU > nms_thresh, first `max_detections` survivors.
  * classes : dev int32[n] in [0, cfg->num_classes) (other ids are honoured, on a slower single-workgroup route).
  * keep : dev int32[max_detections] candidate indices in keep order;  n_keep : dev int32 (written).
- * scratch : dev, 16-byte aligned, pod_nms_scratch_bytes(n_capacity) bytes, no initialisation needed
- *           (per-class survivor lists between the two launches).  boxes must be 16-byte aligned. */
+ * scratch : dev, 16-byte aligned, pod_nms_scratch_bytes(n_capacity) bytes, ZEROED ONCE after allocation and then owned
+ *           by this entry point (per-class survivor lists between the two launches; a call-generation word and the
+ *           survivor scores the class sweeps publish to each other so that a class stops as soon as max_detections
+ *           higher-scoring survivors exist overall).  boxes must be 16-byte aligned. */
 size_t pod_nms_scratch_bytes(int32_t n_capacity);
 int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capacity,
                     const float* boxes, const float* scores, const int32_t* classes,
@@ -248,6 +261,27 @@ int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_row
                  float* det_boxes, float* det_cov, float* det_scores, int32_t* det_classes, float* det_probs,
                  float* records, int32_t* n_det, pod_stream_t stream);
 
+/* ---- K5 + K7 / K6 + K7 in one launch -------------------------------------------------------------
+ * pod_bayes_fuse / pod_anchor_stats_merge followed by pod_finalize(keep = NULL) on their outputs, same results bit for
+ * bit, without the dependent launch: every cluster workgroup writes its merged row to the staging arrays m_*
+ * (max_detections rows each, caller-owned scratch), publishes it (device-scope release) and takes a ticket; the workgroup
+ * that draws the last ticket runs the K7 body over all rows with device-scope loads.  Nothing spins.
+ * ticket : dev int32, ZERO on entry (pod_reset_counters once after allocation), left zero. */
+typedef struct PodDetections {     /* pod_finalize's outputs */
+    float* boxes;  float* cov;  float* scores;  int32_t* classes;  float* probs;  float* records;  int32_t* n_det;
+} PodDetections;
+int pod_bayes_fuse_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
+                            const float* boxes, const float* cov, const float* scores, const int32_t* classes,
+                            const float* probs, int32_t box_mode, int32_t cls_mode,
+                            float* m_boxes, float* m_cov, float* m_scores, int32_t* m_classes, float* m_probs,
+                            int32_t* ticket, float scale_x, float scale_y, float out_h, float out_w,
+                            const PodDetections* out, pod_stream_t stream);
+int pod_anchor_stats_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
+                              const float* boxes, const float* cov, const int32_t* classes, const float* probs,
+                              float* m_boxes, float* m_cov, float* m_scores, int32_t* m_classes, float* m_probs,
+                              int32_t* ticket, float scale_x, float scale_y, float out_h, float out_w,
+                              const PodDetections* out, pod_stream_t stream);
+
 /* ---- conv-net side: fused ReLU + dropout -------------------------------------------------------
  * Replaces: the `nn.ReLU(), nn.Dropout(p)` pair after every 3x3 conv of the head subnets (PR:403-424) in
  * MC-dropout mode (PR:103-108), in place, one pass.  x: dev fp32, 16-byte aligned, n elements.
@@ -311,7 +345,7 @@ int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids,
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
  * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence
  *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_decode (= pod_gather_candidates + pod_decode_cov)
- *   -> pod_nms_cluster -> {pod_bayes_fuse | pod_anchor_stats_merge | -} -> pod_finalize
+ *   -> pod_nms_cluster -> {pod_bayes_fuse_finalize | pod_anchor_stats_finalize | pod_finalize}
  * enqueued from C on `stream`, in-kernel Philox draws (levels[].eps_cls must be NULL: the eps-replay parity
  * mode needs the host between launches and uses the individual entry points).  Nothing here
  * synchronises or allocates; the workspace is caller-owned, every pointer is device memory sized as the
@@ -322,18 +356,17 @@ typedef struct PodWorkspace {
     float* mean_cls;  float* mean_cls_var;  float* mean_delta;  float* mean_reg_var;
     uint64_t* cand_keys;  int32_t* cand_count;  uint64_t* maybe_bits;
     uint64_t* sel_keys;   int32_t* sel_count;
+    uint64_t* cat_keys;   int32_t* cat_level;          /* level-concatenated selection, n_capacity rows each */
+    float* probs_dense;                                /* (R, K) or NULL when the model has no variance head */
     int32_t* n_total;     int32_t* cand_anchor_idx;  int32_t* cand_level;  int32_t* cand_class;
     float* cand_score;    float* cand_probs;  float* cand_delta;  float* cand_reg_var;  float* cand_anchor;
     float* cand_run_delta;
     float* boxes;  float* cov;
     int32_t* keep;  int32_t* n_keep;  void* nms_scratch;
     float* m_boxes;  float* m_cov;  float* m_scores;  int32_t* m_classes;  float* m_probs;
+    int32_t* cluster_ticket;       /* int32, zero on entry, left zero (pod_bayes_fuse_finalize / pod_anchor_stats_finalize) */
     int32_t n_capacity;  int32_t reserved;
 } PodWorkspace;
-
-typedef struct PodDetections {     /* pod_finalize's outputs */
-    float* boxes;  float* cov;  float* scores;  int32_t* classes;  float* probs;  float* records;  int32_t* n_det;
-} PodDetections;
 
 #define POD_MODE_STANDARD_NMS 0    /* also the pre-NMS MC-dropout / ensemble modes (PI:402-442, PI:483-505) */
 #define POD_MODE_BAYES_OD 1

@@ -351,6 +351,7 @@ struct K1bParams {
     uint64_t* maybe_bits;
     uint64_t* cand_keys;
     int32_t* cand_count;
+    float* probs_dense;      // (R, K), level-concatenated anchor order: the K probabilities of every anchor emitted here, or null
 };
 
 template <int KP>
@@ -401,6 +402,8 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
             float best = p;
 #pragma unroll
             for (int o = KP >> 1; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+            if (P.probs_dense && valid && k < K && best > P.score_thresh)      // the gather kernel reuses them (same function, same inputs)
+                P.probs_dense[((int64_t)lv.anchor_base + (int64_t)hw * A + a) * K + k] = p;
             const bool emit = valid && k == 0 && best > P.score_thresh;
             const unsigned long long em = __ballot(emit);
             if (emit) park[parked + __popcll(em & ((1ull << lane) - 1ull))] = make_key(best, hw * A + a);
@@ -520,7 +523,8 @@ extern "C" int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels)
 }
 
 extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
-                               uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, pod_stream_t stream) {
+                               uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, float* probs_dense,
+                               pod_stream_t stream) {
     if (!cfg || !levels || !maybe_bits || !cand_keys || !cand_count) return POD_E_INVALID;
     const int L = cfg->n_levels, K = cfg->num_classes;
     if (L < 1 || L > POD_MAX_LEVELS || K < 1 || K > POD_MAX_CLASSES || !cfg->has_cls_var) return POD_E_INVALID;
@@ -538,7 +542,7 @@ extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, con
     P.word_begin[L] = wb;
     P.n_levels = L; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = K; P.cls_samples = cfg->cls_samples;
     P.score_thresh = cfg->score_thresh; P.seed = cfg->philox_seed; P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var;
-    P.maybe_bits = maybe_bits; P.cand_keys = cand_keys; P.cand_count = cand_count;
+    P.maybe_bits = maybe_bits; P.cand_keys = cand_keys; P.cand_count = cand_count; P.probs_dense = probs_dense;
     const int blocks = (wb + 3) / 4 < 1024 ? (wb + 3) / 4 : 1024;   // one wavefront per bitmap word up to a persistent 4096
     const dim3 grid(blocks), block(256);
     if (K <= 8) hipLaunchKernelGGL(pod::k1b_score_maybe<8>, grid, block, 0, (hipStream_t)stream, P);

@@ -68,6 +68,9 @@ struct K2Params {
     int32_t n_levels;
     uint64_t* sel_keys;
     int32_t* sel_count;
+    uint64_t* cat_keys;       // level-concatenated selection: row offset_l + i = sel_keys[l][i]   (may be null)
+    int32_t* cat_level;       // level of every row of cat_keys                                     (may be null)
+    int32_t* n_total;         // sum over levels of min(count, topk)                                (may be null)
 };
 
 constexpr int TOPK_SLICES = 16;   // workgroups per level; only a level with more than SORT_CAP candidates uses more than one
@@ -79,6 +82,37 @@ struct TopkLds {
     uint32_t wtot[4];
     int32_t remaining, fill, bucket, ticket, pick, pick_rem;
 };
+
+// Where level l's rows start in the level-concatenated candidate list, and the list's length: the counts of ALL levels are
+// final when this kernel starts (K1 / K1b are done) and nobody changes them before the gather kernel consumes them.
+__device__ __forceinline__ int level_offset(const K2Params& P, int l, int& total) {
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < POD_MAX_LEVELS; ++i) {
+        const int ci = i < P.n_levels ? min(P.cand_count[i], P.topk) : 0;
+        if (i < l) off += ci;
+        total += ci;
+    }
+    return off;
+}
+
+__device__ __forceinline__ void write_selection(const K2Params& P, const TopkLds& S, int l, int k, uint64_t* out) {
+    int total;
+    const int off = P.cat_keys ? level_offset(P, l, total) : 0;
+    for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
+        const uint64_t key = S.keys[i];
+        out[i] = key;
+        if (P.cat_keys) {
+            P.cat_keys[off + i] = key;
+            P.cat_level[off + i] = l;
+        }
+    }
+    if (threadIdx.x == 0) {
+        P.sel_count[l] = k;
+        if (P.cat_keys && l == 0 && P.n_total) *P.n_total = total;
+    }
+}
 
 // The `want` largest of the `count` keys fetch(0..count-1) (all distinct, or 0 = absent), sorted descending in S.keys[0..want).
 // count <= SORT_CAP: straight into the LDS bitonic network.  Otherwise an MSB radix select (LDS histograms, from the top byte
@@ -217,17 +251,13 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     const int tid = threadIdx.x;
     uint64_t* keys = P.cand_keys + P.anchor_base[l];
     int32_t* ticket = P.cand_count + P.n_levels + l;
-    const int C = P.cand_count[l];           // stays put until the last workgroup of the level resets it
+    const int C = P.cand_count[l];           // stays put: the gather kernel (K2b / K23) consumes (re-zeroes) the counts
     const int k = min(P.topk, C);
     uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
     if (C <= SORT_CAP) {
         if (b != 0) return;
         topk_into_lds<true>(S, [=](int i) { return keys[i]; }, C, k);
-        for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
-        if (tid == 0) {
-            P.sel_count[l] = k;
-            P.cand_count[l] = 0;   // consumed: the next image's K1 appends from zero (no reset launch per image)
-        }
+        write_selection(P, S, l, k, out);
         return;
     }
     const int slice = ((C + TOPK_SLICES - 1) / TOPK_SLICES + 7) & ~7;      // keys per slice
@@ -255,12 +285,8 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
         return r < min(SORT_CAP, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     };
     topk_into_lds<true>(S, survivors, TOPK_SLICES * SORT_CAP, k);
-    for (int i = tid; i < k; i += TOPK_THREADS) out[i] = S.keys[i];
-    if (tid == 0) {
-        P.sel_count[l] = k;
-        P.cand_count[l] = 0;
-        *ticket = 0;
-    }
+    write_selection(P, S, l, k, out);
+    if (tid == 0) *ticket = 0;
 }
 
 __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
@@ -271,25 +297,28 @@ __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
 }  // namespace pod
 
 extern "C" int pod_level_topk(const PodConfig* cfg, const PodLevel* levels, uint64_t* cand_keys,
-                              int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, pod_stream_t stream) {
+                              int32_t* cand_count, uint64_t* sel_keys, int32_t* sel_count, uint64_t* cat_keys,
+                              int32_t* cat_level, int32_t* n_total, pod_stream_t stream) {
     if (!cfg || !levels || !cand_keys || !cand_count || !sel_keys || !sel_count) return POD_E_INVALID;
+    if ((cat_keys != nullptr) != (cat_level != nullptr) || (cat_keys && !n_total)) return POD_E_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS || cfg->topk < 1 || cfg->topk > POD_MAX_TOPK) return POD_E_INVALID;
     pod::K2Params P;
     for (int l = 0; l < cfg->n_levels; ++l) P.anchor_base[l] = levels[l].anchor_base;
     P.topk = cfg->topk; P.cand_keys = cand_keys; P.cand_count = cand_count; P.n_levels = cfg->n_levels; P.sel_keys = sel_keys;
-    P.sel_count = sel_count;
+    P.sel_count = sel_count; P.cat_keys = cat_keys; P.cat_level = cat_level; P.n_total = n_total;
     hipLaunchKernelGGL(pod::k2_level_topk, dim3(cfg->n_levels * pod::TOPK_SLICES), dim3(pod::TOPK_THREADS), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
 
 extern "C" int pod_gather_candidates(const PodConfig* cfg, const PodLevel* levels, const float* anchors,
-                                     const uint64_t* sel_keys, const int32_t* sel_count, int32_t* cand_anchor_idx,
+                                     const uint64_t* cat_keys, const int32_t* cat_level, const int32_t* n_total,
+                                     int32_t* cand_count, const float* probs_dense, int32_t* cand_anchor_idx,
                                      int32_t* cand_level, float* cand_score, int32_t* cand_class, float* cand_probs,
                                      float* cand_delta, float* cand_reg_var, float* cand_anchor, float* cand_run_delta,
-                                     int32_t* n_total, pod_stream_t stream) {
-    if (!cfg || !levels || !anchors || !sel_keys || !sel_count || !cand_anchor_idx || !cand_level || !cand_score ||
-        !cand_class || !cand_probs || !cand_delta || !cand_anchor || !n_total)
+                                     pod_stream_t stream) {
+    if (!cfg || !levels || !anchors || !cat_keys || !cat_level || !n_total || !cand_count || !cand_anchor_idx || !cand_level ||
+        !cand_score || !cand_class || !cand_probs || !cand_delta || !cand_anchor)
         return POD_E_INVALID;
     if (cfg->cov_dims > 0 && !cand_reg_var) return POD_E_INVALID;
     if (cfg->n_levels * cfg->topk > POD_MAX_CANDIDATES * 4) return POD_E_INVALID;
@@ -298,10 +327,11 @@ extern "C" int pod_gather_candidates(const PodConfig* cfg, const PodLevel* level
     for (int l = 0; l < cfg->n_levels; ++l) P.lv[l] = levels[l];
     P.n_levels = cfg->n_levels; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = cfg->num_classes; P.D = cfg->cov_dims;
     P.has_cls_var = cfg->has_cls_var; P.quirk = cfg->merge_quirk; P.cls_samples = cfg->cls_samples; P.topk = cfg->topk;
-    P.seed = cfg->philox_seed; P.anchors = anchors; P.sel_keys = sel_keys; P.sel_count = sel_count;
+    P.seed = cfg->philox_seed; P.anchors = anchors; P.cat_keys = cat_keys; P.cat_level = cat_level; P.n_total = n_total;
+    P.cand_count = cand_count; P.probs_dense = probs_dense;
     P.cand_anchor_idx = cand_anchor_idx; P.cand_level = cand_level; P.cand_score = cand_score; P.cand_class = cand_class;
     P.cand_probs = cand_probs; P.cand_delta = cand_delta; P.cand_reg_var = cand_reg_var; P.cand_anchor = cand_anchor;
-    P.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr; P.n_total = n_total;
+    P.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr;
     const int slots = cfg->n_levels * cfg->topk;
     hipLaunchKernelGGL(pod::k2b_gather, dim3(slots), dim3(64), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();

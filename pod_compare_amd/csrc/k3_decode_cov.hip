@@ -19,9 +19,12 @@
 
 namespace pod {
 
-// One 64-thread workgroup (= one wavefront) per candidate: barriers are wave-local and free.
+constexpr int K3_MAX_SAMPLES = POD_MAX_PROP_SAMPLES;
+
+// One 64-thread workgroup (= one wavefront) per candidate (eps-replay parity mode and the call-by-call path).
 __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
-    __shared__ float part[64 * 10];   // [lane][component]
+    __shared__ float4 xs[K3_MAX_SAMPLES];   // decoded samples
+    __shared__ __attribute__((aligned(16))) float part[10 * 64];   // [component][lane]
     __shared__ float small[16 + 4 * POD_MAX_RUNS];
     const int lane = threadIdx.x;
     const int i = blockIdx.x;
@@ -29,43 +32,68 @@ __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
     const float4 d4 = *reinterpret_cast<const float4*>(P.cand_delta + (size_t)i * 4);
     const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
     const Box anc = load_box(P.cand_anchor, i);
-    float rv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t gid = 0;
     if (P.D > 0) {
+        float rv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < 10; ++c)
             if (c < P.D) rv[c] = P.cand_reg_var[(size_t)i * P.D + c];
-        gid = (uint32_t)(P.anchor_base[P.cand_level[i]] + P.cand_anchor_idx[i]);
+        const uint32_t gid = (uint32_t)(P.anchor_base[P.cand_level[i]] + P.cand_anchor_idx[i]);
+        generate_samples(P, i, lane, 64, dl, rv, anc, gid, xs);
+        wave_sync();
     }
-    decode_candidate(P, i, lane, dl, rv, anc, gid, P.n_runs > 1 ? P.cand_run_delta + (size_t)i * P.n_runs * 4 : nullptr, part, small);
+    decode_candidate(P, i, lane, dl, anc, P.n_runs > 1 ? P.cand_run_delta + (size_t)i * P.n_runs * 4 : nullptr, xs, part, small);
 }
 
-// K2b + K3 fused (native draws): the wavefront that gathered a candidate decodes it.  The merged deltas and
-// log-variances stay in registers (lane c of the gather owns channel c), the N runs' raw deltas go through LDS, so the
-// candidate arrays in HBM are written for the later kernels but never read back here: one launch and two dependent
-// global round trips less than K2b -> K3.
+// K2b + K3 fused (native draws): the workgroup that gathered a candidate decodes it.  256 threads per candidate: wavefront 0
+// gathers (lane = channel) and hands the merged deltas / log-variances / anchor to the others through LDS; all four
+// wavefronts draw and decode the 1000 samples (the bulk of the arithmetic: ~6 000 VALU instructions when one wavefront did
+// it alone, 14 of the kernel's 22 us); wavefront 0 then forms the moments in the reference's summation order.  The
+// candidate arrays in HBM are written for the later kernels but never read back here.
 struct K23Params {
     K2bParams g;
     K3Params d;
 };
 
-__global__ void __launch_bounds__(64) k23_gather_decode(const K23Params P) {
-    __shared__ float part[64 * 10];
+constexpr int K23_THREADS = 256;
+
+__global__ void __launch_bounds__(K23_THREADS) k23_gather_decode(const K23Params P) {
+    __shared__ float4 xs[K3_MAX_SAMPLES];
+    __shared__ __attribute__((aligned(16))) float part[10 * 64];
     __shared__ float small[16 + 4 * POD_MAX_RUNS];
     __shared__ float run_delta[4 * POD_MAX_RUNS];
-    const int lane = threadIdx.x;
-    GatheredCandidate c;
-    if (!gather_candidate(P.g, blockIdx.x, lane, run_delta, c)) return;   // wave-uniform
+    __shared__ float hand[4 + 10 + 4 + 2];    // merged deltas, reg_var entries, anchor, gid, live flag
+    const int tid = threadIdx.x, lane = tid & 63;
     const int K = P.g.K, D = P.g.D, nvar = P.g.has_cls_var ? K : 0;
-    float dl[4], rv[10];
+    GatheredCandidate c;
+    POD_STAMP(blockIdx.x, 0);
+    if (tid < 64) {
+        const bool live = gather_candidate(P.g, blockIdx.x, lane, run_delta, c);   // wave-uniform
+        if (lane == 0) hand[19] = live ? 1.0f : 0.0f;
+        if (live) {
+            if (lane >= K + nvar && lane < K + nvar + 4 + D) hand[lane - K - nvar] = c.merged;
+            if (lane == 0) {
+                const float4 a = c.anchor;
+                hand[14] = a.x; hand[15] = a.y; hand[16] = a.z; hand[17] = a.w;
+                hand[18] = __uint_as_float((uint32_t)(P.g.lv[c.level].anchor_base + c.r));
+            }
+        }
+    }
+    __syncthreads();
+    if (hand[19] == 0.0f) return;
+    POD_STAMP(blockIdx.x, 4);
+    const float dl[4] = {hand[0], hand[1], hand[2], hand[3]};
+    const Box anc{hand[14], hand[15], hand[16], hand[17]};
+    if (D > 0) {
+        float rv[10];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dl[j] = __shfl(c.merged, K + nvar + j, 64);
-#pragma unroll
-    for (int j = 0; j < 10; ++j) rv[j] = (j < D) ? __shfl(c.merged, K + nvar + 4 + (j < D ? j : 0), 64) : 0.0f;
-    const Box anc = load_box(P.g.anchors, P.g.lv[c.level].anchor_base + c.r);
-    const uint32_t gid = (uint32_t)(P.g.lv[c.level].anchor_base + c.r);
-    __syncthreads();   // run_delta (LDS) written by the delta lanes
-    decode_candidate(P.d, c.dst, lane, dl, rv, anc, gid, run_delta, part, small);
+        for (int j = 0; j < 10; ++j) rv[j] = j < D ? hand[4 + j] : 0.0f;
+        generate_samples(P.d, (int)blockIdx.x, tid, K23_THREADS, dl, rv, anc, __float_as_uint(hand[18]), xs);
+        __syncthreads();
+    }
+    POD_STAMP(blockIdx.x, 5);
+    if (tid >= 64) return;
+    decode_candidate(P.d, c.dst, lane, dl, anc, run_delta, xs, part, small);
+    POD_STAMP(blockIdx.x, 6);
 }
 
 }  // namespace pod
@@ -92,12 +120,13 @@ extern "C" int pod_decode_cov(const PodConfig* cfg, const PodLevel* levels, cons
     return POD_OK;
 }
 
-extern "C" int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float* anchors, const uint64_t* sel_keys,
-                                 const int32_t* sel_count, int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score,
+extern "C" int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, const float* anchors, const uint64_t* cat_keys,
+                                 const int32_t* cat_level, const int32_t* n_total, int32_t* cand_count, const float* probs_dense,
+                                 int32_t* cand_anchor_idx, int32_t* cand_level, float* cand_score,
                                  int32_t* cand_class, float* cand_probs, float* cand_delta, float* cand_reg_var, float* cand_anchor,
-                                 float* cand_run_delta, int32_t* n_total, float* boxes, float* cov, pod_stream_t stream) {
-    if (!cfg || !levels || !anchors || !sel_keys || !sel_count || !cand_anchor_idx || !cand_level || !cand_score || !cand_class ||
-        !cand_probs || !cand_delta || !cand_anchor || !n_total || !boxes || !cov)
+                                 float* cand_run_delta, float* boxes, float* cov, pod_stream_t stream) {
+    if (!cfg || !levels || !anchors || !cat_keys || !cat_level || !n_total || !cand_count || !cand_anchor_idx || !cand_level ||
+        !cand_score || !cand_class || !cand_probs || !cand_delta || !cand_anchor || !boxes || !cov)
         return POD_E_INVALID;
     if (cfg->cov_dims > 0 && !cand_reg_var) return POD_E_INVALID;
     if (cfg->cov_dims > 0 && (cfg->prop_samples < 2 || cfg->prop_samples > POD_MAX_PROP_SAMPLES)) return POD_E_INVALID;
@@ -111,10 +140,11 @@ extern "C" int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, c
     for (int l = 0; l < cfg->n_levels; ++l) G.lv[l] = levels[l];
     G.n_levels = cfg->n_levels; G.n_runs = cfg->n_runs; G.A = cfg->num_anchors; G.K = cfg->num_classes; G.D = cfg->cov_dims;
     G.has_cls_var = cfg->has_cls_var; G.quirk = cfg->merge_quirk; G.cls_samples = cfg->cls_samples; G.topk = cfg->topk;
-    G.seed = cfg->philox_seed; G.anchors = anchors; G.sel_keys = sel_keys; G.sel_count = sel_count;
+    G.seed = cfg->philox_seed; G.anchors = anchors; G.cat_keys = cat_keys; G.cat_level = cat_level; G.n_total = n_total;
+    G.cand_count = cand_count; G.probs_dense = probs_dense;
     G.cand_anchor_idx = cand_anchor_idx; G.cand_level = cand_level; G.cand_score = cand_score; G.cand_class = cand_class;
     G.cand_probs = cand_probs; G.cand_delta = cand_delta; G.cand_reg_var = cand_reg_var; G.cand_anchor = cand_anchor;
-    G.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr; G.n_total = n_total;
+    G.cand_run_delta = cfg->n_runs > 1 ? cand_run_delta : nullptr;
     pod::K3Params& Dp = P.d;
     for (int l = 0; l < cfg->n_levels; ++l) Dp.anchor_base[l] = levels[l].anchor_base;
     Dp.n_runs = cfg->n_runs; Dp.D = cfg->cov_dims; Dp.S = cfg->prop_samples; Dp.n_capacity = cfg->n_levels * cfg->topk; Dp.n_replay = 0;
@@ -122,7 +152,33 @@ extern "C" int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, c
     Dp.seed = cfg->philox_seed; Dp.n_total = n_total; Dp.cand_delta = cand_delta; Dp.cand_reg_var = cand_reg_var;
     Dp.cand_anchor = cand_anchor; Dp.cand_run_delta = cand_run_delta; Dp.cand_anchor_idx = cand_anchor_idx;
     Dp.cand_level = cand_level; Dp.eps_prop = nullptr; Dp.boxes = boxes; Dp.cov = cov;
-    hipLaunchKernelGGL(pod::k23_gather_decode, dim3(cfg->n_levels * cfg->topk), dim3(64), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(pod::k23_gather_decode, dim3(cfg->n_levels * cfg->topk), dim3(pod::K23_THREADS), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
+
+#ifdef POD_TRACE
+#include <stdio.h>
+extern "C" int pod_trace_dump(void) {   // diagnostics build only (not in include/pod_mi355x.h)
+    static long long host[4096 * 8];
+    if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pod_trace), sizeof(host)) != hipSuccess) return POD_E_LAUNCH;
+    long long t0 = 0;
+    int n = 0;
+    for (int i = 0; i < 4096; ++i)
+        if (host[i * 8 + 6]) {
+            if (!t0 || host[i * 8] < t0) t0 = host[i * 8];
+            ++n;
+        }
+    fprintf(stderr, "trace: %d live workgroups; 10 ns ticks from the earliest start: start | keys | merged | probs | handed | generated | end\n", n);
+    for (int i = 0; i < 4096; ++i)
+        if (host[i * 8 + 6] && (i < 6 || i % 50 == 0 || i >= n - 3)) {
+            fprintf(stderr, " wg %4d", i);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %5lld", host[i * 8 + k] - t0);
+            fprintf(stderr, "  | tail: blocksums | mean | pass2 | cov | epi:");
+            for (int k = 0; k < 5; ++k) fprintf(stderr, " %5lld", host[(i + 2048) * 8 + k] - t0);
+            fprintf(stderr, "\n");
+        }
+    return POD_OK;
+}
+#endif

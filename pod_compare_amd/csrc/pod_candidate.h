@@ -14,8 +14,11 @@ struct K2bParams {
     int32_t n_levels, n_runs, A, K, D, has_cls_var, quirk, cls_samples, topk;
     uint64_t seed;
     const float* anchors;
-    const uint64_t* sel_keys;
-    const int32_t* sel_count;
+    const uint64_t* cat_keys;      // level-concatenated selection written by K2 (row = candidate)
+    const int32_t* cat_level;
+    const int32_t* n_total;        // number of candidates (written by K2)
+    int32_t* cand_count;           // the per-level counters K1 / K1b appended with: consumed (zeroed) here
+    const float* probs_dense;      // (R, K) class probabilities K1b stored for the anchors it emitted, or null (recompute)
     int32_t* cand_anchor_idx;
     int32_t* cand_level;
     float* cand_score;
@@ -25,7 +28,6 @@ struct K2bParams {
     float* cand_reg_var;
     float* cand_anchor;
     float* cand_run_delta;
-    int32_t* n_total;
 };
 
 // Merged value of one element (plane-layout offset `e` inside a run) in the reference order; all N
@@ -34,13 +36,13 @@ template <class Sink>
 __device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int64_t e, int n_runs, int quirk, Sink sink) {
     float acc = 0.0f;
     float x0 = 0.0f;
-    for (int r0 = 0; r0 < n_runs; r0 += 8) {
-        float v[8];
+    for (int r0 = 0; r0 < n_runs; r0 += 16) {      // N = 10 (MC dropout) / 5 (ensembles): ONE round of independent loads
+        float v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 16; ++j)
             if (r0 + j < n_runs) v[j] = base[(int64_t)(r0 + j) * rs + e];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int run = r0 + j;
             if (run < n_runs) {
                 sink(run, v[j]);
@@ -57,6 +59,7 @@ __device__ __forceinline__ float merge_scalar(const float* base, int64_t rs, int
 }
 
 struct GatheredCandidate {
+    float4 anchor;       // its anchor box
     int dst, level, r;   // row in the level-concatenated candidate arrays; level; anchor index inside the level
     float merged;        // this lane's channel: [0,K) logits, [K,2K) log-variances, then 4 deltas, then D reg_var entries
 };
@@ -67,24 +70,16 @@ struct GatheredCandidate {
 // lanes then re-derive the class probabilities with K1's device function (bit-identical).
 // Returns false when there is no candidate row `dst`.  run_delta_lds (N*4 floats) also receives every run's raw delta.
 __device__ __forceinline__ bool gather_candidate(const K2bParams& P, int dst, int lane, float* run_delta_lds, GatheredCandidate& out) {
-    // workgroup `dst` = candidate row `dst` of the level-concatenated list: the live workgroups are the first n_total of the
-    // grid, so none of them waits behind the dispatch of thousands of empty ones (a (level, rank) grid put level 3's
-    // candidates at workgroup ids 3000+, ~6 us into the launch)
-    const int L = P.n_levels;
-    int l = -1, j = 0, begin = 0;
-#pragma unroll 1
-    for (int i = 0; i < L; ++i) {
-        const int cnt = P.sel_count[i];
-        if (l < 0 && dst < begin + cnt) {
-            l = i;
-            j = dst - begin;
-        }
-        begin += cnt;
-    }
-    if (dst == 0 && lane == 0) *P.n_total = begin;
-    if (l < 0) return false;
+    // workgroup `dst` = candidate row `dst` of the level-concatenated list K2 wrote (key + level per row): the count, the
+    // key and the level are three independent loads, one round trip (walking per-level counts and then fetching the key
+    // was two dependent ones, in a kernel whose gather phase is nothing but a chain of HBM round trips)
+    const int n = *P.n_total;
+    if (dst == 0 && lane < P.n_levels) P.cand_count[lane] = 0;   // consumed: the next image's K1 appends from zero
+    const uint64_t key = P.cat_keys[dst];      // dst < n_levels * topk = the arrays' capacity (= the grid size)
+    const int l = P.cat_level[dst];
+    if (dst >= n) return false;
+    POD_STAMP(dst, 1);
     const PodLevel& lv = P.lv[l];
-    const uint64_t key = P.sel_keys[(int64_t)l * P.topk + j];
     const int r = key_index(key);
     const int A = P.A, K = P.K, D = P.D, N = P.n_runs;
     const int hw = r / A;
@@ -93,8 +88,12 @@ __device__ __forceinline__ bool gather_candidate(const K2bParams& P, int dst, in
     const bool has_var = P.has_cls_var != 0;
     const int nvar = has_var ? K : 0;
     const int C = K + nvar + 4 + D;
+    // issued together with the run loads below (it used to trail them by a full round trip)
+    const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
     float merged = 0.0f;
-    if (lane < K) {
+    if (lane < K + nvar && P.probs_dense) {
+        // class channels: only needed to re-derive the probabilities, which K1b already stored for this anchor
+    } else if (lane < K) {
         merged = merge_scalar(lv.cls, lv.run_stride_cls, (int64_t)(a * K + lane) * HW + hw, N, P.quirk, [](int, float) {});
     } else if (lane < K + nvar) {
         merged = merge_scalar(lv.cls_var, lv.run_stride_cls, (int64_t)(a * K + lane - K) * HW + hw, N, P.quirk, [](int, float) {});
@@ -112,12 +111,17 @@ __device__ __forceinline__ bool gather_candidate(const K2bParams& P, int dst, in
         merged = merge_scalar(lv.reg_var, lv.run_stride_reg, (int64_t)(a * D + c) * HW + hw, N, P.quirk, [](int, float) {});
         P.cand_reg_var[(int64_t)dst * D + c] = merged;
     }
+    POD_STAMP(dst, 2);
     const float lvar = has_var ? __shfl(merged, (lane < K ? lane : 0) + K, 64) : 0.0f;
     float p = -1.0f;
     if (lane < K) {
-        p = class_prob_cell(merged, lvar, has_var, P.cls_samples, lv.eps_cls, HW * A, K, A, l, hw, a, lane, P.seed);
+        // K1b evaluated exactly this function on exactly these merged values when it emitted the anchor: reuse its result
+        // (bit-identical; saves 3 Philox calls + 10 sigmoids on the critical path of every candidate)
+        p = P.probs_dense ? P.probs_dense[((int64_t)lv.anchor_base + r) * K + lane]
+                          : class_prob_cell(merged, lvar, has_var, P.cls_samples, lv.eps_cls, HW * A, K, A, l, hw, a, lane, P.seed);
         P.cand_probs[(int64_t)dst * K + lane] = p;
     }
+    POD_STAMP(dst, 3);
     // max / first argmax over the K class lanes
     float best = __shfl(p, 0, 64);
     int best_k = 0;
@@ -133,9 +137,9 @@ __device__ __forceinline__ bool gather_candidate(const K2bParams& P, int dst, in
         P.cand_class[dst] = best_k;
         P.cand_anchor_idx[dst] = r;
         P.cand_level[dst] = l;
-        const float4 anc = *reinterpret_cast<const float4*>(P.anchors + ((int64_t)lv.anchor_base + r) * 4);
         *reinterpret_cast<float4*>(P.cand_anchor + (int64_t)dst * 4) = anc;
     }
+    out.anchor = anc;
     out.dst = dst;
     out.level = l;
     out.r = r;
@@ -162,29 +166,110 @@ struct K3Params {
 
 // torch cascade_sum combination of per-block sums (blocks of 16 rows): block sums accumulate into
 // acc1; every 16 blocks (256 rows) acc1 is flushed into acc2; the trailing partial block is acc0.
-// `part[b]` holds the sum of block b (b < nblk_full) and, if S % 16 != 0, part[nblk_full] the tail.
-__device__ __forceinline__ float cascade_combine(const float* part, int stride, int S) {
+// `col[b]` (64 consecutive, 16-byte aligned floats of LDS) holds the sum of block b (b < S / 16) and, if S % 16 != 0,
+// col[S / 16] the sum of the tail.  The whole column is fetched with 16 independent 16-byte LDS reads BEFORE the first
+// add: written as a loop of scalar reads the compiler paired every add with its own LDS round trip (64 x ~100 cycles,
+// 2.5-2.8 us per call, two calls per candidate -- measured with in-kernel time stamps, tools/exp_trace.py).
+__device__ __forceinline__ float cascade_combine(const float* col, int S) {
+    constexpr int MAXB = POD_MAX_PROP_SAMPLES / 16;     // 64 blocks
     const int nfull = S >> 4;
-    float acc1 = 0.0f, acc2 = 0.0f;
-    for (int b = 0; b < nfull; ++b) {
-        acc1 = acc1 + part[b * stride];
-        if (((b + 1) & 15) == 0) {
-            acc2 = acc2 + acc1;
-            acc1 = 0.0f;
+    float4 q[MAXB / 4];
+#pragma unroll
+    for (int i = 0; i < MAXB / 4; ++i) q[i] = reinterpret_cast<const float4*>(col)[i];
+    __builtin_amdgcn_sched_barrier(0);                   // all reads issued; the adds below wait once
+    float acc1 = 0.0f, acc2 = 0.0f, tail = 0.0f;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const float4 w = q[b >> 2];
+        const float v = (b & 3) == 0 ? w.x : ((b & 3) == 1 ? w.y : ((b & 3) == 2 ? w.z : w.w));
+        if (b < nfull) {
+            acc1 = acc1 + v;
+            if (((b + 1) & 15) == 0) {
+                acc2 = acc2 + acc1;
+                acc1 = 0.0f;
+            }
+        } else if (b == nfull) {
+            tail = v;
         }
     }
-    float acc0 = (S & 15) ? part[nfull * stride] : 0.0f;
+    float acc0 = (S & 15) ? tail : 0.0f;
     acc0 = acc0 + acc1;
     acc0 = acc0 + acc2;
     return acc0;
 }
 
-// Candidate `i` (one wavefront): dl = merged deltas, rv = merged reg_var entries (D of them), anc = its anchor,
-// gid = global anchor id (Philox counter), run_delta = the N runs' raw deltas (N x 4 floats, HBM or LDS).
-// part: 64*10 floats of LDS, small: 16 + 4*POD_MAX_RUNS floats of LDS.
-__device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int lane, const float (&dl)[4], const float (&rv)[10], const Box& anc,
-                                                 uint32_t gid, const float* run_delta, float* part, float* small) {
-    const bool active = true;
+// Draw + decode the S samples of one candidate (PI:351-356 rsample, IU:510-547 decode) into LDS, by `nthreads` threads
+// (thread u of them).  The expensive part of the candidate -- Philox, Box-Muller, exp -- is embarrassingly parallel over
+// samples, so the fused kernel spreads it over 4 wavefronts; the ORDER-sensitive part (torch's block sums) stays with
+// one wavefront, which reads the decoded samples back from LDS (decode_candidate).  Sample values do not depend on which
+// thread produced them, so any nthreads gives bit-identical results.
+//   native draws: one Philox call serves the two samples (2m, 2m+1); thread u takes calls m = u, u + nthreads, ...
+//   replayed draws: thread u takes samples s = u, u + nthreads, ...
+// xs: S float4 of LDS (decoded x1,y1,x2,y2 of sample s).  dl / rv / anc / gid as in decode_candidate.
+__device__ __forceinline__ void generate_samples(const K3Params& P, int i, int u, int nthreads, const float (&dl)[4], const float (&rv)[10],
+                                                 const Box& anc, uint32_t gid, float4* xs) {
+    const int S = P.S, D = P.D;
+    // ---- Cholesky factor (row-major lower triangle), MU:4-22 ------------------------------------------
+    float Lm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Lm[r][c] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Lm[c][c] = sqrtf(expf(rv[c]));
+    if (D == 10) {   // torch.tril_indices(4,4,-1): (1,0),(2,0),(2,1),(3,0),(3,1),(3,2)
+        Lm[1][0] = rv[4]; Lm[2][0] = rv[5]; Lm[2][1] = rv[6];
+        Lm[3][0] = rv[7]; Lm[3][1] = rv[8]; Lm[3][2] = rv[9];
+    }
+    auto one = [&](int s, const float (&e)[4]) {
+        float d[4];
+        if (D == 4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = dl[c] + Lm[c][c] * e[c];   // L eps exact for diagonal L
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = Lm[c][0] * e[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) acc = fmaf(Lm[c][k], e[k], acc);
+                d[c] = dl[c] + acc;
+            }
+        }
+        const Box b = decode_box(d[0], d[1], d[2], d[3], anc, P.wts);
+        xs[s] = float4{b.x1, b.y1, b.x2, b.y2};
+    };
+    if (P.eps_prop) {
+        for (int s = u; s < S; s += nthreads) {
+            const float4 e4 = *reinterpret_cast<const float4*>(P.eps_prop + ((size_t)s * P.n_replay + i) * 4);
+            const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+            one(s, e);
+        }
+    } else {
+        for (int m = u; 2 * m < S; m += nthreads) {
+            const f32x8n z = philox_normals8(P.seed, gid, (uint32_t)m, 0u, STREAM_BOX);
+            const float e0[4] = {z.v[0], z.v[1], z.v[2], z.v[3]};
+            one(2 * m, e0);
+            if (2 * m + 1 < S) {
+                const float e1[4] = {z.v[4], z.v[5], z.v[6], z.v[7]};
+                one(2 * m + 1, e1);
+            }
+        }
+    }
+}
+
+// Candidate `i`, ONE wavefront (lane = threadIdx & 63 of the calling wave): sample moments in torch's summation order +
+// epistemic covariance + stores.  xs: the decoded samples (generate_samples; D > 0 only), anc its anchor, dl its merged
+// deltas, run_delta = the N runs' raw deltas (N x 4 floats, HBM or LDS).
+// part: 10*64 floats of LDS (16-byte aligned), small: 16 + 4*POD_MAX_RUNS floats of LDS.  The caller has synchronised the producers of xs;
+// all LDS traffic below stays inside this wavefront (wave_sync).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int lane, const float (&dl)[4], const Box& anc,
+                                                 const float* run_delta, const float4* xs_lds, float* part, float* small) {
     const int S = P.S, D = P.D, N = P.n_runs;
     float mean[4] = {0, 0, 0, 0};
     float cv[10];
@@ -192,64 +277,28 @@ __device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int l
     for (int c = 0; c < 10; ++c) cv[c] = 0.0f;
 
     if (D > 0) {
-        // ---- Cholesky factor (row-major lower triangle) --------------------------------------------
-        float Lm[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Lm[r][c] = 0.0f;
-        if (active) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Lm[c][c] = sqrtf(expf(rv[c]));
-            if (D == 10) {   // torch.tril_indices(4,4,-1): (1,0),(2,0),(2,1),(3,0),(3,1),(3,2)
-                Lm[1][0] = rv[4]; Lm[2][0] = rv[5]; Lm[2][1] = rv[6];
-                Lm[3][0] = rv[7]; Lm[3][1] = rv[8]; Lm[3][2] = rv[9];
-            }
-        }
-        // ---- pass 1: draw, decode, block sums --------------------------------------------------------
+        // ---- pass 1: lane l owns samples [16l, 16l+16) = one 16-row block of torch's cascade sum ----------------
         float xs[16][4];
         float bs[4] = {0, 0, 0, 0};
-        f32x8n z;   // native mode: one Philox call serves the two samples (2m, 2m+1)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int s = lane * 16 + t;
-            float e[4] = {0, 0, 0, 0};
-            if (active && s < S) {
-                if (P.eps_prop) {
-                    const float4 e4 = *reinterpret_cast<const float4*>(P.eps_prop + ((size_t)s * P.n_replay + i) * 4);
-                    e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
-                } else {
-                    if ((t & 1) == 0) z = philox_normals8(P.seed, gid, (uint32_t)(s >> 1), 0u, STREAM_BOX);
-                    e[0] = z.v[(t & 1) * 4 + 0]; e[1] = z.v[(t & 1) * 4 + 1]; e[2] = z.v[(t & 1) * 4 + 2]; e[3] = z.v[(t & 1) * 4 + 3];
-                }
-            }
-            float d[4];
-            if (D == 4) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[c] = dl[c] + Lm[c][c] * e[c];   // L eps exact for diagonal L
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float acc = Lm[c][0] * e[0];
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) acc = fmaf(Lm[c][k], e[k], acc);
-                    d[c] = dl[c] + acc;
-                }
-            }
-            const Box b = decode_box(d[0], d[1], d[2], d[3], anc, P.wts);
             const bool live = s < S;
-            xs[t][0] = b.x1; xs[t][1] = b.y1; xs[t][2] = b.x2; xs[t][3] = b.y2;
+            const float4 v = live ? xs_lds[s] : float4{0.f, 0.f, 0.f, 0.f};
+            xs[t][0] = v.x; xs[t][1] = v.y; xs[t][2] = v.z; xs[t][3] = v.w;
 #pragma unroll
             for (int c = 0; c < 4; ++c) bs[c] = live ? bs[c] + xs[t][c] : bs[c];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) part[lane * 10 + c] = bs[c];
-        __syncthreads();
-        if (lane < 4) small[lane] = __fdiv_rn(cascade_combine(part + lane, 10, S), (float)S);
-        __syncthreads();
+        for (int c = 0; c < 4; ++c) part[c * 64 + lane] = bs[c];        // component-major: a column per component
+        wave_sync();
+        POD_STAMP(i + 2048, 0);
+        if (lane < 4) small[lane] = __fdiv_rn(cascade_combine(part + lane * 64, S), (float)S);
+        wave_sync();
+        POD_STAMP(i + 2048, 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) mean[c] = small[c];
-        __syncthreads();
+        wave_sync();
         // ---- pass 2: residual products, block sums, / (S-1) -------------------------------------------
         float ps[10];
 #pragma unroll
@@ -267,14 +316,16 @@ __device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int l
                 for (int b = a; b < 4; ++b, ++q) ps[q] = live ? ps[q] + r[a] * r[b] : ps[q];
         }
 #pragma unroll
-        for (int c = 0; c < 10; ++c) part[lane * 10 + c] = ps[c];
-        __syncthreads();
-        if (lane < 10) small[lane] = __fdiv_rn(cascade_combine(part + lane, 10, S), (float)(S - 1));
-        __syncthreads();
+        for (int c = 0; c < 10; ++c) part[c * 64 + lane] = ps[c];
+        wave_sync();
+        POD_STAMP(i + 2048, 2);
+        if (lane < 10) small[lane] = __fdiv_rn(cascade_combine(part + lane * 64, S), (float)(S - 1));
+        wave_sync();
+        POD_STAMP(i + 2048, 3);
 #pragma unroll
         for (int c = 0; c < 10; ++c) cv[c] = small[c];
-        __syncthreads();
-    } else if (active) {
+        wave_sync();
+    } else {
         const Box b = decode_box(dl[0], dl[1], dl[2], dl[3], anc, P.wts);   // PI:384
         mean[0] = b.x1; mean[1] = b.y1; mean[2] = b.x2; mean[3] = b.y2;
     }
@@ -282,28 +333,28 @@ __device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int l
     // ---- epistemic covariance over the N runs (PI:323-331): lanes = runs ---------------------------------
     if (N > 1) {
         float e[4] = {0, 0, 0, 0};
-        if (active && lane < N) {
+        if (lane < N) {
             const float4 rd = *reinterpret_cast<const float4*>(run_delta + (size_t)lane * 4);
             const Box b = decode_box(rd.x, rd.y, rd.z, rd.w, anc, P.wts);
             e[0] = b.x1; e[1] = b.y1; e[2] = b.x2; e[3] = b.y2;
 #pragma unroll
             for (int c = 0; c < 4; ++c) small[16 + lane * 4 + c] = e[c];
         }
-        __syncthreads();
+        wave_sync();
         if (lane < 4) {
             float acc = 0.0f;
             for (int r = 0; r < N; ++r) acc = acc + small[16 + r * 4 + lane];
             small[lane] = __fdiv_rn(acc, (float)N);
         }
-        __syncthreads();
+        wave_sync();
         float em[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) em[c] = small[c];
-        __syncthreads();
+        wave_sync();
         if (lane < N)
 #pragma unroll
             for (int c = 0; c < 4; ++c) small[16 + lane * 4 + c] = e[c] - em[c];
-        __syncthreads();
+        wave_sync();
         if (lane < 10) {
             int a = 0, b = lane;   // unpack q -> (a,b), a <= b
             if (lane >= 4) { a = 1; b = lane - 3; }
@@ -313,12 +364,13 @@ __device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int l
             for (int r = 0; r < N; ++r) acc = acc + small[16 + r * 4 + a] * small[16 + r * 4 + b];
             small[lane] = __fdiv_rn(acc, (float)(N - 1));
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int c = 0; c < 10; ++c) cv[c] = cv[c] + small[c];   // PI:374 cov += epistemic
     }
 
-    if (active && lane == 0) {
+    POD_STAMP(i + 2048, 4);
+    if (lane == 0) {
         *reinterpret_cast<float4*>(P.boxes + (size_t)i * 4) = float4{mean[0], mean[1], mean[2], mean[3]};
         float* o = P.cov + (size_t)i * 16;
         int q = 0;

@@ -17,6 +17,18 @@
         if (hipGetLastError() != hipSuccess) return POD_E_LAUNCH; \
     } while (0)
 
+// -DPOD_TRACE (python -m pod_compare_amd.build with POD_TRACE=1; diagnostics only, never the shipped library): phase
+// time stamps of the first workgroups of a kernel, constant 100 MHz clock, dumped by pod_trace_dump() of the same file.
+#ifdef POD_TRACE
+static __device__ long long g_pod_trace[4096 * 8];
+#define POD_STAMP(wg, k)                                                                         \
+    do {                                                                                         \
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < 64 && (wg) < 4096) g_pod_trace[(wg) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define POD_STAMP(wg, k)
+#endif
+
 namespace pod {
 
 // ---------------------------------------------------------------------------------------------
@@ -147,10 +159,12 @@ __device__ __forceinline__ Box decode_box(float d0, float d1, float d2, float d3
     const float h = a.y2 - a.y1;
     const float cx = a.x1 + 0.5f * w;
     const float cy = a.y1 + 0.5f * h;
-    const float dx = __fdiv_rn(d0, wts[0]);
-    const float dy = __fdiv_rn(d1, wts[1]);
-    float dw = __fdiv_rn(d2, wts[2]);
-    float dh = __fdiv_rn(d3, wts[3]);
+    // x / 1.0f == x exactly: with the reference's weights (1,1,1,1) (PI:175-176) the four IEEE divides are skipped
+    const bool unit = wts[0] == 1.0f && wts[1] == 1.0f && wts[2] == 1.0f && wts[3] == 1.0f;
+    const float dx = unit ? d0 : __fdiv_rn(d0, wts[0]);
+    const float dy = unit ? d1 : __fdiv_rn(d1, wts[1]);
+    float dw = unit ? d2 : __fdiv_rn(d2, wts[2]);
+    float dh = unit ? d3 : __fdiv_rn(d3, wts[3]);
     dw = fminf(dw, POD_SCALE_CLAMP);
     dh = fminf(dh, POD_SCALE_CLAMP);
     const float pcx = dx * w + cx;

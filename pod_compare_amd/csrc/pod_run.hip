@@ -31,36 +31,37 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     const bool prune = cfg->has_cls_var != 0;           // native draws + variance head: K1 flags, K1b samples
     const bool has_cov = cfg->cov_dims > 0 || merged;   // PI:381: otherwise the reference carries no covariance
     if (prune && !ws->maybe_bits) return POD_E_INVALID;
+    if (!ws->cat_keys || !ws->cat_level || !ws->n_total) return POD_E_INVALID;
+    if (mode != POD_MODE_STANDARD_NMS && !ws->cluster_ticket) return POD_E_INVALID;
     if (mode == POD_MODE_BAYES_OD && !has_cov) return POD_E_INVALID;
 
     POD_TRY(pod_mc_merge_score(cfg, levels, merged ? ws->mean_cls : nullptr, merged ? ws->mean_cls_var : nullptr,
                                merged ? ws->mean_delta : nullptr, merged ? ws->mean_reg_var : nullptr, ws->cand_keys,
                                ws->cand_count, prune ? ws->maybe_bits : nullptr, stream));
     if (prune)
-        POD_TRY(pod_score_maybe(cfg, levels, ws->mean_cls, ws->mean_cls_var, ws->maybe_bits, ws->cand_keys, ws->cand_count, stream));
-    POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, stream));
-    POD_TRY(pod_gather_decode(cfg, levels, ws->anchors, ws->sel_keys, ws->sel_count, ws->cand_anchor_idx, ws->cand_level,
+        POD_TRY(pod_score_maybe(cfg, levels, ws->mean_cls, ws->mean_cls_var, ws->maybe_bits, ws->cand_keys, ws->cand_count,
+                                ws->probs_dense, stream));
+    POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, ws->cat_keys, ws->cat_level,
+                           ws->n_total, stream));
+    POD_TRY(pod_gather_decode(cfg, levels, ws->anchors, ws->cat_keys, ws->cat_level, ws->n_total, ws->cand_count,
+                              prune ? ws->probs_dense : nullptr, ws->cand_anchor_idx, ws->cand_level,
                               ws->cand_score, ws->cand_class, ws->cand_probs, ws->cand_delta,
-                              cfg->cov_dims > 0 ? ws->cand_reg_var : nullptr, ws->cand_anchor, ws->cand_run_delta, ws->n_total,
+                              cfg->cov_dims > 0 ? ws->cand_reg_var : nullptr, ws->cand_anchor, ws->cand_run_delta,
                               ws->boxes, ws->cov, stream));
     POD_TRY(pod_nms_cluster(cfg, ws->n_total, ws->n_capacity, ws->boxes, ws->cand_score, ws->cand_class, ws->keep, ws->n_keep,
                             ws->nms_scratch, stream));
     const float* cov_in = has_cov ? ws->cov : nullptr;
     // IU:394-396: scale factors are Python floats (doubles) rounded once to fp32
     const float sx = (float)((double)out_w / (double)image_w), sy = (float)((double)out_h / (double)image_h);
-    if (mode == POD_MODE_BAYES_OD) {
-        POD_TRY(pod_bayes_fuse(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, ws->cov, ws->cand_score, ws->cand_class,
-                               ws->cand_probs, box_merge_mode, cls_merge_mode, ws->m_boxes, ws->m_cov, ws->m_scores,
-                               ws->m_classes, ws->m_probs, stream));
-    } else if (mode == POD_MODE_ANCHOR_STATISTICS) {
-        POD_TRY(pod_anchor_stats_merge(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_class, ws->cand_probs,
-                                       ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, stream));
-    }
-    if (mode == POD_MODE_STANDARD_NMS)
-        return pod_finalize(cfg, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_score, ws->cand_class, ws->cand_probs, sx, sy,
-                            (float)out_h, (float)out_w, out->boxes, out->cov, out->scores, out->classes, out->probs,
-                            out->records, out->n_det, stream);
-    return pod_finalize(cfg, nullptr, ws->n_keep, ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, sx, sy,
-                        (float)out_h, (float)out_w, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records,
-                        out->n_det, stream);
+    const float oh = (float)out_h, ow = (float)out_w;
+    if (mode == POD_MODE_BAYES_OD)       // K5 + K7 in one launch: the cluster workgroup that finishes last finalizes
+        return pod_bayes_fuse_finalize(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, ws->cov, ws->cand_score, ws->cand_class,
+                                       ws->cand_probs, box_merge_mode, cls_merge_mode, ws->m_boxes, ws->m_cov, ws->m_scores,
+                                       ws->m_classes, ws->m_probs, ws->cluster_ticket, sx, sy, oh, ow, out, stream);
+    if (mode == POD_MODE_ANCHOR_STATISTICS)
+        return pod_anchor_stats_finalize(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_class, ws->cand_probs,
+                                         ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, ws->cluster_ticket,
+                                         sx, sy, oh, ow, out, stream);
+    return pod_finalize(cfg, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_score, ws->cand_class, ws->cand_probs, sx, sy,
+                        oh, ow, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records, out->n_det, stream);
 }

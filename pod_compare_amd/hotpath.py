@@ -132,13 +132,19 @@ class HotPath:
         self.mean_delta = f32(self.R * 4) if merged and dense_box_merge else None
         self.mean_reg_var = f32(self.R * D) if merged and D > 0 and dense_box_merge else None
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
-        self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count, [L:2L] K2's tickets
+        # [0:L] cand_count, [L:2L] K2's tickets, [2*MAX_LEVELS] the cluster kernels' ticket; all zero between images
+        self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS + 4, dtype=torch.int32, device=dev)
         self.cand_count = self.counters[: self.L]
+        self.cluster_ticket = self.counters[2 * hip.POD_MAX_LEVELS: 2 * hip.POD_MAX_LEVELS + 1]
         n_words = sum(A * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words()
         self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None
         # K2 outputs
         self.sel_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)
         self.sel_count = i32(self.L)
+        self.cat_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)   # level-concatenated selection
+        self.cat_level = i32(self.L * params.topk_candidates)
+        # class probabilities of the anchors K1b emits, reused by the gather kernel (native draws + variance head)
+        self.probs_dense = f32(self.R * K) if has_cls_var else None
         n = self.n_cap
         self.n_total = i32(1)
         self.cand_anchor_idx, self.cand_level, self.cand_class = i32(n), i32(n), i32(n)
@@ -150,7 +156,7 @@ class HotPath:
         self.boxes, self.cov = f32(n, 4), f32(n, 4, 4)
         # K4
         self.keep, self.n_keep = i32(hip.POD_MAX_DETECTIONS), i32(1)
-        self.nms_scratch = torch.empty(self.lib.pod_nms_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        self.nms_scratch = torch.zeros(self.lib.pod_nms_scratch_bytes(n), dtype=torch.uint8, device=dev)     # zeroed once (generation word)
         # K5/K6 outputs
         md = hip.POD_MAX_DETECTIONS
         self.m_boxes, self.m_cov, self.m_scores = f32(md, 4), f32(md, 4, 4), f32(md)
@@ -161,13 +167,14 @@ class HotPath:
         for name, t in (("anchors", self.anchors), ("mean_cls", self.mean_cls), ("mean_cls_var", self.mean_cls_var),
                         ("mean_delta", self.mean_delta), ("mean_reg_var", self.mean_reg_var), ("cand_keys", self.cand_keys),
                         ("cand_count", self.cand_count), ("maybe_bits", self.maybe_bits), ("sel_keys", self.sel_keys),
-                        ("sel_count", self.sel_count), ("n_total", self.n_total), ("cand_anchor_idx", self.cand_anchor_idx),
+                        ("sel_count", self.sel_count), ("cat_keys", self.cat_keys), ("cat_level", self.cat_level),
+                        ("probs_dense", self.probs_dense), ("n_total", self.n_total), ("cand_anchor_idx", self.cand_anchor_idx),
                         ("cand_level", self.cand_level), ("cand_class", self.cand_class), ("cand_score", self.cand_score),
                         ("cand_probs", self.cand_probs), ("cand_delta", self.cand_delta), ("cand_reg_var", self.cand_reg_var),
                         ("cand_anchor", self.cand_anchor), ("cand_run_delta", self.cand_run_delta), ("boxes", self.boxes),
                         ("cov", self.cov), ("keep", self.keep), ("n_keep", self.n_keep), ("nms_scratch", self.nms_scratch),
                         ("m_boxes", self.m_boxes), ("m_cov", self.m_cov), ("m_scores", self.m_scores),
-                        ("m_classes", self.m_classes), ("m_probs", self.m_probs)):
+                        ("m_classes", self.m_classes), ("m_probs", self.m_probs), ("cluster_ticket", self.cluster_ticket)):
             setattr(ws, name, hip.ptr(t))
         ws.n_capacity = self.n_cap
         self.ws = ws
@@ -261,7 +268,7 @@ class HotPath:
         lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
         self._lv_keepalive = (lv, eps_cls)
         P = hip.ptr
-        # cand_count is zero here: allocated zeroed, and pod_level_topk consumes (re-zeroes) it every image
+        # cand_count is zero here: allocated zeroed, and the gather kernel consumes (re-zeroes) it every image
         # prune mode: native RNG with a variance head -> dense pass flags, K1b samples (see k1_mc_merge_score.hip)
         prune = self.has_cls_var and eps_cls is None
         wm = (write_merged or prune) and self.n_runs > 1
@@ -272,13 +279,14 @@ class HotPath:
                   "pod_mc_merge_score")
         if prune:
             hip.check(lib.pod_score_maybe(cfg, lv, P(self.mean_cls), P(self.mean_cls_var), P(self.maybe_bits),
-                                          P(self.cand_keys), P(self.cand_count), st), "pod_score_maybe")
-        hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.cand_count), P(self.sel_keys), P(self.sel_count), st),
-                  "pod_level_topk")
-        hip.check(lib.pod_gather_candidates(cfg, lv, P(self.anchors), P(self.sel_keys), P(self.sel_count),
+                                          P(self.cand_keys), P(self.cand_count), P(self.probs_dense), st), "pod_score_maybe")
+        hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.cand_count), P(self.sel_keys), P(self.sel_count),
+                                     P(self.cat_keys), P(self.cat_level), P(self.n_total), st), "pod_level_topk")
+        hip.check(lib.pod_gather_candidates(cfg, lv, P(self.anchors), P(self.cat_keys), P(self.cat_level), P(self.n_total),
+                                            P(self.cand_count), P(self.probs_dense) if prune else None,
                                             P(self.cand_anchor_idx), P(self.cand_level), P(self.cand_score), P(self.cand_class),
                                             P(self.cand_probs), P(self.cand_delta), P(self.cand_reg_var) if self.cov_dims else None,
-                                            P(self.cand_anchor), P(self.cand_run_delta), P(self.n_total), st),
+                                            P(self.cand_anchor), P(self.cand_run_delta), st),
                   "pod_gather_candidates")
         return lv
 
@@ -451,7 +459,7 @@ class PostNmsEnsemble:
         self.seeds, self.n_seeds = i32(cap), i32(1)
         self.c_boxes, self.c_cov, self.c_scores, self.c_classes, self.c_probs = f32(cap, 4), f32(cap, 4, 4), f32(cap), i32(cap), f32(cap, K)
         self.keep, self.n_keep = i32(hip.POD_MAX_DETECTIONS), i32(1)
-        self.scratch = torch.empty(hp.lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        self.scratch = torch.zeros(hp.lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device=dev)
 
     def run(self, members, *, image_size, out_size, eps_fn: Optional[Callable] = None,
             draw_id: Optional[int] = None) -> DeviceDetections:

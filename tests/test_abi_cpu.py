@@ -65,7 +65,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
     lib = hip.load()
     cfg = hip.PodConfig()
     assert lib.pod_reset_counters(None, 4, None) == -1
-    assert lib.pod_level_topk(cfg, None, None, None, None, None, None) == -1
+    assert lib.pod_level_topk(cfg, None, None, None, None, None, None, None, None, None) == -1
     assert lib.pod_reg_nll(None, None, None, 3, None, None) == -1
     assert lib.pod_run_image(cfg, None, None, 0, 0, 0, 10, 10, 10, 10, None, None) == -1
     assert lib.pod_nms_cluster(cfg, None, 8, None, None, None, None, None, None, None) == -1

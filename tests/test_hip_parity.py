@@ -173,9 +173,10 @@ def _native_candidates(hp, hd, prune):
     if prune:
         n_maybe = sum(bin(int(x) & (2 ** 64 - 1)).count("1") for x in hp.maybe_bits.cpu().tolist())   # K1b clears the bitmap
         hip.check(lib.pod_score_maybe(hp.cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits),
-                                      P(hp.cand_keys), P(hp.cand_count), st), "k1b")
+                                      P(hp.cand_keys), P(hp.cand_count), P(hp.probs_dense), st), "k1b")
     torch.cuda.synchronize()
     counts = hp.cand_count.cpu().tolist()
+    hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")      # leave the workspace clean for the next image
     keys = [torch.sort(hp.cand_keys[b:b + c].cpu())[0] for b, c in zip(hp.anchor_base, counts)]
     assert not prune or int(hp.maybe_bits.abs().sum().item()) == 0      # left zeroed for the next image
     return counts, keys, [n_maybe]

@@ -13,7 +13,7 @@ from pod_compare_amd import hip
 pytestmark = pytest.mark.gpu
 
 
-def run_kernel(boxes, scores, classes, num_classes=7, thr=0.5, max_det=100, cap=None):
+def run_kernel(boxes, scores, classes, num_classes=7, thr=0.5, max_det=100, cap=None, scratch=None):
     lib = hip.load()
     cfg = hip.PodConfig()
     cfg.max_detections, cfg.nms_thresh, cfg.num_classes = max_det, thr, num_classes
@@ -24,7 +24,8 @@ def run_kernel(boxes, scores, classes, num_classes=7, thr=0.5, max_det=100, cap=
     keep = torch.full((hip.POD_MAX_DETECTIONS,), -1, dtype=torch.int32, device="cuda")
     n_keep = torch.full((1,), -7, dtype=torch.int32, device="cuda")
     nt = torch.tensor([n], dtype=torch.int32, device="cuda")
-    scratch = torch.empty(lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device="cuda")
+    if scratch is None:
+        scratch = torch.zeros(lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device="cuda")      # zeroed once (include/pod_mi355x.h)
     P = hip.ptr
     hip.check(lib.pod_nms_cluster(cfg, P(nt), cap, P(b), P(s), P(c), P(keep), P(n_keep), P(scratch), hip.current_stream()),
               "pod_nms_cluster")
@@ -118,3 +119,23 @@ def test_class_id_out_of_range_takes_the_single_workgroup_route():
     got, flag = run_kernel(boxes, scores, classes, num_classes=3)
     assert flag == 1
     assert torch.equal(got, ref)
+
+
+def test_early_stop_of_the_class_sweeps_is_exact_and_survives_scratch_reuse():
+    """Every class fills up (thousands of barely overlapping boxes, 7 classes): a class sweep stops as soon as the other
+    classes have published enough higher-scoring survivors (k4_nms.hip).  keep[:100] must still be the reference's, on every
+    one of several calls that reuse ONE scratch buffer (the published scores of earlier calls carry an older generation tag)."""
+    lib = hip.load()
+    scratch = torch.zeros(lib.pod_nms_scratch_bytes(8192), dtype=torch.uint8, device="cuda")
+    for seed, n, K in ((1, 4594, 7), (2, 4594, 7), (3, 700, 7), (4, 8192, 15), (5, 4594, 2), (6, 50, 7)):
+        g = torch.Generator().manual_seed(seed)
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([1300.0, 740.0])
+        wh = torch.rand(n, 2, generator=g) * 30 + 4
+        boxes = torch.cat([xy, xy + wh], 1)
+        scores = torch.rand(n, generator=g)
+        if seed == 2:
+            scores = (scores * 16).floor() / 16                    # heavy score ties across classes
+        classes = torch.randint(0, K, (n,), generator=g).to(torch.int32)
+        ref = po.class_aware_nms(boxes, scores, classes.long(), 0.5)[:100]
+        got, flag = run_kernel(boxes, scores, classes, num_classes=K, cap=8192, scratch=scratch)
+        assert flag == 0 and torch.equal(got, ref), seed

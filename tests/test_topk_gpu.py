@@ -1,6 +1,7 @@
 """pod_level_topk through the C ABI against torch.sort: exact top-k of every level's key list, sorted descending, for the
-single-workgroup path (<= 2048 candidates), the sliced path (16 workgroups + last-one-merges) and its corner sizes;
-counters and tickets left zeroed."""
+single-workgroup path (<= 2048 candidates), the sliced path (16 workgroups + last-one-merges) and its corner sizes; the
+level-concatenated copy (cat_keys / cat_level / n_total) the gather kernels read; tickets left zeroed, counts untouched
+(the gather kernel consumes them)."""
 import pytest
 import torch
 
@@ -43,13 +44,22 @@ def test_level_topk_equals_sorted_prefix(counts, skew):
     cnt[:L] = torch.tensor(counts, dtype=torch.int32)
     sel = torch.full((L * topk,), -1, dtype=torch.int64, device="cuda")
     sc = torch.full((L,), -1, dtype=torch.int32, device="cuda")
-    for _ in range(2):                     # second round on the consumed counters: every level must come out empty
-        hip.check(lib.pod_level_topk(cfg, lv, P(dk), P(cnt), P(sel), P(sc), hip.current_stream()), "pod_level_topk")
+    cat = torch.full((L * topk,), -1, dtype=torch.int64, device="cuda")
+    cat_lv = torch.full((L * topk,), -1, dtype=torch.int32, device="cuda")
+    nt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    for rnd in range(2):                   # second round: the gather kernel has consumed the counts, every level comes out empty
+        hip.check(lib.pod_level_topk(cfg, lv, P(dk), P(cnt), P(sel), P(sc), P(cat), P(cat_lv), P(nt), hip.current_stream()), "pod_level_topk")
         torch.cuda.synchronize()
-        assert int(cnt.abs().sum()) == 0
-        if _ == 0:
+        assert int(cnt[L:].abs().sum()) == 0                       # tickets
+        if rnd == 0:
+            assert cnt[:L].cpu().tolist() == counts                # only read here
             assert sc.cpu().tolist() == [min(topk, c) for c in counts]
             for l in range(L):
                 assert torch.equal(sel[l * topk:l * topk + len(refs[l])].cpu(), refs[l]), l
+            n = sum(min(topk, c) for c in counts)
+            assert int(nt.item()) == n
+            assert torch.equal(cat[:n].cpu(), torch.cat(refs))
+            assert cat_lv[:n].cpu().tolist() == [l for l, r in enumerate(refs) for _ in range(len(r))]
+            cnt[:L] = 0                                            # what pod_gather_candidates / pod_gather_decode do
         else:
-            assert sc.cpu().tolist() == [0] * L
+            assert sc.cpu().tolist() == [0] * L and int(nt.item()) == 0

@@ -32,7 +32,7 @@ def launch(j):
     if prune:
         if j >= 0: evb[j][0].record()
         check(hp.lib.pod_score_maybe(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits),
-                                     P(hp.cand_keys), P(hp.cand_count), st), "k1b")
+                                     P(hp.cand_keys), P(hp.cand_count), P(hp.probs_dense), st), "k1b")
         if j >= 0: evb[j][1].record()
 for j in range(3): launch(-1)
 torch.cuda.synchronize()
