@@ -20,10 +20,11 @@
 namespace pod {
 
 constexpr int K3_MAX_SAMPLES = POD_MAX_PROP_SAMPLES;
+constexpr int WAVE_SCRATCH = 10 * 64 + (16 + 4 * POD_MAX_RUNS) + 4 * POD_MAX_RUNS;   // part + small + run_delta, floats per wavefront
 
-// One 64-thread workgroup (= one wavefront) per candidate (eps-replay parity mode and the call-by-call path).
+// One 64-thread workgroup (= one wavefront) per candidate (eps-replay parity mode and the call-by-call path); the lane's
+// 16 samples never leave its registers.
 __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
-    __shared__ float4 xs[K3_MAX_SAMPLES];   // decoded samples
     __shared__ __attribute__((aligned(16))) float part[10 * 64];   // [component][lane]
     __shared__ float small[16 + 4 * POD_MAX_RUNS];
     const int lane = threadIdx.x;
@@ -32,40 +33,64 @@ __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
     const float4 d4 = *reinterpret_cast<const float4*>(P.cand_delta + (size_t)i * 4);
     const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
     const Box anc = load_box(P.cand_anchor, i);
+    float rv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t gid = 0;
     if (P.D > 0) {
-        float rv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < 10; ++c)
             if (c < P.D) rv[c] = P.cand_reg_var[(size_t)i * P.D + c];
-        const uint32_t gid = (uint32_t)(P.anchor_base[P.cand_level[i]] + P.cand_anchor_idx[i]);
-        generate_samples(P, i, lane, 64, dl, rv, anc, gid, xs);
-        wave_sync();
+        gid = (uint32_t)(P.anchor_base[P.cand_level[i]] + P.cand_anchor_idx[i]);
     }
-    decode_candidate(P, i, lane, dl, anc, P.n_runs > 1 ? P.cand_run_delta + (size_t)i * P.n_runs * 4 : nullptr, xs, part, small);
+    decode_candidate<false>(P, i, lane, dl, rv, anc, gid, P.n_runs > 1 ? P.cand_run_delta + (size_t)i * P.n_runs * 4 : nullptr, nullptr,
+                            part, small);
 }
 
-// K2b + K3 fused (native draws): the workgroup that gathered a candidate decodes it.  256 threads per candidate: wavefront 0
-// gathers (lane = channel) and hands the merged deltas / log-variances / anchor to the others through LDS; all four
-// wavefronts draw and decode the 1000 samples (the bulk of the arithmetic: ~6 000 VALU instructions when one wavefront did
-// it alone, 14 of the kernel's 22 us); wavefront 0 then forms the moments in the reference's summation order.  The
-// candidate arrays in HBM are written for the later kernels but never read back here.
+// K2b + K3 fused (native draws): the workgroup that gathered a candidate decodes it; merged deltas / log-variances / per-run
+// deltas never leave the workgroup (the candidate arrays in HBM are written for the later kernels, never read back here).
+// 256-thread workgroups, two shapes chosen on the device by the candidate count n (uniform over the grid):
+//   n <= K23_SMALL_MAX (every image of a typical detector: a few hundred candidates, fewer workgroups than CUs):
+//     one candidate per workgroup; wavefront 0 gathers (lane = channel), all four wavefronts draw and decode the 1000
+//     samples into LDS (Philox + Box-Muller + exp: ~6 000 VALU instructions when one wavefront did it alone, 14 of the
+//     kernel's 22 us), wavefront 0 forms the moments in the reference's summation order;
+//   n  > K23_SMALL_MAX: one candidate per WAVEFRONT (workgroup g takes rows 4g .. 4g+3), samples in registers: with
+//     thousands of candidates every SIMD has work anyway, and three idle wavefronts per candidate would only cost occupancy.
 struct K23Params {
     K2bParams g;
     K3Params d;
 };
 
 constexpr int K23_THREADS = 256;
+constexpr int K23_SMALL_MAX = 1024;
 
 __global__ void __launch_bounds__(K23_THREADS) k23_gather_decode(const K23Params P) {
-    __shared__ float4 xs[K3_MAX_SAMPLES];
-    __shared__ __attribute__((aligned(16))) float part[10 * 64];
-    __shared__ float small[16 + 4 * POD_MAX_RUNS];
-    __shared__ float run_delta[4 * POD_MAX_RUNS];
-    __shared__ float hand[4 + 10 + 4 + 2];    // merged deltas, reg_var entries, anchor, gid, live flag
-    const int tid = threadIdx.x, lane = tid & 63;
+    // small shape: xs | part | small | run_delta | hand;  big shape: 4 x WAVE_SCRATCH carved from the same array
+    __shared__ __attribute__((aligned(16))) float lds[4 * K3_MAX_SAMPLES + WAVE_SCRATCH + 24];
+    static_assert(4 * WAVE_SCRATCH <= 4 * K3_MAX_SAMPLES + WAVE_SCRATCH + 24 && WAVE_SCRATCH % 4 == 0, "per-wave scratch fits / stays aligned");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = P.g.K, D = P.g.D, nvar = P.g.has_cls_var ? K : 0;
+    const int n = *P.g.n_total;
     GatheredCandidate c;
     POD_STAMP(blockIdx.x, 0);
+    if (n > K23_SMALL_MAX) {
+        float* part = lds + wave * WAVE_SCRATCH;
+        float* small = part + 10 * 64;
+        float* run_delta = small + 16 + 4 * POD_MAX_RUNS;
+        if (!gather_candidate(P.g, (int)blockIdx.x * 4 + wave, lane, run_delta, c)) return;   // wave-uniform
+        float dl[4], rv[10];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dl[j] = __shfl(c.merged, K + nvar + j, 64);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) rv[j] = (j < D) ? __shfl(c.merged, K + nvar + 4 + (j < D ? j : 0), 64) : 0.0f;
+        const Box anc{c.anchor.x, c.anchor.y, c.anchor.z, c.anchor.w};
+        wave_sync();   // run_delta (LDS) written by the delta lanes of this wavefront
+        decode_candidate<false>(P.d, c.dst, lane, dl, rv, anc, (uint32_t)(P.g.lv[c.level].anchor_base + c.r), run_delta, nullptr, part, small);
+        return;
+    }
+    float4* xs = reinterpret_cast<float4*>(lds);
+    float* part = lds + 4 * K3_MAX_SAMPLES;
+    float* small = part + 10 * 64;
+    float* run_delta = small + 16 + 4 * POD_MAX_RUNS;
+    float* hand = run_delta + 4 * POD_MAX_RUNS;    // merged deltas, reg_var entries, anchor, gid, live flag
     if (tid < 64) {
         const bool live = gather_candidate(P.g, blockIdx.x, lane, run_delta, c);   // wave-uniform
         if (lane == 0) hand[19] = live ? 1.0f : 0.0f;
@@ -83,16 +108,16 @@ __global__ void __launch_bounds__(K23_THREADS) k23_gather_decode(const K23Params
     POD_STAMP(blockIdx.x, 4);
     const float dl[4] = {hand[0], hand[1], hand[2], hand[3]};
     const Box anc{hand[14], hand[15], hand[16], hand[17]};
-    if (D > 0) {
-        float rv[10];
+    float rv[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) rv[j] = j < D ? hand[4 + j] : 0.0f;
-        generate_samples(P.d, (int)blockIdx.x, tid, K23_THREADS, dl, rv, anc, __float_as_uint(hand[18]), xs);
+    for (int j = 0; j < 10; ++j) rv[j] = j < D ? hand[4 + j] : 0.0f;
+    if (D > 0) {
+        generate_samples(P.d, tid, K23_THREADS, dl, rv, anc, __float_as_uint(hand[18]), xs);
         __syncthreads();
     }
     POD_STAMP(blockIdx.x, 5);
     if (tid >= 64) return;
-    decode_candidate(P.d, c.dst, lane, dl, anc, run_delta, xs, part, small);
+    decode_candidate<true>(P.d, c.dst, lane, dl, rv, anc, 0u, run_delta, xs, part, small);
     POD_STAMP(blockIdx.x, 6);
 }
 

@@ -75,8 +75,9 @@ __device__ __forceinline__ bool gather_candidate(const K2bParams& P, int dst, in
     // was two dependent ones, in a kernel whose gather phase is nothing but a chain of HBM round trips)
     const int n = *P.n_total;
     if (dst == 0 && lane < P.n_levels) P.cand_count[lane] = 0;   // consumed: the next image's K1 appends from zero
-    const uint64_t key = P.cat_keys[dst];      // dst < n_levels * topk = the arrays' capacity (= the grid size)
-    const int l = P.cat_level[dst];
+    const int row = dst < P.n_levels * P.topk ? dst : 0;      // the arrays hold n_levels * topk rows; n never exceeds that
+    const uint64_t key = P.cat_keys[row];
+    const int l = P.cat_level[row];
     if (dst >= n) return false;
     POD_STAMP(dst, 1);
     const PodLevel& lv = P.lv[l];
@@ -198,78 +199,82 @@ __device__ __forceinline__ float cascade_combine(const float* col, int S) {
     return acc0;
 }
 
-// Draw + decode the S samples of one candidate (PI:351-356 rsample, IU:510-547 decode) into LDS, by `nthreads` threads
-// (thread u of them).  The expensive part of the candidate -- Philox, Box-Muller, exp -- is embarrassingly parallel over
-// samples, so the fused kernel spreads it over 4 wavefronts; the ORDER-sensitive part (torch's block sums) stays with
-// one wavefront, which reads the decoded samples back from LDS (decode_candidate).  Sample values do not depend on which
-// thread produced them, so any nthreads gives bit-identical results.
-//   native draws: one Philox call serves the two samples (2m, 2m+1); thread u takes calls m = u, u + nthreads, ...
-//   replayed draws: thread u takes samples s = u, u + nthreads, ...
-// xs: S float4 of LDS (decoded x1,y1,x2,y2 of sample s).  dl / rv / anc / gid as in decode_candidate.
-__device__ __forceinline__ void generate_samples(const K3Params& P, int i, int u, int nthreads, const float (&dl)[4], const float (&rv)[10],
-                                                 const Box& anc, uint32_t gid, float4* xs) {
-    const int S = P.S, D = P.D;
-    // ---- Cholesky factor (row-major lower triangle), MU:4-22 ------------------------------------------
-    float Lm[4][4];
+// ---- one sample of the propagation (PI:351-356 rsample + IU:510-547 decode) -------------------------------------------
+struct CholeskyL {
+    float m[4][4];   // row-major lower triangle, MU:4-22
+};
+
+__device__ __forceinline__ CholeskyL cholesky_from_head(const float (&rv)[10], int D) {
+    CholeskyL L;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Lm[r][c] = 0.0f;
+        for (int c = 0; c < 4; ++c) L.m[r][c] = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Lm[c][c] = sqrtf(expf(rv[c]));
+    for (int c = 0; c < 4; ++c) L.m[c][c] = sqrtf(expf(rv[c]));
     if (D == 10) {   // torch.tril_indices(4,4,-1): (1,0),(2,0),(2,1),(3,0),(3,1),(3,2)
-        Lm[1][0] = rv[4]; Lm[2][0] = rv[5]; Lm[2][1] = rv[6];
-        Lm[3][0] = rv[7]; Lm[3][1] = rv[8]; Lm[3][2] = rv[9];
+        L.m[1][0] = rv[4]; L.m[2][0] = rv[5]; L.m[2][1] = rv[6];
+        L.m[3][0] = rv[7]; L.m[3][1] = rv[8]; L.m[3][2] = rv[9];
     }
-    auto one = [&](int s, const float (&e)[4]) {
-        float d[4];
-        if (D == 4) {
+    return L;
+}
+
+// delta + L eps, decoded against the anchor: the ONE definition of a sample's value, whoever computes it
+__device__ __forceinline__ float4 decode_sample(const K3Params& P, const float (&dl)[4], const CholeskyL& L, const float (&e)[4],
+                                                const Box& anc) {
+    float d[4];
+    if (P.D == 4) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = dl[c] + Lm[c][c] * e[c];   // L eps exact for diagonal L
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = Lm[c][0] * e[0];
-#pragma unroll
-                for (int k = 1; k < 4; ++k) acc = fmaf(Lm[c][k], e[k], acc);
-                d[c] = dl[c] + acc;
-            }
-        }
-        const Box b = decode_box(d[0], d[1], d[2], d[3], anc, P.wts);
-        xs[s] = float4{b.x1, b.y1, b.x2, b.y2};
-    };
-    if (P.eps_prop) {
-        for (int s = u; s < S; s += nthreads) {
-            const float4 e4 = *reinterpret_cast<const float4*>(P.eps_prop + ((size_t)s * P.n_replay + i) * 4);
-            const float e[4] = {e4.x, e4.y, e4.z, e4.w};
-            one(s, e);
-        }
+        for (int c = 0; c < 4; ++c) d[c] = dl[c] + L.m[c][c] * e[c];   // L eps exact for diagonal L
     } else {
-        for (int m = u; 2 * m < S; m += nthreads) {
-            const f32x8n z = philox_normals8(P.seed, gid, (uint32_t)m, 0u, STREAM_BOX);
-            const float e0[4] = {z.v[0], z.v[1], z.v[2], z.v[3]};
-            one(2 * m, e0);
-            if (2 * m + 1 < S) {
-                const float e1[4] = {z.v[4], z.v[5], z.v[6], z.v[7]};
-                one(2 * m + 1, e1);
-            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = L.m[c][0] * e[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = fmaf(L.m[c][k], e[k], acc);
+            d[c] = dl[c] + acc;
+        }
+    }
+    const Box b = decode_box(d[0], d[1], d[2], d[3], anc, P.wts);
+    return float4{b.x1, b.y1, b.x2, b.y2};
+}
+
+// Draw + decode the S samples of one candidate into LDS, by `nthreads` threads (thread u of them).  The expensive part of
+// a candidate -- Philox, Box-Muller, exp -- is embarrassingly parallel over samples, so the fused kernel spreads it over
+// 4 wavefronts when there are few candidates; the ORDER-sensitive part (torch's block sums) stays with one wavefront,
+// which reads the decoded samples back from LDS (decode_candidate<true>).  Native draws only: one Philox call serves the
+// two samples (2m, 2m+1); thread u takes calls m = u, u + nthreads, ...   xs: S float4 of LDS.
+__device__ __forceinline__ void generate_samples(const K3Params& P, int u, int nthreads, const float (&dl)[4], const float (&rv)[10],
+                                                 const Box& anc, uint32_t gid, float4* xs) {
+    const int S = P.S;
+    const CholeskyL L = cholesky_from_head(rv, P.D);
+    for (int m = u; 2 * m < S; m += nthreads) {
+        const f32x8n z = philox_normals8(P.seed, gid, (uint32_t)m, 0u, STREAM_BOX);
+        const float e0[4] = {z.v[0], z.v[1], z.v[2], z.v[3]};
+        xs[2 * m] = decode_sample(P, dl, L, e0, anc);
+        if (2 * m + 1 < S) {
+            const float e1[4] = {z.v[4], z.v[5], z.v[6], z.v[7]};
+            xs[2 * m + 1] = decode_sample(P, dl, L, e1, anc);
         }
     }
 }
 
-// Candidate `i`, ONE wavefront (lane = threadIdx & 63 of the calling wave): sample moments in torch's summation order +
-// epistemic covariance + stores.  xs: the decoded samples (generate_samples; D > 0 only), anc its anchor, dl its merged
-// deltas, run_delta = the N runs' raw deltas (N x 4 floats, HBM or LDS).
-// part: 10*64 floats of LDS (16-byte aligned), small: 16 + 4*POD_MAX_RUNS floats of LDS.  The caller has synchronised the producers of xs;
-// all LDS traffic below stays inside this wavefront (wave_sync).
+// All LDS traffic of decode_candidate stays inside one wavefront: order it without a workgroup barrier.
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int lane, const float (&dl)[4], const Box& anc,
-                                                 const float* run_delta, const float4* xs_lds, float* part, float* small) {
+// Candidate `i`, ONE wavefront (lane = threadIdx & 63 of the calling wave): sample moments in torch's summation order +
+// epistemic covariance + stores.  Lane l owns samples [16l, 16l+16) = one 16-row block of torch's cascade sum.
+//   FROM_LDS  : the samples were produced by generate_samples (xs_lds; the caller synchronised the producers);
+//   otherwise : this wavefront draws / replays and decodes its own 16 samples per lane (rv, gid, P.eps_prop).
+// dl its merged deltas, anc its anchor, run_delta = the N runs' raw deltas (N x 4 floats, HBM or LDS).
+// part: 10*64 floats of LDS (16-byte aligned), small: 16 + 4*POD_MAX_RUNS floats of LDS -- private to this wavefront.
+template <bool FROM_LDS>
+__device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int lane, const float (&dl)[4], const float (&rv)[10], const Box& anc,
+                                                 uint32_t gid, const float* run_delta, const float4* xs_lds, float* part, float* small) {
     const int S = P.S, D = P.D, N = P.n_runs;
     float mean[4] = {0, 0, 0, 0};
     float cv[10];
@@ -277,14 +282,32 @@ __device__ __forceinline__ void decode_candidate(const K3Params& P, int i, int l
     for (int c = 0; c < 10; ++c) cv[c] = 0.0f;
 
     if (D > 0) {
-        // ---- pass 1: lane l owns samples [16l, 16l+16) = one 16-row block of torch's cascade sum ----------------
+        // ---- pass 1: the lane's 16 samples, block sums --------------------------------------------------------
         float xs[16][4];
         float bs[4] = {0, 0, 0, 0};
+        CholeskyL L;
+        if (!FROM_LDS) L = cholesky_from_head(rv, D);
+        f32x8n z;   // native draws: one Philox call serves the two samples (2m, 2m+1)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int s = lane * 16 + t;
             const bool live = s < S;
-            const float4 v = live ? xs_lds[s] : float4{0.f, 0.f, 0.f, 0.f};
+            float4 v = float4{0.f, 0.f, 0.f, 0.f};
+            if (FROM_LDS) {
+                if (live) v = xs_lds[s];
+            } else {
+                float e[4] = {0, 0, 0, 0};
+                if (live) {
+                    if (P.eps_prop) {
+                        const float4 e4 = *reinterpret_cast<const float4*>(P.eps_prop + ((size_t)s * P.n_replay + i) * 4);
+                        e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+                    } else {
+                        if ((t & 1) == 0) z = philox_normals8(P.seed, gid, (uint32_t)(s >> 1), 0u, STREAM_BOX);
+                        e[0] = z.v[(t & 1) * 4 + 0]; e[1] = z.v[(t & 1) * 4 + 1]; e[2] = z.v[(t & 1) * 4 + 2]; e[3] = z.v[(t & 1) * 4 + 3];
+                    }
+                }
+                v = decode_sample(P, dl, L, e, anc);
+            }
             xs[t][0] = v.x; xs[t][1] = v.y; xs[t][2] = v.z; xs[t][3] = v.w;
 #pragma unroll
             for (int c = 0; c < 4; ++c) bs[c] = live ? bs[c] + xs[t][c] : bs[c];
