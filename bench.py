@@ -210,10 +210,10 @@ def main():
     if args.ensemble_per_gpu:
         if args.config != "cfg5" or world < spec["members"]:
             raise SystemExit("--ensemble-per-gpu is BASELINE configs[4]: --config cfg5 and --gpus >= %d" % spec["members"])
-        if backend != "nccl":
-            raise SystemExit("--ensemble-per-gpu exchanges device buffers point-to-point: needs the nccl (RCCL) backend")
+        # (backend nccl = RCCL moves the packed device buffers directly; any other backend stages rows through pinned host
+        #  memory: the functional check on a single-GPU box, POD_BENCH_BACKEND=gloo POD_BENCH_SHARE_GPU=1)
         dt, merged_here = run_ensemble_per_gpu(args, spec, world, rank, dev)
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = stage(torch.tensor([dt], device=dev, dtype=torch.float64))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         if rank == 0:
@@ -223,7 +223,8 @@ def main():
                 "higher_is_better": True, "scaling": "fixed: 5 member ranks, the other ranks only merge", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (seeded 1280x720 uint8 frames; random-init members seeded 0,1000,..; detections of the members' own outputs)",
                 "config": {"workload": spec["name"] + ", one seed per GPU", "parallelism": "5 member ranks + rotating merge rank, RCCL p2p",
-                           "rccl_ranks": world, "images_in_flight": 2, "conv_net_in_timed_region": True}}))
+                           "rccl_ranks": world, "collective_backend": backend, "ranks_share_one_gpu": bool(share),
+                           "images_in_flight": 2, "conv_net_in_timed_region": True}}))
         dist.destroy_process_group()
         return
 

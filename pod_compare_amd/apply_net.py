@@ -74,7 +74,9 @@ class EnsemblePerGpu:
     (PI:495-505).  Ranks >= M only merge; they never build a model: the predictor reads the model's test-time
     attributes from `model_test_attributes(cfg)` and the level geometry comes from the anchor generator."""
 
-    def __init__(self, cfg, rank: int, world: int, frame_hw=(720, 1280)):
+    def __init__(self, cfg, rank: int, world: int, frame_hw=(720, 1280), net_hw=None, model=None):
+        """frame_hw: output resolution ('height' / 'width' of input_im); net_hw: network-input size (default: the test
+        transform of frame_hw, AN:83); model: this rank's member model (default: built and loaded per PI:59-77)."""
         from . import anchors, ensemble_dist, modeling
         from .probabilistic_inference import RetinaNetProbabilisticPredictor, build_model, ensemble_member_dir, model_test_attributes
         from .synthetic import HeadOutputs
@@ -83,8 +85,8 @@ class EnsemblePerGpu:
         if world < self.M:
             raise SystemExit("one ensemble member per rank needs at least %d ranks, got %d" % (self.M, world))
         self.dev = torch.device(cfg.MODEL.DEVICE)
-        self.model = None
-        if rank < self.M:
+        self.model = model if rank < self.M else None
+        if rank < self.M and self.model is None:
             state = torch.random.get_rng_state()
             torch.manual_seed(int(seeds[rank]))          # a member without a checkpoint is a random-init model seeded with its number
             self.model = build_model(cfg, save_dir=ensemble_member_dir(cfg, seeds[rank]))      # PI:59-77
@@ -94,7 +96,8 @@ class EnsemblePerGpu:
                                                          model_list=[object()] * self.M)
         self.predictor.return_device = True
         self.frame_hw = tuple(frame_hw)
-        self.net_hw = anchors.resize_shortest_edge(frame_hw[0], frame_hw[1], cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+        self.net_hw = tuple(net_hw) if net_hw is not None else \
+            anchors.resize_shortest_edge(frame_hw[0], frame_hw[1], cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
         padded = anchors.padded_size(*self.net_hw)
         shapes = anchors.level_shapes(*padded)
         pm = cfg.MODEL.PROBABILISTIC_MODELING
@@ -150,6 +153,7 @@ def main(argv=None):
                     help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="BASELINE config 5: rank s < M runs ensemble member s, dense pre-NMS tensors meet on a rotating merge rank")
+    ap.add_argument("--binary-output", default="", help="also write the detections as a binary sidecar (inference_utils.write_binary_results)")
     ap.add_argument("--data-dir", default="", help="the reference's core.data_dir(): OUTPUT_DIR = <data-dir>/<dataset>/<family>/<config>/"
                                                    "random_seed_<seed>, whose last_checkpoint is loaded (CS:170-182, PI:59-84)")
     ap.add_argument("--weights", default=None, help="overrides MODEL.WEIGHTS (a local .pth / .pkl with detectron2 names)")
@@ -231,6 +235,9 @@ def main(argv=None):
     if rank == 0:
         with open(args.output, "w") as fp:
             json.dump(results_json(ids, cnt, rec, K, BDD_CAT_MAP), fp, indent=4, separators=(",", ": "))
+        if args.binary_output:
+            from .inference_utils import write_binary_results
+            write_binary_results(args.binary_output, ids, cnt, rec, K)
         print("wrote %s: %d images, %d detections" % (args.output, len(ids), int(cnt.sum())))
     if world > 1:
         dist.destroy_process_group()

@@ -118,6 +118,14 @@ class MemberPipeline:
         self.stacked: List[Optional[torch.Tensor]] = [None] * depth        # allocated on first use as a merge rank
         self._send: List[list] = [[] for _ in range(depth)]
         self._recv = {}
+        # RCCL moves device buffers directly (xGMI).  Any other backend (gloo: the functional check of this very code path
+        # with all ranks on ONE GPU, and the CPU tests) cannot send device memory: rows are staged through pinned host
+        # buffers -- same schedule, same buffers on the device side.
+        self.host_staged = self.device.type == "cuda" and dist.get_backend() != "nccl"
+        if self.host_staged:
+            pin = lambda *shape: torch.empty(shape, dtype=torch.float32).pin_memory()
+            self._h_send = [pin(layout.total) for _ in range(depth)] if rank < n_members else None
+            self._h_recv: List[Optional[torch.Tensor]] = [None] * depth
 
     def post(self, image_index: int, member_outputs: Optional[HeadOutputs]) -> None:
         dst, slot = merge_rank(image_index, self.world), image_index % self.depth
@@ -130,13 +138,19 @@ class MemberPipeline:
         if self.rank == dst:
             if self.stacked[slot] is None:
                 self.stacked[slot] = torch.empty((self.M, self.layout.total), dtype=torch.float32, device=self.device)
+                if self.host_staged:
+                    self._h_recv[slot] = torch.empty((self.M, self.layout.total), dtype=torch.float32).pin_memory()
             for s in range(self.M):
                 if s == self.rank:
                     self.stacked[slot][s].copy_(self.packed[slot])
                 else:
-                    ops.append(dist.P2POp(dist.irecv, self.stacked[slot][s], s))
+                    ops.append(dist.P2POp(dist.irecv, (self._h_recv if self.host_staged else self.stacked)[slot][s], s))
         elif self.rank < self.M:
-            ops.append(dist.P2POp(dist.isend, self.packed[slot], dst))
+            if self.host_staged:
+                self._h_send[slot].copy_(self.packed[slot])          # synchronous: the row is on the host when isend starts
+                ops.append(dist.P2POp(dist.isend, self._h_send[slot], dst))
+            else:
+                ops.append(dist.P2POp(dist.isend, self.packed[slot], dst))
         works = dist.batch_isend_irecv(ops) if ops else []
         if self.rank == dst:
             self._recv[image_index] = works
@@ -147,7 +161,12 @@ class MemberPipeline:
         """(M, packed) buffer of image `image_index` on its merge rank (valid until round image_index + depth is posted)."""
         for w in self._recv.pop(image_index):
             w.wait()
-        return self.stacked[image_index % self.depth]
+        slot = image_index % self.depth
+        if self.host_staged:
+            for s in range(self.M):
+                if s != self.rank:
+                    self.stacked[slot][s].copy_(self._h_recv[slot][s])      # blocking: the host row may be overwritten by a later round
+        return self.stacked[slot]
 
     def drain(self) -> None:
         for works in self._send:

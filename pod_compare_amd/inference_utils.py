@@ -54,3 +54,52 @@ def records_to_json(records: torch.Tensor, count: int, img_id, num_classes: int,
         out.append({"image_id": img_id, "category_id": cid, "bbox": row[0:4], "score": row[4],
                     "cls_prob": row[RECORD_HEAD:RECORD_HEAD + num_classes], "bbox_covar": [cov[0:4], cov[4:8], cov[8:12], cov[12:16]]})
     return out
+
+
+# ---- binary sidecar of coco_instances_results.json (SURVEY f-2) --------------------------------------------------------
+# The reference's result file is 4-space-indented JSON (AN:100-102): ~1.5 KB of text per detection, most of it the 16 floats
+# of `bbox_covar`, parsed back by the offline evaluation one torch.cat per detection (EU:19-73).  The sidecar holds the
+# same payload as K7 wrote it: little-endian
+#     magic "PODR" | u32 version | u32 n_images | u32 num_classes | u32 max_det | i64 image_id[n] | i32 count[n] |
+#     f32 records[n][max_det][6 + K + 16]          (x, y, w, h, score, class, probs[K], T cov T^T row-major)
+# `read_binary_results` returns what `records_to_json` would have produced, so either file feeds the evaluation.
+import struct
+
+_MAGIC = b"PODR"
+
+
+def write_binary_results(path: str, image_ids, counts: torch.Tensor, records: torch.Tensor, num_classes: int) -> None:
+    import numpy as np
+    n = len(image_ids)
+    rec = records.detach().cpu().to(torch.float32).contiguous().numpy()
+    assert rec.shape[0] == n and rec.shape[2] == record_width(num_classes)
+    with open(path, "wb") as f:
+        f.write(_MAGIC + struct.pack("<IIII", 1, n, int(num_classes), int(rec.shape[1])))
+        f.write(np.asarray(list(image_ids), dtype="<i8").tobytes())
+        f.write(counts.detach().cpu().to(torch.int32).contiguous().numpy().astype("<i4").tobytes())
+        f.write(rec.astype("<f4").tobytes())
+
+
+def read_binary_results(path: str):
+    """-> (image ids list, counts (n,) int32, records (n, max_det, 6 + K + 16) fp32, num_classes)."""
+    import numpy as np
+    with open(path, "rb") as f:
+        head = f.read(20)
+        if head[:4] != _MAGIC:
+            raise ValueError("{} is not a pod_mi355x result sidecar".format(path))
+        version, n, k, md = struct.unpack("<IIII", head[4:])
+        if version != 1:
+            raise ValueError("unsupported sidecar version {}".format(version))
+        ids = np.frombuffer(f.read(8 * n), dtype="<i8").tolist()
+        counts = torch.from_numpy(np.frombuffer(f.read(4 * n), dtype="<i4").copy())
+        w = record_width(k)
+        rec = torch.from_numpy(np.frombuffer(f.read(4 * n * md * w), dtype="<f4").copy()).reshape(n, md, w)
+    return ids, counts, rec, k
+
+
+def binary_results_to_json(path: str, cat_mapping_dict: Optional[Dict[int, int]] = None) -> List[dict]:
+    ids, counts, rec, k = read_binary_results(path)
+    out = []
+    for i, image_id in enumerate(ids):
+        out.extend(records_to_json(rec[i], int(counts[i]), image_id, k, cat_mapping_dict))
+    return out

@@ -1,0 +1,118 @@
+"""`torch.ops.pod_mi355x.*`: the C-ABI entry points as registered PyTorch operators (last row).
+
+A maintainer of the reference who prefers operator calls over ctypes gets the hot path as ops that take and return
+tensors, run on the CURRENT HIP stream and validate their arguments (`torch._check`: fp32 / int32, contiguous, on one
+CUDA device).  The ops are thin: argument checks + the same `libpod_mi355x.so` launches `hotpath.HotPath` makes; there is
+no second implementation and no CPU kernel (calling them with CPU tensors raises).
+
+    import pod_compare_amd.torch_ops          # registers the library
+    boxes, cov, scores, classes, probs = torch.ops.pod_mi355x.predict(
+        box_cls, box_delta, box_cls_var, box_reg_var, anchors, "bayes_od", [750, 1333], [720, 1280], ...)
+
+    predict      everything RetinaNetProbabilisticPredictor.__call__ does after the model forward (PI:86-111): one image's
+                 dense head tensors (per level, NCHW planes `(n_runs, A*C, H, W)`, the conv head's own layout) -> detections
+    nms_cluster  detectron2 batched_nms as called at PI:554-560 / IU:31-36 -> keep indices
+    reg_nll      compute_reg_scores' per-row NLL, scoring_rules.py:68-74
+"""
+from typing import List, Tuple
+
+import torch
+
+from . import hip, hotpath
+
+_LIB = torch.library.Library("pod_mi355x", "DEF")
+_LIB.define("predict(Tensor[] box_cls, Tensor[] box_delta, Tensor[] box_cls_var, Tensor[] box_reg_var, Tensor[] anchors, "
+            "str mode, int[] image_size, int[] out_size, int num_classes=7, int topk_candidates=1000, float score_thresh=0.05, "
+            "float nms_thresh=0.5, int max_detections=100, int cls_var_num_samples=10, float affinity_thresh=0.9, "
+            "bool merge_quirk=True, str box_merge_mode='bayesian_inference', str cls_merge_mode='max_score', int draw_id=-1) "
+            "-> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_LIB.define("nms_cluster(Tensor boxes, Tensor scores, Tensor classes, float nms_thresh, int max_detections, int num_classes) -> Tensor")
+_LIB.define("reg_nll(Tensor means, Tensor covs, Tensor gt) -> Tensor")
+
+_PATHS = {}
+
+
+def _check_dense(name: str, ts: List[torch.Tensor], like: List[torch.Tensor]) -> None:
+    torch._check(len(ts) == len(like), lambda: "{}: {} levels, box_cls has {}".format(name, len(ts), len(like)))
+    for l, (t, ref) in enumerate(zip(ts, like)):
+        torch._check(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4, lambda: "{}[{}] must be a CUDA fp32 (runs, A*C, H, W) tensor".format(name, l))
+        torch._check(t.shape[0] == ref.shape[0] and tuple(t.shape[2:]) == tuple(ref.shape[2:]) and t.device == ref.device,
+                     lambda: "{}[{}]: shape {} does not match box_cls {}".format(name, l, tuple(t.shape), tuple(ref.shape)))
+
+
+def _predict(box_cls, box_delta, box_cls_var, box_reg_var, anchors, mode, image_size, out_size, num_classes=7, topk_candidates=1000,
+             score_thresh=0.05, nms_thresh=0.5, max_detections=100, cls_var_num_samples=10, affinity_thresh=0.9, merge_quirk=True,
+             box_merge_mode="bayesian_inference", cls_merge_mode="max_score", draw_id=-1) -> Tuple[torch.Tensor, ...]:
+    # (the dispatcher hands a Python kernel only the arguments the caller wrote: the schema's defaults are repeated here)
+    torch._check(len(box_cls) >= 1, lambda: "box_cls: at least one FPN level")
+    _check_dense("box_cls", box_cls, box_cls)
+    _check_dense("box_delta", box_delta, box_cls)
+    if box_cls_var:
+        _check_dense("box_cls_var", box_cls_var, box_cls)
+    if box_reg_var:
+        _check_dense("box_reg_var", box_reg_var, box_cls)
+    torch._check(len(anchors) == len(box_cls) and len(image_size) == 2 and len(out_size) == 2, lambda: "anchors per level; (h, w) sizes")
+    K = int(num_classes)
+    torch._check(box_cls[0].shape[1] % K == 0, lambda: "box_cls channels {} are not A * num_classes".format(box_cls[0].shape[1]))
+    A = box_cls[0].shape[1] // K
+    n_runs = int(box_cls[0].shape[0])
+    D = box_reg_var[0].shape[1] // A if box_reg_var else 0
+    dev = box_cls[0].device
+    shapes = tuple(tuple(t.shape[2:]) for t in box_cls)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (shapes, A, K, n_runs, bool(box_cls_var), D, str(dev), stream, topk_candidates, score_thresh, nms_thresh, max_detections,
+           cls_var_num_samples, affinity_thresh, merge_quirk)
+    hp = _PATHS.get(key)
+    if hp is None:      # one workspace per (geometry, stream), as the predictor keeps them
+        p = hotpath.PathParams(num_classes=K, num_anchors=A, topk_candidates=topk_candidates, score_thresh=score_thresh,
+                               nms_thresh=nms_thresh, max_detections=max_detections, cls_var_num_samples=cls_var_num_samples,
+                               affinity_thresh=affinity_thresh, merge_quirk=merge_quirk)
+        hp = _PATHS[key] = hotpath.HotPath(shapes, anchors, p, n_runs=n_runs, has_cls_var=bool(box_cls_var), cov_dims=D, device=dev)
+    with torch.cuda.device(dev):
+        det = hp.run(mode, list(box_cls), list(box_delta), list(box_cls_var) or None, list(box_reg_var) or None,
+                     image_size=tuple(image_size), out_size=tuple(out_size), box_merge_mode=box_merge_mode,
+                     cls_merge_mode=cls_merge_mode, draw_id=None if draw_id < 0 else int(draw_id))
+    m = det.count()      # the one host sync of an image (the operator returns exact-size tensors, like the reference)
+    return det.boxes[:m], det.cov[:m], det.scores[:m], det.classes[:m].long(), det.probs[:m]
+
+
+def _nms_cluster(boxes, scores, classes, nms_thresh, max_detections, num_classes) -> torch.Tensor:
+    torch._check(boxes.is_cuda and boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.shape[1] == 4, lambda: "boxes: CUDA fp32 (n, 4)")
+    n = int(boxes.shape[0])
+    torch._check(tuple(scores.shape) == (n,) and scores.dtype == torch.float32 and scores.device == boxes.device, lambda: "scores: fp32 (n,)")
+    torch._check(tuple(classes.shape) == (n,) and classes.device == boxes.device, lambda: "classes: (n,)")
+    torch._check(n <= hip.POD_MAX_CANDIDATES, lambda: "at most {} boxes".format(hip.POD_MAX_CANDIDATES))
+    lib, P = hip.load(), hip.ptr
+    cfg = hip.PodConfig()
+    cfg.max_detections, cfg.nms_thresh, cfg.num_classes = int(max_detections), float(nms_thresh), int(num_classes)
+    dev = boxes.device
+    with torch.cuda.device(dev):
+        cap = max(n, 1)
+        b = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
+        b[:n] = boxes
+        s, c = scores.contiguous(), classes.to(torch.int32).contiguous()
+        if n == 0:
+            s, c = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        keep = torch.empty(hip.POD_MAX_DETECTIONS, dtype=torch.int32, device=dev)
+        n_keep = torch.zeros(1, dtype=torch.int32, device=dev)
+        nt = torch.tensor([n], dtype=torch.int32, device=dev)
+        scratch = torch.zeros(lib.pod_nms_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        hip.check(lib.pod_nms_cluster(cfg, P(nt), cap, P(b), P(s), P(c), P(keep), P(n_keep), P(scratch), hip.current_stream()), "pod_nms_cluster")
+        return keep[:int(n_keep.item())].long()
+
+
+def _reg_nll(means, covs, gt) -> torch.Tensor:
+    n = int(means.shape[0])
+    for name, t, shape in (("means", means, (n, 4)), ("covs", covs, (n, 4, 4)), ("gt", gt, (n, 4))):
+        torch._check(t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == shape, lambda: "{}: CUDA fp32 {}".format(name, shape))
+    out = torch.empty(n, dtype=torch.float32, device=means.device)
+    with torch.cuda.device(means.device):
+        hip.check(hip.load().pod_reg_nll(hip.ptr(means.contiguous()), hip.ptr(covs.contiguous()), hip.ptr(gt.contiguous()), n, hip.ptr(out),
+                                         hip.current_stream()), "pod_reg_nll")
+    return out
+
+
+_IMPL = torch.library.Library("pod_mi355x", "IMPL")
+_IMPL.impl("predict", _predict, "CUDA")
+_IMPL.impl("nms_cluster", _nms_cluster, "CUDA")
+_IMPL.impl("reg_nll", _reg_nll, "CUDA")

@@ -249,3 +249,24 @@ def test_member_pipeline_keeps_two_images_in_flight(tmp_path, world, n_members, 
         else:
             assert all(kind == "merge" for kind, _ in log)
     assert sorted(merged) == list(range(num_images))
+
+
+def test_binary_sidecar_round_trip_equals_the_json_records(tmp_path):
+    """SURVEY f-2: the binary sidecar of coco_instances_results.json carries the same detections as the JSON file."""
+    K, md = 7, 128
+    g = torch.Generator().manual_seed(8)
+    ids = [5, 9, 12]
+    counts = torch.tensor([3, 0, 100], dtype=torch.int32)
+    rec = torch.randn(3, md, inference_utils.record_width(K), generator=g)
+    rec[:, :, 5] = torch.randint(0, K, (3, md), generator=g).float()
+    path = str(tmp_path / "results.podr")
+    inference_utils.write_binary_results(path, ids, counts, rec, K)
+    ids2, counts2, rec2, k2 = inference_utils.read_binary_results(path)
+    assert ids2 == ids and k2 == K and torch.equal(counts2, counts) and torch.equal(rec2, rec)
+    want = apply_net.results_json(ids, counts, rec, K, apply_net.BDD_CAT_MAP)
+    got = inference_utils.binary_results_to_json(path, apply_net.BDD_CAT_MAP)
+    assert got == want and len(got) == 103
+    assert os.path.getsize(path) < 0.35 * len(json.dumps(want, indent=4))          # ~4x smaller than the indented JSON
+    with pytest.raises(ValueError):
+        open(path, "r+b").write(b"XXXX")
+        inference_utils.read_binary_results(path)

@@ -1,0 +1,58 @@
+"""torch.ops.pod_mi355x.* (SURVEY 8b): the registered operators give exactly what the ctypes path gives, refuse CPU tensors
+and malformed arguments."""
+import os
+
+import pytest
+import torch
+
+import pod_compare_amd.torch_ops  # noqa: F401  (registers the library)
+from oracle import pod_oracle as po
+from tests.helpers import GOLDEN, Golden, assert_close
+from tests.test_hip_parity import make_path
+from tests.test_nms_gpu import clustered
+
+pytestmark = pytest.mark.gpu
+
+
+def test_predict_operator_equals_hotpath_and_reference_counts():
+    g = Golden(os.path.join(GOLDEN, "cfg3_bayes_od_mc10_s31.npz"))
+    ho = g.head_outputs().to("cuda")
+    image, out = list(g.meta["image"]), list(g.meta["out"])
+    b, c, s, k, p = torch.ops.pod_mi355x.predict(ho.cls, ho.delta, ho.cls_var, ho.reg_var, ho.anchors, "bayes_od", image, out, draw_id=4)
+    hp = make_path(ho)
+    det = hp.run("bayes_od", ho.cls, ho.delta, ho.cls_var, ho.reg_var, image_size=tuple(image), out_size=tuple(out), draw_id=4)
+    m = det.count()
+    assert b.shape == (m, 4) and c.shape == (m, 4, 4) and k.dtype == torch.int64 and p.shape == (m, 7)
+    assert torch.equal(b, det.boxes[:m]) and torch.equal(c, det.cov[:m]) and torch.equal(s, det.scores[:m])
+    assert torch.equal(k, det.classes[:m].long()) and torch.equal(p, det.probs[:m])
+    assert abs(m - g.t("pred_boxes").shape[0]) <= 1          # native draws: the reference's detections up to a threshold case
+    # a model without variance heads: empty lists
+    g1 = Golden(os.path.join(GOLDEN, "cfg4_anchor_stats_plain_s41.npz"))
+    h1 = g1.head_outputs().to("cuda")
+    b1, c1, s1, k1, p1 = torch.ops.pod_mi355x.predict(h1.cls, h1.delta, [], [], h1.anchors, "anchor_statistics", list(g1.meta["image"]),
+                                                      list(g1.meta["out"]), affinity_thresh=0.9)
+    assert torch.equal(k1.cpu(), g1.t("pred_classes"))
+    assert_close(b1.cpu(), g1.t("pred_boxes"), "boxes")
+    assert_close(c1.cpu(), g1.t("pred_boxes_covariance"), "cov")
+
+
+def test_nms_and_nll_operators():
+    boxes, scores, classes = clustered(1000, 5, (1344.0, 768.0))
+    keep = torch.ops.pod_mi355x.nms_cluster(boxes.cuda(), scores.cuda(), classes.cuda(), 0.5, 100, 3)
+    assert torch.equal(keep.cpu(), po.class_aware_nms(boxes, scores, classes.long(), 0.5)[:100])
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(50, 4, 4, generator=gen)
+    cov = a @ a.transpose(1, 2) + 0.1 * torch.eye(4)
+    means, gt = 100 * torch.rand(50, 4, generator=gen), 100 * torch.rand(50, 4, generator=gen)
+    nll = torch.ops.pod_mi355x.reg_nll(means.cuda(), cov.cuda(), gt.cuda())
+    assert_close(nll.cpu(), po.reg_nll(means, cov, gt), "nll", rtol=1e-5, atol=1e-4)
+
+
+def test_operators_reject_bad_arguments():
+    with pytest.raises(NotImplementedError):
+        torch.ops.pod_mi355x.reg_nll(torch.zeros(2, 4), torch.zeros(2, 4, 4), torch.zeros(2, 4))
+    with pytest.raises(RuntimeError):
+        torch.ops.pod_mi355x.reg_nll(torch.zeros(2, 4, device="cuda"), torch.zeros(2, 3, 3, device="cuda"), torch.zeros(2, 4, device="cuda"))
+    with pytest.raises(RuntimeError):
+        torch.ops.pod_mi355x.nms_cluster(torch.zeros(4, 4, device="cuda", dtype=torch.float64), torch.zeros(4, device="cuda"),
+                                         torch.zeros(4, device="cuda"), 0.5, 100, 3)
