@@ -97,9 +97,7 @@ __device__ __forceinline__ int level_offset(const K2Params& P, int l, int& total
     return off;
 }
 
-__device__ __forceinline__ void write_selection(const K2Params& P, const TopkLds& S, int l, int k, uint64_t* out) {
-    int total;
-    const int off = P.cat_keys ? level_offset(P, l, total) : 0;
+__device__ __forceinline__ void write_selection(const K2Params& P, const TopkLds& S, int l, int k, uint64_t* out, int off, int total) {
     for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
         const uint64_t key = S.keys[i];
         out[i] = key;
@@ -252,12 +250,14 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     uint64_t* keys = P.cand_keys + P.anchor_base[l];
     int32_t* ticket = P.cand_count + P.n_levels + l;
     const int C = P.cand_count[l];           // stays put: the gather kernel (K2b / K23) consumes (re-zeroes) the counts
+    int total = 0;
+    const int off = P.cat_keys ? level_offset(P, l, total) : 0;      // the other levels' counts: same round trip as C
     const int k = min(P.topk, C);
     uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
     if (C <= SORT_CAP) {
         if (b != 0) return;
         topk_into_lds<true>(S, [=](int i) { return keys[i]; }, C, k);
-        write_selection(P, S, l, k, out);
+        write_selection(P, S, l, k, out, off, total);
         return;
     }
     const int slice = ((C + TOPK_SLICES - 1) / TOPK_SLICES + 7) & ~7;      // keys per slice
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
         return r < min(SORT_CAP, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     };
     topk_into_lds<true>(S, survivors, TOPK_SLICES * SORT_CAP, k);
-    write_selection(P, S, l, k, out);
+    write_selection(P, S, l, k, out, off, total);
     if (tid == 0) *ticket = 0;
 }
 

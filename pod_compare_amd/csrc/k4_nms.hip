@@ -54,7 +54,7 @@ struct K4Params {
     int32_t* n_keep;
     int32_t* flag;        // scratch[0]: 1 = classes may interact, run the single-workgroup sweep
     int32_t* cls_count;   // scratch: POD_MAX_CLASSES survivor counts
-    int32_t* cls_keep;    // scratch: POD_MAX_CLASSES x NMS_LIST candidate indices, descending score within a class
+    uint64_t* cls_keys;   // scratch: POD_MAX_CLASSES x NMS_LIST (score, ~index) keys of a class's survivors, descending
     int32_t* gen;         // scratch[1]: call generation, bumped by k4_merge; tags the published survivor scores below
     uint64_t* pub;        // scratch: POD_MAX_CLASSES x NMS_LIST entries (gen << 32 | score bits) of the survivors found so far
 };
@@ -83,12 +83,33 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | (unsigned long long)uniform_u32((uint32_t)v);
 }
 
+// What a thread fetched for candidate `tid` in the kernel's FIRST round trip, before the candidate count was known
+// (row tid < n_capacity exists whatever n is): these kernels are chains of dependent HBM / L2 round trips with little
+// arithmetic in between, so the loads that do not depend on n travel with the load of n.
+struct NmsFirst {
+    float4 box;
+    float score;
+    int cls;
+    uint32_t gen;
+};
+
+__device__ __forceinline__ NmsFirst nms_first(const K4Params& P) {
+    NmsFirst f;
+    const int tid = threadIdx.x;
+    const bool in = tid < P.n_capacity;
+    f.box = in ? *reinterpret_cast<const float4*>(P.boxes + (size_t)tid * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    f.score = in ? P.scores[tid] : 0.0f;
+    f.cls = in ? P.classes[tid] : -1;
+    f.gen = P.gen ? (uint32_t)*P.gen : 0u;     // stable during k4_class_sweep: only k4_merge advances it
+    return f;
+}
+
 // coordinate extremes of the n candidate boxes (every thread returns the same values)
-__device__ NmsExtent nms_extent(NmsLds& S, const float* boxes, int n) {
+__device__ NmsExtent nms_extent(NmsLds& S, const float* boxes, int n, const NmsFirst& first) {
     const int tid = threadIdx.x;
     float mx = -INFINITY, nx1 = INFINITY, xx2 = -INFINITY, ny1 = INFINITY, xy2 = -INFINITY;
     for (int i = tid; i < n; i += NMS_THREADS) {
-        const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)i * 4);
+        const float4 b = i == tid ? first.box : *reinterpret_cast<const float4*>(boxes + (size_t)i * 4);
         mx = fmaxf(mx, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
         nx1 = fminf(nx1, b.x);
         ny1 = fminf(ny1, b.y);
@@ -121,9 +142,10 @@ __device__ NmsExtent nms_extent(NmsLds& S, const float* boxes, int n) {
 }
 
 // Greedy NMS of the members of `only_class` (or of every candidate when only_class < 0) by one workgroup.
-// Survivor candidate indices go to out_idx[0 .. *out_count), in descending (score, ~index) order, at most max_det.
-__device__ void nms_block(NmsLds& S, const K4Params& P, int n, float shift_unit, int only_class, int32_t* out_idx,
-                          int32_t* out_count) {
+// Survivors, in descending (score, ~index) order, at most max_det: candidate indices to out_idx and / or their keys to
+// out_keys (either may be null); the count to *out_count.
+__device__ void nms_block(NmsLds& S, const K4Params& P, int n, float shift_unit, int only_class, const NmsFirst& first,
+                          int32_t* out_idx, uint64_t* out_keys, int32_t* out_count) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t* const s_keys = reinterpret_cast<uint64_t*>(S.pool);                                            // first 64 KiB
     uint64_t* const s_sorted = reinterpret_cast<uint64_t*>(S.pool + POD_MAX_CANDIDATES * sizeof(uint64_t));  // rank-sort target
@@ -135,13 +157,13 @@ __device__ void nms_block(NmsLds& S, const K4Params& P, int n, float shift_unit,
     for (int base = 0; base < n; base += NMS_THREADS) {
         const int i = base + tid;
         int cls = -1;
-        if (i < n) cls = P.classes[i];
+        if (i < n) cls = base == 0 ? first.cls : P.classes[i];
         const bool mine = i < n && (only_class < 0 || cls == only_class);
         const unsigned long long mask = __ballot(mine);
         int at = 0;
         if (lane == 0 && mask) at = atomicAdd(&S.n_members, __popcll(mask));
         at = (int)uniform_u32((uint32_t)at);
-        if (mine) s_keys[at + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(P.scores[i], i);
+        if (mine) s_keys[at + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(base == 0 ? first.score : P.scores[i], i);
     }
     __syncthreads();
     const int m = S.n_members;
@@ -217,7 +239,7 @@ __device__ void nms_block(NmsLds& S, const K4Params& P, int n, float shift_unit,
     const int nwords = (m + 63) >> 6;
     int cur = -1, kept = 0;
     const bool publish = only_class >= 0 && P.pub != nullptr;
-    const uint32_t gen = publish ? (uint32_t)*P.gen : 0u;     // stable during this launch: only k4_merge advances it
+    const uint32_t gen = first.gen;
     while (true) {
         int next = -1;
         const int start = cur + 1;
@@ -253,9 +275,11 @@ __device__ void nms_block(NmsLds& S, const K4Params& P, int n, float shift_unit,
         }
         if (tid == 0) {
             const int idx = S.order[next];
-            out_idx[kept] = idx;
+            const float sc = P.scores[idx];
+            if (out_idx) out_idx[kept] = idx;
+            if (out_keys) out_keys[kept] = make_key(sc, idx);
             if (publish)
-                __hip_atomic_store(P.pub + only_class * NMS_LIST + kept, ((uint64_t)gen << 32) | __float_as_uint(P.scores[idx]),
+                __hip_atomic_store(P.pub + only_class * NMS_LIST + kept, ((uint64_t)gen << 32) | __float_as_uint(sc),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ++kept;
@@ -336,7 +360,9 @@ __device__ void nms_independence_check(NmsLds& S, const K4Params& P, int n, cons
 
 __global__ void __launch_bounds__(NMS_THREADS) k4_class_sweep(const K4Params P) {
     __shared__ NmsLds S;
-    const int n = min(*P.n_total, P.n_capacity);
+    const int n_raw = *P.n_total;
+    const NmsFirst first = nms_first(P);            // same round trip as the count
+    const int n = min(n_raw, P.n_capacity);
     const int c = blockIdx.x;
     if (n <= 0) {
         if (threadIdx.x == 0) {
@@ -345,47 +371,49 @@ __global__ void __launch_bounds__(NMS_THREADS) k4_class_sweep(const K4Params P) 
         }
         return;
     }
-    const NmsExtent e = nms_extent(S, P.boxes, n);
+    const NmsExtent e = nms_extent(S, P.boxes, n, first);
     const float shift_unit = e.max_all + 1.0f;
-    if (c < P.num_classes) nms_block(S, P, n, shift_unit, c, P.cls_keep + c * NMS_LIST, P.cls_count + c);
+    if (c < P.num_classes) nms_block(S, P, n, shift_unit, c, first, nullptr, P.cls_keys + c * NMS_LIST, P.cls_count + c);
     else nms_independence_check(S, P, n, e, shift_unit);
 }
 
 __global__ void __launch_bounds__(NMS_THREADS) k4_merge(const K4Params P) {
     __shared__ NmsLds S;
     const int tid = threadIdx.x;
-    const int n = min(*P.n_total, P.n_capacity);
+    // one round trip: the count, the interaction flag, the generation, the per-class survivor counts
+    const int n_raw = *P.n_total;
+    const int flag = *P.flag;
+    const int gen = P.gen ? *P.gen : 0;
+    const int my_cnt = (tid < 64 && tid < P.num_classes) ? P.cls_count[tid] : 0;
+    const int n = min(n_raw, P.n_capacity);
     if (n <= 0) {
         if (tid == 0) *P.n_keep = 0;
         return;
     }
-    if (tid == 0 && P.gen) *P.gen = *P.gen + 1;   // the next call's published scores carry a new tag (stale entries never match)
-    if (*P.flag) {   // classes may interact: the reference's sweep over the whole list, one workgroup
-        const NmsExtent e = nms_extent(S, P.boxes, n);
-        nms_block(S, P, n, e.max_all + 1.0f, -1, P.keep, P.n_keep);
+    if (tid == 0 && P.gen) *P.gen = gen + 1;   // the next call's published scores carry a new tag (stale entries never match)
+    if (flag) {   // classes may interact: the reference's sweep over the whole list, one workgroup
+        const NmsFirst first = nms_first(P);
+        const NmsExtent e = nms_extent(S, P.boxes, n, first);
+        nms_block(S, P, n, e.max_all + 1.0f, -1, first, P.keep, nullptr, P.n_keep);
         return;
     }
     // merge the per-class survivor lists: position = number of survivors with a larger (score, ~index) key
     uint64_t* const s_keys = reinterpret_cast<uint64_t*>(S.pool);
     int* const s_begin = reinterpret_cast<int*>(S.removed);   // POD_MAX_CLASSES + 1 ints
-    if (tid < 64) {   // the counts are independent loads (one round trip), the prefix a wavefront scan
-        const int cnt = tid < P.num_classes ? P.cls_count[tid] : 0;
-        int incl = cnt;
+    if (tid < 64) {   // prefix of the counts by a wavefront scan
+        int incl = my_cnt;
 #pragma unroll
         for (int o = 1; o < POD_MAX_CLASSES; o <<= 1) {
             const int up = __shfl_up(incl, o, 64);
             if (tid >= o) incl += up;
         }
-        if (tid <= P.num_classes) s_begin[tid] = incl - cnt;       // entry num_classes = total (cnt = 0 there)
+        if (tid <= P.num_classes) s_begin[tid] = incl - my_cnt;    // entry num_classes = total (its count is 0)
     }
     __syncthreads();
     const int total = s_begin[P.num_classes];
     for (int c = 0; c < P.num_classes; ++c) {
         const int cnt = s_begin[c + 1] - s_begin[c];
-        if (tid < cnt) {
-            const int idx = P.cls_keep[c * NMS_LIST + tid];
-            s_keys[s_begin[c] + tid] = make_key(P.scores[idx], idx);
-        }
+        if (tid < cnt) s_keys[s_begin[c] + tid] = P.cls_keys[c * NMS_LIST + tid];   // the sweeps left keys: no score gather
     }
     __syncthreads();
     for (int q = tid; q < total; q += NMS_THREADS) {
@@ -402,7 +430,7 @@ __global__ void __launch_bounds__(NMS_THREADS) k4_merge(const K4Params P) {
 extern "C" size_t pod_nms_scratch_bytes(int32_t n_capacity) {
     if (n_capacity < 1) return 0;
     // flag + generation, counts, per-class survivor lists, published survivor scores
-    return 256 + sizeof(int32_t) * (size_t)POD_MAX_CLASSES * pod::NMS_LIST + sizeof(uint64_t) * (size_t)POD_MAX_CLASSES * pod::NMS_LIST;
+    return 256 + 2 * sizeof(uint64_t) * (size_t)POD_MAX_CLASSES * pod::NMS_LIST;
 }
 
 extern "C" int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capacity, const float* boxes,
@@ -421,8 +449,8 @@ extern "C" int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int
     P.flag = s;
     P.gen = s + 1;
     P.cls_count = s + 16;
-    P.cls_keep = s + 64;
-    P.pub = reinterpret_cast<uint64_t*>(s + 64 + POD_MAX_CLASSES * pod::NMS_LIST);
+    P.cls_keys = reinterpret_cast<uint64_t*>(s + 64);
+    P.pub = P.cls_keys + POD_MAX_CLASSES * pod::NMS_LIST;
     hipLaunchKernelGGL(pod::k4_class_sweep, dim3(cfg->num_classes + 1), dim3(pod::NMS_THREADS), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     hipLaunchKernelGGL(pod::k4_merge, dim3(1), dim3(pod::NMS_THREADS), 0, (hipStream_t)stream, P);

@@ -233,6 +233,7 @@ struct K5Params {
     const int32_t* classes;
     const float* probs;
     int32_t K, box_mode, cls_mode, n_capacity;
+    int32_t n_alloc;       // rows the candidate arrays really hold (speculative first loads stay inside)
     float aff;
     float* out_boxes;
     float* out_cov;
@@ -247,34 +248,47 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
     __shared__ double s_red[4 * 40];
     __shared__ int s_flag[POD_MAX_DETECTIONS];
     const int c = blockIdx.x;
+    const int tid = threadIdx.x;
+    // Round trip 1 -- everything that does not depend on the centre, issued together: the two counts, this cluster's
+    // centre index (keep[] has a slot for every workgroup of the grid) and the first two candidate boxes of this thread.
+    // The kernel is a chain of HBM / L2 round trips with a few hundred instructions in between: what counts is how many.
     const int n_live = *P.n_keep;
+    const int n_raw = *P.n_total;
+    const int ctr = P.keep[c];
+    Box pre[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = tid + q * 256;
+        pre[q] = j < P.n_alloc ? load_box(P.boxes, j) : Box{0.f, 0.f, 0.f, 0.f};
+    }
     if (c >= n_live) {
-        if (P.ticket && c == 0 && threadIdx.x == 0) *P.fin.n_det = 0;   // nothing kept: nobody else writes the count
+        if (P.ticket && c == 0 && tid == 0) *P.fin.n_det = 0;   // nothing kept: nobody else writes the count
         return;
     }
-    const int n = min(*P.n_total, P.n_capacity);
+    const int n = min(n_raw, P.n_capacity);
     const int K = P.K;
-    const int ctr = P.keep[c];
+    // round trip 2 -- the centre
     const Box bc = load_box(P.boxes, ctr);
     const int ccls = argmax_probs(P.probs + (size_t)ctr * K, K);     // PI:578-579
-    const int tid = threadIdx.x;
 
     // pass A: total precision, precision-weighted mean, member count, prob sums
     double acc[16 + 4 + 2 + POD_MAX_CLASSES];   // [0,16) sum of precisions, [16,20) sum P mu, [20] same-class members, [21] IoU members, [22,..) prob sums
 #pragma unroll
     for (int q = 0; q < 22 + POD_MAX_CLASSES; ++q) acc[q] = 0.0;
-    for (int j = tid; j < n; j += 256) {
-        const Box bj = load_box(P.boxes, j);
+    for (int j = tid, it = 0; j < n; j += 256, ++it) {
+        const Box bj = it == 0 ? pre[0] : (it == 1 ? pre[1] : load_box(P.boxes, j));
         if (!(iou_pair(bc, bj) > P.aff)) continue;                    // PI:565-566
+        // round trip 3 -- the members' probabilities and covariances (a handful of rows per cluster)
         if (P.cls_mode == 1) {                                        // PI:583-585: mean over ALL IoU members
 #pragma unroll
             for (int k = 0; k < POD_MAX_CLASSES; ++k)             // static indices: the accumulators stay in registers
                 if (k < K) acc[22 + k] += (double)P.probs[(size_t)j * K + k];
             acc[21] += 1.0;
         }
+        M4 cv;
+        load_m4(P.cov + (size_t)j * 16, cv);                          // issued with the probability loads of argmax_probs
         if (argmax_probs(P.probs + (size_t)j * K, K) != ccls) continue;   // PI:580-582
-        M4 cv, pr;
-        load_m4(P.cov + (size_t)j * 16, cv);
+        M4 pr;
         inv4(cv, pr);                                                 // IU:306
         const double mu[4] = {bj.x1, bj.y1, bj.x2, bj.y2};
 #pragma unroll
@@ -388,6 +402,8 @@ struct K6Params {
     const int32_t* classes;
     const float* probs;
     int32_t K, n_capacity;
+    int32_t n_alloc;         // rows the candidate arrays really hold (speculative first loads stay inside)
+    int32_t n_keep_alloc;    // entries of keep[]
     int32_t ensemble_rule;   // 0: anchor statistics (IoU > aff, IU:102 singleton rule); 1: black-box ensembles (IoU >= aff, IU:211-247)
     float aff;
     float* out_boxes;
@@ -403,17 +419,27 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
     __shared__ double s_red[4 * 40];
     __shared__ int s_flag[POD_MAX_DETECTIONS];
     const int c = blockIdx.x;
+    const int tid = threadIdx.x;
+    // round trip 1: counts, centre index, this thread's first two candidate boxes and classes (see k5_bayes_fuse)
     const int n_live = *P.n_keep;
+    const int n_raw = *P.n_total;
+    const int ctr = c < P.n_keep_alloc ? P.keep[c] : 0;
+    Box pre[2];
+    int pre_cls[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = tid + q * 256;
+        pre[q] = j < P.n_alloc ? load_box(P.boxes, j) : Box{0.f, 0.f, 0.f, 0.f};
+        pre_cls[q] = j < P.n_alloc ? P.classes[j] : -1;
+    }
     if (c >= n_live) {
-        if (P.ticket && c == 0 && threadIdx.x == 0) *P.fin.n_det = 0;
+        if (P.ticket && c == 0 && tid == 0) *P.fin.n_det = 0;
         return;
     }
-    const int n = min(*P.n_total, P.n_capacity);
+    const int n = min(n_raw, P.n_capacity);
     const int K = P.K;
-    const int ctr = P.keep[c];
     const Box bc = load_box(P.boxes, ctr);
     const int ccls = P.classes[ctr];                                 // IU:104
-    const int tid = threadIdx.x;
     const bool has_cov = P.cov != nullptr;
 
     // pass 1: member counts, box sum, prob sum, covariance sum of same-class members
@@ -421,12 +447,13 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
 #pragma unroll
     for (int q = 0; q < 22 + POD_MAX_CLASSES; ++q) acc[q] = 0.0;
     const bool ens = P.ensemble_rule != 0;
-    for (int j = tid; j < n; j += 256) {
-        const Box bj = load_box(P.boxes, j);
+    for (int j = tid, it = 0; j < n; j += 256, ++it) {
+        const Box bj = it == 0 ? pre[0] : (it == 1 ? pre[1] : load_box(P.boxes, j));
         const float iou = iou_pair(bc, bj);
         if (!(ens ? iou >= P.aff : iou > P.aff)) continue;            // IU:91-92 (>) / IU:211-212 (>=)
         acc[0] += 1.0;                                                // IU:102 counts every IoU member
-        if (P.classes[j] != ccls) continue;                           // IU:104-106
+        const int cj = it == 0 ? pre_cls[0] : (it == 1 ? pre_cls[1] : P.classes[j]);
+        if (cj != ccls) continue;                                     // IU:104-106
         acc[1] += 1.0;
         acc[2] += bj.x1; acc[3] += bj.y1; acc[4] += bj.x2; acc[5] += bj.y2;
 #pragma unroll
@@ -632,7 +659,7 @@ extern "C" int pod_bayes_fuse(const PodConfig* cfg, const int32_t* n_total, cons
     pod::K5Params P;
     P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.scores = scores;
     P.classes = classes; P.probs = probs; P.K = cfg->num_classes; P.box_mode = box_mode; P.cls_mode = cls_mode;
-    P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh;
+    P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.n_alloc = cfg->n_levels * cfg->topk;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
     P.ticket = nullptr; P.fin = pod::K7Params{};
     hipLaunchKernelGGL(pod::k5_bayes_fuse, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
@@ -665,7 +692,7 @@ extern "C" int pod_bayes_fuse_finalize(const PodConfig* cfg, const int32_t* n_to
     pod::K5Params P;
     P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.scores = scores;
     P.classes = classes; P.probs = probs; P.K = cfg->num_classes; P.box_mode = box_mode; P.cls_mode = cls_mode;
-    P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh;
+    P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.n_alloc = cfg->n_levels * cfg->topk;
     P.out_boxes = m_boxes; P.out_cov = m_cov; P.out_scores = m_scores; P.out_classes = m_classes; P.out_probs = m_probs;
     P.ticket = ticket;
     if (!fill_finalize(P.fin, cfg, n_keep, m_boxes, m_cov, m_scores, m_classes, m_probs, scale_x, scale_y, out_h, out_w, out)) return POD_E_INVALID;
@@ -686,6 +713,7 @@ extern "C" int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_tot
     pod::K6Params P;
     P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
     P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.ensemble_rule = 0;
+    P.n_alloc = cfg->n_levels * cfg->topk; P.n_keep_alloc = cfg->max_detections;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
     P.ticket = nullptr; P.fin = pod::K7Params{};
     hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
@@ -706,6 +734,7 @@ extern "C" int pod_anchor_stats_finalize(const PodConfig* cfg, const int32_t* n_
     pod::K6Params P;
     P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
     P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.ensemble_rule = 0;
+    P.n_alloc = cfg->n_levels * cfg->topk; P.n_keep_alloc = cfg->max_detections;
     P.out_boxes = m_boxes; P.out_cov = m_cov; P.out_scores = m_scores; P.out_classes = m_classes; P.out_probs = m_probs;
     P.ticket = ticket;
     if (!fill_finalize(P.fin, cfg, n_keep, m_boxes, m_cov, m_scores, m_classes, m_probs, scale_x, scale_y, out_h, out_w, out)) return POD_E_INVALID;
@@ -745,6 +774,7 @@ extern "C" int pod_ensemble_merge(const PodConfig* cfg, const int32_t* m_total, 
     pod::K6Params P;
     P.n_total = m_total; P.keep = seeds; P.n_keep = n_seeds; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
     P.K = cfg->num_classes; P.n_capacity = capacity; P.aff = cfg->affinity_thresh; P.ensemble_rule = 1;
+    P.n_alloc = capacity; P.n_keep_alloc = capacity;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
     P.ticket = nullptr; P.fin = pod::K7Params{};
     hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(capacity), dim3(256), 0, (hipStream_t)stream, P);

@@ -1,24 +1,44 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel trace of bench.py + separate PMC passes for K1.
-#   tools/profile_round.sh r01     -> gpurun_out/prof_<tag>/...   (copy the summaries into profiles/ afterwards)
+# Runs on the GPU box (via gpurun): the round's rocprofv3 evidence.
+#   tools/profile_round.sh r02     -> gpurun_out/prof_<tag>/...   (then: python tools/summarize_profile.py <tag> -> profiles/<tag>_*)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
-# (1) per-kernel time of the same command the bench line comes from (hot path only, so the trace stays small)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hotpath -o hp -- python bench.py --no-cnn --steps 40 --no-cpu-baseline > $OUT/bench_hotpath.json 2> $OUT/bench_hotpath.err
-# (2) the headline command (conv net in the timed region)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -o full -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_full.json 2> $OUT/bench_full.err
-# (2b) the same with one stream: per-kernel durations are only meaningful when kernels of different images do not overlap
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full1 -o full1 -- python bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline > $OUT/bench_full_streams1.json 2> $OUT/bench_full_streams1.err
-python tools/steady_state.py $OUT/full1/full1_kernel_trace.csv 8 6 > $OUT/steady_state.txt 2>&1
-# (3) HBM traffic of K1: separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
+mkdir -p "$OUT"
+stats() {   # name, command...: rocprofv3 --kernel-trace --stats, keep the stats csv (+ the trace when KEEP_TRACE=1)
+  local name=$1; shift
+  local dir="gpurun_out/prof_${TAG}/raw_${name}"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$dir" -o p -- "$@" > "$OUT/$name.out" 2> "$OUT/$name.err"
+  cp "$(find "$dir" -name '*kernel_stats.csv' | head -1)" "$OUT/${name}_kernel_stats.csv" 2>/dev/null
+  if [ "${KEEP_TRACE:-0}" = "1" ]; then cp "$(find "$dir" -name '*kernel_trace.csv' | head -1)" "$OUT/${name}_kernel_trace.csv" 2>/dev/null; fi
+  find "$dir" -type f -delete
+}
+# (1) K1 alone, ONE variant per run (>= 100 launches each): the table row whose average reproduces `roofline` by itself
+stats k1_class python tools/k1_only.py 120
+K1_DENSE=1 stats k1_dense python tools/k1_only.py 120
+python tools/k1_only.py 120 > "$OUT/k1_events.txt" 2>&1
+K1_DENSE=1 python tools/k1_only.py 120 >> "$OUT/k1_events.txt" 2>&1
+# (2) HBM traffic of K1: separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2), no trace domains
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
-  K1_DENSE=1 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_dense_$c -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
+  K1_DENSE=1 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_dense_$c" -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ -o p -- python tools/k1_only.py 12 > /dev/null 2>&1
-python tools/k1_only.py 60 > $OUT/k1_events.txt 2>&1
-K1_DENSE=1 python tools/k1_only.py 60 >> $OUT/k1_events.txt 2>&1
-ls -R $OUT | head -40
+# (3) the hot path alone, one stream: per-kernel stats + one-image timelines, planted and worst-case inputs
+for synth in planted worst; do
+  KEEP_TRACE=1 stats hot_$synth python bench.py --no-cnn --streams 1 --steps 100 --warmup 10 --synth $synth --no-cpu-baseline --no-diagnostics
+  python tools/trace_timeline.py "$OUT/hot_${synth}_kernel_trace.csv" > "$OUT/hot_${synth}_timeline.txt" 2>&1
+  rm -f "$OUT/hot_${synth}_kernel_trace.csv"
+done
+# (4) the headline command on one stream (per-kernel durations are only meaningful when images do not overlap): steady state
+KEEP_TRACE=1 stats full1 python bench.py --steps 10 --warmup 3 --streams 1 --no-cpu-baseline --no-diagnostics
+python tools/steady_state.py "$OUT/full1_kernel_trace.csv" 8 6 > "$OUT/steady_state.txt" 2>&1
+rm -f "$OUT/full1_kernel_trace.csv"
+# (5) bench lines: the default command (200 timed steps after 20 warm-up), the driver's shape, the other single-GPU configs,
+#     the 2-rank functional check and config 5 with one member per rank (all ranks on this one GPU, gloo)
+python bench.py > "$OUT/bench_default_200steps.json" 2> "$OUT/bench_default.err"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_20steps.json" 2>> "$OUT/bench_default.err"
+for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_$c.json" 2>> "$OUT/bench_default.err"; done
+POD_BENCH_BACKEND=gloo POD_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-diagnostics > "$OUT/bench_gloo2_shared_gpu.json" 2>> "$OUT/bench_default.err"
+POD_BENCH_BACKEND=gloo POD_BENCH_SHARE_GPU=1 python bench.py --gpus 6 --config cfg5 --ensemble-per-gpu --steps 12 --warmup 2 > "$OUT/bench_cfg5_gloo6_shared_gpu.json" 2>> "$OUT/bench_default.err"
+ls "$OUT"

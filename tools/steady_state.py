@@ -1,7 +1,7 @@
 """Per-image kernel time in the steady state of `bench.py` (conv net + hot path) from a rocprofv3 kernel trace:
     rocprofv3 --kernel-trace --output-format csv -d DIR -o full -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline
     python tools/steady_state.py DIR/full_kernel_trace.csv [images] [first]
-Images are delimited by k7_finalize (the last kernel of an image).  bench.py runs 2 x streams priming images, W warm-up images,
+Images are delimited by K1 (pod_mc_merge_score's kernel: the first hot-path kernel of an image, right after its conv net).  bench.py runs 2 x streams priming images, W warm-up images,
 K timed images, then hot-path-only loops: `first` (default 2*3 + 3 + 1; 2*1 + 3 + 1 = 6 for --streams 1) skips to the timed region and `images` of them are
 aggregated (with several streams the kernels of neighbouring images interleave; the aggregate is what matters)."""
 import csv, collections, sys
@@ -9,7 +9,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-idx = [i for i, r in enumerate(rows) if "k7_finalize" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]]
+# K1 of image j comes AFTER image j's conv net: the span between K1 of image first-1 and K1 of image first-1+n covers n
+# hot-path tails + n conv nets
 a, b = idx[first - 1], idx[first - 1 + n]
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows[a + 1:b + 1]:

@@ -1,50 +1,46 @@
-"""Condenses a tools/profile_round.sh output directory into profiles/<tag>_*.md|csv (tracked)."""
+"""Condenses a tools/profile_round.sh output directory into profiles/<tag>_* (tracked)."""
 import collections, csv, glob, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = "gpurun_out/prof_%s" % tag
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 lines = ["# rocprofv3 summary, round tag %s" % tag, ""]
 
+
 def short(n):
     n = n.replace("void ", "")
     return (n[:110] + "...") if len(n) > 113 else n
 
-for name, title in (("hotpath/hp", "`rocprofv3 --kernel-trace --stats -- python bench.py --no-cnn --steps 40 --no-cpu-baseline`"),
-                    ("full/full", "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline`")):
-    f = glob.glob(os.path.join(src, name + "*kernel_stats.csv"))
-    if not f:
-        continue
-    rows = list(csv.DictReader(open(f[0])))
-    lines += ["## " + title, "", "| kernel | calls | avg us | min us | max us | total ms | % |", "|---|---|---|---|---|---|---|"]
-    for r in rows[:22]:
+
+def table(name, title, only_pod=False, top=24):
+    f = os.path.join(src, name + "_kernel_stats.csv")
+    if not os.path.exists(f):
+        return
+    rows = [r for r in csv.DictReader(open(f)) if not only_pod or "pod::" in r["Name"]]
+    lines.extend(["## " + title, "", "| kernel | calls | avg us | min us | max us | total ms | % |", "|---|---|---|---|---|---|---|"])
+    for r in rows[:top]:
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
-    if any("naive_conv" in r["Name"] for r in rows[:22]):
-        lines += ["", "(`naive_conv_*` and most of the first rows are MIOpen's find pass on the first images -- every solver is tried once per",
-                  "conv shape and stream, including the naive reference kernel -- not the steady state; with 3 streams the durations of",
-                  "overlapping kernels also stretch.  The steady-state table below is the per-kernel breakdown.)"]
     lines.append("")
-    out = os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name.split("/")[0]))
-    with open(out, "w") as fo:
+    with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)), "w") as fo:
         w = csv.writer(fo)
         w.writerow(rows[0].keys())
         for r in rows[:40]:
             w.writerow([short(v) if k == "Name" else v for k, v in r.items()])
-ss = os.path.join(src, "steady_state.txt")
-if os.path.exists(ss):
-    lines += ["## steady state per image, one stream (`bench.py --steps 10 --warmup 3 --streams 1`, `tools/steady_state.py`)", ""]
-    lines += [l.rstrip() for l in open(ss) if "amdgpu" not in l] + [""]
-for j in ("bench_hotpath.json", "bench_full.json", "bench_full_streams1.json"):
-    p = os.path.join(src, j)
-    if os.path.exists(p):
-        txt = [l for l in open(p) if l.startswith("{")]
-        if txt:
-            lines += ["## bench line (%s)" % j, "", "```json", txt[-1].strip(), "```", ""]
+
+
+table("k1_class", "K1 alone, product configuration (2K class channels): `rocprofv3 --kernel-trace --stats -- python tools/k1_only.py 120`", True)
+table("k1_dense", "K1 alone, dense merge of all 2K+4+D channels: `K1_DENSE=1 rocprofv3 --kernel-trace --stats -- python tools/k1_only.py 120`", True)
+ev = os.path.join(src, "k1_events.txt")
+if os.path.exists(ev):
+    lines += ["K1 alone, HIP events per launch (`python tools/k1_only.py 120`, class channels then `K1_DENSE=1`):", "", "```"] + \
+             [l.rstrip() for l in open(ev) if "events" in l or "counts" in l] + ["```", ""]
+
+
 def k1_counters(prefix):
     pm = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
-        f = glob.glob(os.path.join(src, "pmc_%s%s" % (prefix, c), "*counter_collection.csv"))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob(os.path.join(src, "pmc_%s%s" % (prefix, c), "**", "*counter_collection.csv"), recursive=True)
         if not f:
             continue
         agg = collections.defaultdict(list)
@@ -54,6 +50,7 @@ def k1_counters(prefix):
         for k, v in agg.items():
             pm[k] = (sum(v) / len(v), min(v), max(v), len(v))
     return pm
+
 
 traffic = {"workload": {"anchors_R": 193374, "mc_runs": 10, "config": "cfg3", "synthetic_mode": "planted"},
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/k1_only.py 12; FETCH_SIZE x2 (gfx950)"}
@@ -78,8 +75,39 @@ for prefix, key, what in (("", "k1_class_traffic_bytes", "product path: K1 strea
         traffic[key.replace("traffic_bytes", "write_bytes")] = write_b
 if len(traffic) > 2:
     json.dump(traffic, open(os.path.join(dst, "%s_k1_traffic.json" % tag), "w"))
-ev = os.path.join(src, "k1_events.txt")
-if os.path.exists(ev):
-    lines += ["## K1 alone, HIP events (`python tools/k1_only.py 60`)", "", "```"] + [l.rstrip() for l in open(ev) if "events" in l or "counts" in l] + ["```", ""]
+
+for synth in ("planted", "worst"):
+    table("hot_" + synth, "hot path alone, one stream, %s inputs: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cnn --streams 1 "
+          "--steps 100 --warmup 10 --synth %s --no-cpu-baseline --no-diagnostics`" % (synth, synth), True)
+    tl = os.path.join(src, "hot_%s_timeline.txt" % synth)
+    if os.path.exists(tl):
+        body = [l.rstrip() for l in open(tl)]
+        starts = [i for i, l in enumerate(body) if l.startswith("image")]
+        if starts:
+            lines += ["one image of that trace (start offset / duration / gap to the previous kernel, us; `tools/trace_timeline.py`):", "", "```"] + \
+                     body[starts[-1]:] + ["```", ""]
+            open(os.path.join(dst, "%s_hot_%s_timeline.txt" % (tag, synth)), "w").write("\n".join(body[starts[-1]:]) + "\n")
+ss = os.path.join(src, "steady_state.txt")
+if os.path.exists(ss):
+    txt = [l.rstrip() for l in open(ss) if "amdgpu" not in l]
+    lines += ["## steady state per image, conv net + hot path, one stream (`bench.py --steps 10 --warmup 3 --streams 1`, `tools/steady_state.py`)", ""] + txt + [""]
+    open(os.path.join(dst, "%s_steady_state.txt" % tag), "w").write("\n".join(txt) + "\n")
+bench = []
+for j in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+    txt = [l for l in open(j) if l.startswith("{")]
+    if txt:
+        bench.append(json.dumps({"file": os.path.basename(j), "line": json.loads(txt[-1])}))
+if bench:
+    open(os.path.join(dst, "%s_bench_lines.jsonl" % tag), "w").write("\n".join(bench) + "\n")
+    lines += ["## bench lines (`profiles/%s_bench_lines.jsonl`)" % tag, "",
+              "| file | n_gpus | value | unit | ms/step | hot path ms | worst ms | K1 frac | conv frac |", "|---|---|---|---|---|---|---|---|---|"]
+    for b in bench:
+        d = json.loads(b)
+        l = d["line"]
+        f = lambda x: "" if x is None else ("%.4g" % x)
+        lines.append("| %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (d["file"], l.get("n_gpus"), f(l.get("value")), l.get("unit"), f(l.get("ms_per_step")),
+                     f(l.get("hot_path_ms_per_image")), f(l.get("hot_path_worst_ms")), f((l.get("roofline") or {}).get("frac")),
+                     f((l.get("conv_roofline") or {}).get("frac"))))
+    lines.append("")
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
-print("\n".join(lines[:60]))
+print("\n".join(lines[:80]))
