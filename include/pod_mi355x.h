@@ -105,7 +105,7 @@ int pod_abi_version(void);
  * mean_* : dev, level-concatenated plane layout: level l starts at anchor_base_l * C elements.
  * cand_keys : dev uint64[R_total], level l's list starts at anchor_base_l.
  * cand_count: dev int32[2 * n_levels] (counts, then pod_level_topk's tickets), MUST be zero on entry
- *             (pod_reset_counters once after allocation; pod_level_topk leaves it zeroed again).
+ *             (pod_reset_counters once after allocation; pod_gather_candidates / pod_gather_decode leave it zeroed again).
  * HBM-bound; algorithmic bytes per image = 4 * R * (2K + 4 + D) * (N + 1)  (SURVEY 8d). */
 int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
                        float* mean_cls, float* mean_cls_var, float* mean_delta, float* mean_reg_var,
@@ -261,26 +261,9 @@ int pod_finalize(const PodConfig* cfg, const int32_t* keep, const int32_t* n_row
                  float* det_boxes, float* det_cov, float* det_scores, int32_t* det_classes, float* det_probs,
                  float* records, int32_t* n_det, pod_stream_t stream);
 
-/* ---- K5 + K7 / K6 + K7 in one launch -------------------------------------------------------------
- * pod_bayes_fuse / pod_anchor_stats_merge followed by pod_finalize(keep = NULL) on their outputs, same results bit for
- * bit, without the dependent launch: every cluster workgroup writes its merged row to the staging arrays m_*
- * (max_detections rows each, caller-owned scratch), publishes it (device-scope release) and takes a ticket; the workgroup
- * that draws the last ticket runs the K7 body over all rows with device-scope loads.  Nothing spins.
- * ticket : dev int32, ZERO on entry (pod_reset_counters once after allocation), left zero. */
 typedef struct PodDetections {     /* pod_finalize's outputs */
     float* boxes;  float* cov;  float* scores;  int32_t* classes;  float* probs;  float* records;  int32_t* n_det;
 } PodDetections;
-int pod_bayes_fuse_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
-                            const float* boxes, const float* cov, const float* scores, const int32_t* classes,
-                            const float* probs, int32_t box_mode, int32_t cls_mode,
-                            float* m_boxes, float* m_cov, float* m_scores, int32_t* m_classes, float* m_probs,
-                            int32_t* ticket, float scale_x, float scale_y, float out_h, float out_w,
-                            const PodDetections* out, pod_stream_t stream);
-int pod_anchor_stats_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
-                              const float* boxes, const float* cov, const int32_t* classes, const float* probs,
-                              float* m_boxes, float* m_cov, float* m_scores, int32_t* m_classes, float* m_probs,
-                              int32_t* ticket, float scale_x, float scale_y, float out_h, float out_w,
-                              const PodDetections* out, pod_stream_t stream);
 
 /* ---- conv-net side: fused ReLU + dropout -------------------------------------------------------
  * Replaces: the `nn.ReLU(), nn.Dropout(p)` pair after every 3x3 conv of the head subnets (PR:403-424) in
@@ -345,7 +328,7 @@ int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids,
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
  * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence
  *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_decode (= pod_gather_candidates + pod_decode_cov)
- *   -> pod_nms_cluster -> {pod_bayes_fuse_finalize | pod_anchor_stats_finalize | pod_finalize}
+ *   -> pod_nms_cluster -> {pod_bayes_fuse | pod_anchor_stats_merge | -} -> pod_finalize
  * enqueued from C on `stream`, in-kernel Philox draws (levels[].eps_cls must be NULL: the eps-replay parity
  * mode needs the host between launches and uses the individual entry points).  Nothing here
  * synchronises or allocates; the workspace is caller-owned, every pointer is device memory sized as the
@@ -364,7 +347,6 @@ typedef struct PodWorkspace {
     float* boxes;  float* cov;
     int32_t* keep;  int32_t* n_keep;  void* nms_scratch;
     float* m_boxes;  float* m_cov;  float* m_scores;  int32_t* m_classes;  float* m_probs;
-    int32_t* cluster_ticket;       /* int32, zero on entry, left zero (pod_bayes_fuse_finalize / pod_anchor_stats_finalize) */
     int32_t n_capacity;  int32_t reserved;
 } PodWorkspace;
 

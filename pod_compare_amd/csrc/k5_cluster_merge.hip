@@ -111,20 +111,8 @@ struct K7Params {
     int32_t* n_det;
 };
 
-// COHERENT: the rows were written by OTHER workgroups of this launch (the fused K5/K6 + K7 kernels): read them with
-// device-scope loads, past this CU's L1 and this XCD's L2 (the 8 L2s are not coherent with each other).
-template <bool COHERENT>
-__device__ __forceinline__ float ld_row(const float* p) {
-    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COHERENT>
-__device__ __forceinline__ int32_t ld_row(const int32_t* p) {
-    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
 // K7 body: thread t < POD_MAX_DETECTIONS owns input row t; every thread of the workgroup must call it (one barrier).
 // s_flag: POD_MAX_DETECTIONS ints of LDS.
-template <bool COHERENT>
 __device__ __forceinline__ void finalize_rows(const K7Params& P, int t, int rows, int* s_flag) {
     const int K = P.K;
     const bool live = t < rows && t < POD_MAX_DETECTIONS;
@@ -133,10 +121,10 @@ __device__ __forceinline__ void finalize_rows(const K7Params& P, int t, int rows
     if (live) {
         const float* b = P.boxes + (size_t)src * 4;
         // Boxes.scale (IU:402) then Boxes.clip (IU:403)
-        x1 = fminf(fmaxf(ld_row<COHERENT>(b + 0) * P.sx, 0.0f), P.out_w);
-        y1 = fminf(fmaxf(ld_row<COHERENT>(b + 1) * P.sy, 0.0f), P.out_h);
-        x2 = fminf(fmaxf(ld_row<COHERENT>(b + 2) * P.sx, 0.0f), P.out_w);
-        y2 = fminf(fmaxf(ld_row<COHERENT>(b + 3) * P.sy, 0.0f), P.out_h);
+        x1 = fminf(fmaxf(*(b + 0) * P.sx, 0.0f), P.out_w);
+        y1 = fminf(fmaxf(*(b + 1) * P.sy, 0.0f), P.out_h);
+        x2 = fminf(fmaxf(*(b + 2) * P.sx, 0.0f), P.out_w);
+        y2 = fminf(fmaxf(*(b + 3) * P.sy, 0.0f), P.out_h);
     }
     const bool ok = live && ((x2 - x1) > 0.0f) && ((y2 - y1) > 0.0f);   // Boxes.nonempty (IU:404)
     // output row = number of non-empty rows before this one: ballots, not a walk over LDS flags (thread 127 paid 127
@@ -150,15 +138,15 @@ __device__ __forceinline__ void finalize_rows(const K7Params& P, int t, int rows
     if (t == 0) *P.n_det = s_flag[0] + s_flag[1];
     if (!ok) return;
     *reinterpret_cast<float4*>(P.det_boxes + (size_t)pos * 4) = float4{x1, y1, x2, y2};
-    const float score = ld_row<COHERENT>(P.scores + src);
-    const int32_t cls = ld_row<COHERENT>(P.classes + src);
+    const float score = *(P.scores + src);
+    const int32_t cls = *(P.classes + src);
     P.det_scores[pos] = score;
     P.det_classes[pos] = cls;
     float pr[POD_MAX_CLASSES];
 #pragma unroll
     for (int k = 0; k < POD_MAX_CLASSES; ++k)
         if (k < K) {
-            pr[k] = ld_row<COHERENT>(P.probs + (size_t)src * K + k);
+            pr[k] = *(P.probs + (size_t)src * K + k);
             P.det_probs[(size_t)pos * K + k] = pr[k];
         }
     const float s[4] = {P.sx, P.sy, P.sx, P.sy};
@@ -167,7 +155,7 @@ __device__ __forceinline__ void finalize_rows(const K7Params& P, int t, int rows
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            float v = P.cov ? ld_row<COHERENT>(P.cov + (size_t)src * 16 + a * 4 + b) : 0.0f;
+            float v = P.cov ? *(P.cov + (size_t)src * 16 + a * 4 + b) : 0.0f;
             v = v + ((a == b) ? 1e-4f : 0.0f);                        // IU:409
             v = (s[a] * v) * s[b];                                    // IU:411-424  S cov S^T
             cv[a * 4 + b] = v;
@@ -202,25 +190,7 @@ __device__ __forceinline__ void finalize_rows(const K7Params& P, int t, int rows
 
 __global__ void __launch_bounds__(POD_MAX_DETECTIONS) k7_finalize(const K7Params P) {
     __shared__ int s_flag[POD_MAX_DETECTIONS];
-    finalize_rows<false>(P, threadIdx.x, min(*P.n_rows, P.max_det), s_flag);
-}
-
-// Tail of the fused K5 / K6 + K7 launches.  Every live cluster workgroup has written its row of the staging arrays
-// (thread 0, plain stores); it publishes them (device-scope release), takes a ticket, and the workgroup that draws the
-// last one finalizes ALL rows (K7) -- no spinning, the others exit; the ticket word is left at zero for the next image.
-// Replaces a dependent launch (~7 us of launch floor + load chain for <= 100 rows) by one fence + one atomic per cluster.
-__device__ __forceinline__ void cluster_ticket_finalize(const K7Params& F, int32_t* ticket, int n_live, int* s_flag) {
-    __shared__ int s_ticket;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        __threadfence();                          // the row stores above (same thread) before the ticket
-        s_ticket = atomicAdd(ticket, 1);
-    }
-    __syncthreads();
-    if (s_ticket != n_live - 1) return;
-    __threadfence();
-    finalize_rows<true>(F, tid, min(n_live, F.max_det), s_flag);
-    if (tid == 0) *ticket = 0;
+    finalize_rows(P, threadIdx.x, min(*P.n_rows, P.max_det), s_flag);
 }
 
 struct K5Params {
@@ -240,13 +210,10 @@ struct K5Params {
     float* out_scores;
     int32_t* out_classes;
     float* out_probs;
-    int32_t* ticket;       // non-null: fused K5 + K7 launch (fin is valid, out_* are the staging rows)
-    K7Params fin;
 };
 
 __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
     __shared__ double s_red[4 * 40];
-    __shared__ int s_flag[POD_MAX_DETECTIONS];
     const int c = blockIdx.x;
     const int tid = threadIdx.x;
     // Round trip 1 -- everything that does not depend on the centre, issued together: the two counts, this cluster's
@@ -261,10 +228,7 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
         const int j = tid + q * 256;
         pre[q] = j < P.n_alloc ? load_box(P.boxes, j) : Box{0.f, 0.f, 0.f, 0.f};
     }
-    if (c >= n_live) {
-        if (P.ticket && c == 0 && tid == 0) *P.fin.n_det = 0;   // nothing kept: nobody else writes the count
-        return;
-    }
+    if (c >= n_live) return;
     const int n = min(n_raw, P.n_capacity);
     const int K = P.K;
     // round trip 2 -- the centre
@@ -390,7 +354,6 @@ __global__ void __launch_bounds__(256) k5_bayes_fuse(const K5Params P) {
             P.out_classes[c] = P.classes[ctr];
         }
     }
-    if (P.ticket) cluster_ticket_finalize(P.fin, P.ticket, n_live, s_flag);
 }
 
 struct K6Params {
@@ -411,13 +374,10 @@ struct K6Params {
     float* out_scores;
     int32_t* out_classes;
     float* out_probs;
-    int32_t* ticket;       // non-null: fused K6 + K7 launch (fin is valid, out_* are the staging rows)
-    K7Params fin;
 };
 
 __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
     __shared__ double s_red[4 * 40];
-    __shared__ int s_flag[POD_MAX_DETECTIONS];
     const int c = blockIdx.x;
     const int tid = threadIdx.x;
     // round trip 1: counts, centre index, this thread's first two candidate boxes and classes (see k5_bayes_fuse)
@@ -432,10 +392,7 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
         pre[q] = j < P.n_alloc ? load_box(P.boxes, j) : Box{0.f, 0.f, 0.f, 0.f};
         pre_cls[q] = j < P.n_alloc ? P.classes[j] : -1;
     }
-    if (c >= n_live) {
-        if (P.ticket && c == 0 && tid == 0) *P.fin.n_det = 0;
-        return;
-    }
+    if (c >= n_live) return;
     const int n = min(n_raw, P.n_capacity);
     const int K = P.K;
     const Box bc = load_box(P.boxes, ctr);
@@ -523,7 +480,6 @@ __global__ void __launch_bounds__(256) k6_anchor_stats(const K6Params P) {
         P.out_scores[c] = op[bk];
         P.out_classes[c] = bk;
     }
-    if (P.ticket) cluster_ticket_finalize(P.fin, P.ticket, n_live, s_flag);
 }
 
 // ---- post-NMS ensemble merge: sequential same-class clustering IU:203-215 ------------------------
@@ -661,41 +617,6 @@ extern "C" int pod_bayes_fuse(const PodConfig* cfg, const int32_t* n_total, cons
     P.classes = classes; P.probs = probs; P.K = cfg->num_classes; P.box_mode = box_mode; P.cls_mode = cls_mode;
     P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.n_alloc = cfg->n_levels * cfg->topk;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
-    P.ticket = nullptr; P.fin = pod::K7Params{};
-    hipLaunchKernelGGL(pod::k5_bayes_fuse, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-static bool fill_finalize(pod::K7Params& F, const PodConfig* cfg, const int32_t* n_rows, const float* boxes, const float* cov,
-                          const float* scores, const int32_t* classes, const float* probs, float sx, float sy, float out_h,
-                          float out_w, const PodDetections* out) {
-    if (!out || !out->boxes || !out->cov || !out->scores || !out->classes || !out->probs || !out->n_det) return false;
-    F.keep = nullptr; F.n_rows = n_rows; F.boxes = boxes; F.cov = cov; F.scores = scores; F.classes = classes; F.probs = probs;
-    F.K = cfg->num_classes; F.max_det = cfg->max_detections; F.sx = sx; F.sy = sy; F.out_h = out_h; F.out_w = out_w;
-    F.det_boxes = out->boxes; F.det_cov = out->cov; F.det_scores = out->scores; F.det_classes = out->classes;
-    F.det_probs = out->probs; F.records = out->records; F.n_det = out->n_det;
-    return true;
-}
-
-extern "C" int pod_bayes_fuse_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
-                                       const float* boxes, const float* cov, const float* scores, const int32_t* classes,
-                                       const float* probs, int32_t box_mode, int32_t cls_mode, float* m_boxes, float* m_cov,
-                                       float* m_scores, int32_t* m_classes, float* m_probs, int32_t* ticket, float scale_x,
-                                       float scale_y, float out_h, float out_w, const PodDetections* out, pod_stream_t stream) {
-    if (!cfg || !n_total || !keep || !n_keep || !boxes || !cov || !scores || !classes || !probs || !m_boxes || !m_cov || !m_scores ||
-        !m_classes || !m_probs || !ticket)
-        return POD_E_INVALID;
-    if (box_mode < 0 || box_mode > 1 || cls_mode < 0 || cls_mode > 1) return POD_E_INVALID;
-    if (cfg->num_classes < 1 || cfg->num_classes >= POD_MAX_CLASSES) return POD_E_INVALID;
-    if (cfg->max_detections < 1 || cfg->max_detections > POD_MAX_DETECTIONS) return POD_E_INVALID;
-    pod::K5Params P;
-    P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.scores = scores;
-    P.classes = classes; P.probs = probs; P.K = cfg->num_classes; P.box_mode = box_mode; P.cls_mode = cls_mode;
-    P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.n_alloc = cfg->n_levels * cfg->topk;
-    P.out_boxes = m_boxes; P.out_cov = m_cov; P.out_scores = m_scores; P.out_classes = m_classes; P.out_probs = m_probs;
-    P.ticket = ticket;
-    if (!fill_finalize(P.fin, cfg, n_keep, m_boxes, m_cov, m_scores, m_classes, m_probs, scale_x, scale_y, out_h, out_w, out)) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k5_bayes_fuse, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
@@ -715,29 +636,6 @@ extern "C" int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_tot
     P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.ensemble_rule = 0;
     P.n_alloc = cfg->n_levels * cfg->topk; P.n_keep_alloc = cfg->max_detections;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
-    P.ticket = nullptr; P.fin = pod::K7Params{};
-    hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-extern "C" int pod_anchor_stats_finalize(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
-                                         const float* boxes, const float* cov, const int32_t* classes, const float* probs,
-                                         float* m_boxes, float* m_cov, float* m_scores, int32_t* m_classes, float* m_probs,
-                                         int32_t* ticket, float scale_x, float scale_y, float out_h, float out_w,
-                                         const PodDetections* out, pod_stream_t stream) {
-    if (!cfg || !n_total || !keep || !n_keep || !boxes || !classes || !probs || !m_boxes || !m_cov || !m_scores || !m_classes ||
-        !m_probs || !ticket)
-        return POD_E_INVALID;
-    if (cfg->num_classes < 1 || cfg->num_classes > POD_MAX_CLASSES) return POD_E_INVALID;
-    if (cfg->max_detections < 1 || cfg->max_detections > POD_MAX_DETECTIONS) return POD_E_INVALID;
-    pod::K6Params P;
-    P.n_total = n_total; P.keep = keep; P.n_keep = n_keep; P.boxes = boxes; P.cov = cov; P.classes = classes; P.probs = probs;
-    P.K = cfg->num_classes; P.n_capacity = POD_MAX_CANDIDATES; P.aff = cfg->affinity_thresh; P.ensemble_rule = 0;
-    P.n_alloc = cfg->n_levels * cfg->topk; P.n_keep_alloc = cfg->max_detections;
-    P.out_boxes = m_boxes; P.out_cov = m_cov; P.out_scores = m_scores; P.out_classes = m_classes; P.out_probs = m_probs;
-    P.ticket = ticket;
-    if (!fill_finalize(P.fin, cfg, n_keep, m_boxes, m_cov, m_scores, m_classes, m_probs, scale_x, scale_y, out_h, out_w, out)) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(cfg->max_detections), dim3(256), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
@@ -776,7 +674,6 @@ extern "C" int pod_ensemble_merge(const PodConfig* cfg, const int32_t* m_total, 
     P.K = cfg->num_classes; P.n_capacity = capacity; P.aff = cfg->affinity_thresh; P.ensemble_rule = 1;
     P.n_alloc = capacity; P.n_keep_alloc = capacity;
     P.out_boxes = out_boxes; P.out_cov = out_cov; P.out_scores = out_scores; P.out_classes = out_classes; P.out_probs = out_probs;
-    P.ticket = nullptr; P.fin = pod::K7Params{};
     hipLaunchKernelGGL(pod::k6_anchor_stats, dim3(capacity), dim3(256), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;

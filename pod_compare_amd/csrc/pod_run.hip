@@ -32,7 +32,6 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     const bool has_cov = cfg->cov_dims > 0 || merged;   // PI:381: otherwise the reference carries no covariance
     if (prune && !ws->maybe_bits) return POD_E_INVALID;
     if (!ws->cat_keys || !ws->cat_level || !ws->n_total) return POD_E_INVALID;
-    if (mode != POD_MODE_STANDARD_NMS && !ws->cluster_ticket) return POD_E_INVALID;
     if (mode == POD_MODE_BAYES_OD && !has_cov) return POD_E_INVALID;
 
     POD_TRY(pod_mc_merge_score(cfg, levels, merged ? ws->mean_cls : nullptr, merged ? ws->mean_cls_var : nullptr,
@@ -54,14 +53,19 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     // IU:394-396: scale factors are Python floats (doubles) rounded once to fp32
     const float sx = (float)((double)out_w / (double)image_w), sy = (float)((double)out_h / (double)image_h);
     const float oh = (float)out_h, ow = (float)out_w;
-    if (mode == POD_MODE_BAYES_OD)       // K5 + K7 in one launch: the cluster workgroup that finishes last finalizes
-        return pod_bayes_fuse_finalize(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, ws->cov, ws->cand_score, ws->cand_class,
-                                       ws->cand_probs, box_merge_mode, cls_merge_mode, ws->m_boxes, ws->m_cov, ws->m_scores,
-                                       ws->m_classes, ws->m_probs, ws->cluster_ticket, sx, sy, oh, ow, out, stream);
-    if (mode == POD_MODE_ANCHOR_STATISTICS)
-        return pod_anchor_stats_finalize(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_class, ws->cand_probs,
-                                         ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, ws->cluster_ticket,
-                                         sx, sy, oh, ow, out, stream);
-    return pod_finalize(cfg, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_score, ws->cand_class, ws->cand_probs, sx, sy,
+    // (K5 / K6 with K7's body run by the last cluster workgroup -- device-scope fence + ticket -- was built and measured:
+    //  17.6 us against 9.7 + 5.9 us for the two launches; the fence costs more than the launch it saves.  See DESIGN.md.)
+    if (mode == POD_MODE_BAYES_OD) {
+        POD_TRY(pod_bayes_fuse(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, ws->cov, ws->cand_score, ws->cand_class,
+                               ws->cand_probs, box_merge_mode, cls_merge_mode, ws->m_boxes, ws->m_cov, ws->m_scores,
+                               ws->m_classes, ws->m_probs, stream));
+    } else if (mode == POD_MODE_ANCHOR_STATISTICS) {
+        POD_TRY(pod_anchor_stats_merge(cfg, ws->n_total, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_class, ws->cand_probs,
+                                       ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, stream));
+    }
+    if (mode == POD_MODE_STANDARD_NMS)
+        return pod_finalize(cfg, ws->keep, ws->n_keep, ws->boxes, cov_in, ws->cand_score, ws->cand_class, ws->cand_probs, sx, sy,
+                            oh, ow, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records, out->n_det, stream);
+    return pod_finalize(cfg, nullptr, ws->n_keep, ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, sx, sy,
                         oh, ow, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records, out->n_det, stream);
 }

@@ -28,7 +28,7 @@ EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_scor
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_bayes_fuse_finalize", "pod_anchor_stats_finalize")
+           "pod_dump_cls_normals", "pod_dump_box_normals")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -52,7 +52,7 @@ class PodWorkspace(Structure):
         "anchors", "mean_cls", "mean_cls_var", "mean_delta", "mean_reg_var", "cand_keys", "cand_count", "maybe_bits",
         "sel_keys", "sel_count", "cat_keys", "cat_level", "probs_dense", "n_total", "cand_anchor_idx", "cand_level", "cand_class", "cand_score", "cand_probs",
         "cand_delta", "cand_reg_var", "cand_anchor", "cand_run_delta", "boxes", "cov", "keep", "n_keep", "nms_scratch",
-        "m_boxes", "m_cov", "m_scores", "m_classes", "m_probs", "cluster_ticket")] + [("n_capacity", c_int32), ("reserved", c_int32)]
+        "m_boxes", "m_cov", "m_scores", "m_classes", "m_probs")] + [("n_capacity", c_int32), ("reserved", c_int32)]
 
 
 class PodDetections(Structure):
@@ -111,8 +111,6 @@ def load() -> ctypes.CDLL:
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_dump_cls_normals.argtypes = [POINTER(PodConfig), POINTER(PodLevel), c_int32, P, P]
     lib.pod_dump_box_normals.argtypes = [POINTER(PodConfig), P, c_int32, P, P]
-    lib.pod_bayes_fuse_finalize.argtypes = [POINTER(PodConfig)] + [P] * 8 + [c_int32, c_int32] + [P] * 6 + [c_float] * 4 + [POINTER(PodDetections), P]
-    lib.pod_anchor_stats_finalize.argtypes = [POINTER(PodConfig)] + [P] * 7 + [P] * 6 + [c_float] * 4 + [POINTER(PodDetections), P]
     lib.pod_run_image.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
     for name in EXPORTS:

@@ -132,10 +132,8 @@ class HotPath:
         self.mean_delta = f32(self.R * 4) if merged and dense_box_merge else None
         self.mean_reg_var = f32(self.R * D) if merged and D > 0 and dense_box_merge else None
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
-        # [0:L] cand_count, [L:2L] K2's tickets, [2*MAX_LEVELS] the cluster kernels' ticket; all zero between images
-        self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS + 4, dtype=torch.int32, device=dev)
+        self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count, [L:2L] K2's tickets
         self.cand_count = self.counters[: self.L]
-        self.cluster_ticket = self.counters[2 * hip.POD_MAX_LEVELS: 2 * hip.POD_MAX_LEVELS + 1]
         n_words = sum(A * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words()
         self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None
         # K2 outputs
@@ -174,7 +172,7 @@ class HotPath:
                         ("cand_anchor", self.cand_anchor), ("cand_run_delta", self.cand_run_delta), ("boxes", self.boxes),
                         ("cov", self.cov), ("keep", self.keep), ("n_keep", self.n_keep), ("nms_scratch", self.nms_scratch),
                         ("m_boxes", self.m_boxes), ("m_cov", self.m_cov), ("m_scores", self.m_scores),
-                        ("m_classes", self.m_classes), ("m_probs", self.m_probs), ("cluster_ticket", self.cluster_ticket)):
+                        ("m_classes", self.m_classes), ("m_probs", self.m_probs)):
             setattr(ws, name, hip.ptr(t))
         ws.n_capacity = self.n_cap
         self.ws = ws
