@@ -110,7 +110,9 @@ class HotPath:
         self.n_runs, self.has_cls_var, self.cov_dims = int(n_runs), bool(has_cls_var), int(cov_dims)
         A, K = params.num_anchors, params.num_classes
         if self.L > hip.POD_MAX_LEVELS or K > hip.POD_MAX_CLASSES - 1 or self.n_runs > hip.POD_MAX_RUNS:
-            raise hip.PodError("unsupported geometry: levels={} classes={} runs={}".format(self.L, K, self.n_runs))
+            raise hip.PodError("unsupported geometry: levels={} (max {}), classes={} (max {}: the kernels put an anchor's classes on the "
+                               "lanes of one 16-lane row; BDD has 7), runs={} (max {})".format(
+                                   self.L, hip.POD_MAX_LEVELS, K, hip.POD_MAX_CLASSES - 1, self.n_runs, hip.POD_MAX_RUNS))
         self.level_R = [h * w * A for h, w in self.shapes]
         self.anchor_base = [0]
         for r in self.level_R[:-1]:

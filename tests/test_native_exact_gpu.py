@@ -24,8 +24,24 @@ from tests.test_hip_parity import make_path
 pytestmark = pytest.mark.gpu
 
 CASES = ["cfg2_bayes_od_regclsvar_s21", "cfg3_bayes_od_mc10_s31", "cfg3_bayes_od_mc10_s32", "standard_nms_regclsvar_s91",
-         "full_cfg3_bayes_od_mc10_s1001"]
+         "anchor_stats_regclsvar_s61", "bayes_od_ci_clsbayes_s71", "full_cov_standard_nms_s121", "mc3_standard_nms_regclsvar_s131",
+         "cfg5_ensembles_pre_nms_s51", "worst_bayes_od_mc4_s111", "full_cfg3_bayes_od_mc10_s1001"]
 SCORE_RTOL = 2e-6
+
+
+def assert_cov_close(a, b, what):
+    """|a - b| <= 1e-4 * max(1, |b|) element-wise -- except that an entry which is tiny only by cancellation (an off-diagonal
+    of a covariance whose diagonal is 1e4: the "worst" inputs' 0.3-sigma deltas on 800-pixel anchors) is held to 1e-6 of
+    its matrix's largest entry instead: fp32 sums of 1000 products of that size differ by more than 1e-4 absolute between
+    any two summation orders."""
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape
+    if a.numel() == 0:
+        return
+    scale = b.abs().reshape(b.shape[0], -1).max(dim=1)[0].reshape(-1, 1, 1)
+    bound = torch.maximum(1e-4 * b.abs().clamp(min=1.0), 1e-6 * scale)
+    err = (a - b).abs()
+    assert bool((err <= bound).all()), "{}: {} elements off, worst excess {:.3e}".format(what, int((err > bound).sum()), float((err - bound).max()))
 
 
 class _ClsThenZeros:
@@ -110,7 +126,7 @@ def test_product_kernels_equal_oracle_on_their_own_draws(name, draw_id):
         span = nat["score"][lo:hi + 1]
         assert float(span.max() - span.min()) <= 2 * SCORE_RTOL * float(span.max()), "candidate order differs outside a near-tie"
     assert_close(nat["boxes"][a], aw.boxes[b], "candidate boxes")
-    assert_close(nat["cov"][a], aw.cov[b], "candidate covariances")
+    assert_cov_close(nat["cov"][a], aw.cov[b], "candidate covariances")
 
     # ---- detections -----------------------------------------------------------------------------------------
     assert m == len(ref) and m > 0
@@ -119,14 +135,14 @@ def test_product_kernels_equal_oracle_on_their_own_draws(name, draw_id):
         assert_close(final["scores"], ref.scores, "scores", rtol=SCORE_RTOL, atol=1e-7)
         assert_close(final["probs"], ref.pred_cls_probs, "probs", rtol=SCORE_RTOL, atol=1e-7)
         assert_close(final["boxes"], ref.pred_boxes, "boxes")
-        assert_close(final["cov"], ref.pred_boxes_covariance, "cov")
+        assert_cov_close(final["cov"], ref.pred_boxes_covariance, "cov")
     else:   # a near-tie moved: match detections by box, then the same bars
         d = (final["boxes"][:, None, :] - ref.pred_boxes[None, :, :]).abs().sum(-1)
         match = d.argmin(1)
         assert sorted(match.tolist()) == list(range(m))
         assert torch.equal(final["classes"], ref.pred_classes[match])
         assert_close(final["boxes"], ref.pred_boxes[match], "boxes")
-        assert_close(final["cov"], ref.pred_boxes_covariance[match], "cov")
+        assert_cov_close(final["cov"], ref.pred_boxes_covariance[match], "cov")
 
     # ---- and the HIP eps-replay kernels on the same draws: the decode / moment code is shared, so with an identical
     # candidate list boxes and covariances must be BIT-identical between the two K1/K2b/K3 implementations --------
