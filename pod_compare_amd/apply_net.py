@@ -44,6 +44,8 @@ def gather_records(local_ids: Sequence[int], local_counts: torch.Tensor, local_r
     rec = torch.zeros((per_rank,) + tuple(local_records.shape[1:]), dtype=local_records.dtype, device=dev)
     rec[:n_local] = local_records
     if world > 1:
+        if dist.get_backend() != "nccl":      # functional runs on gloo: collectives on host copies (RCCL gathers device buffers)
+            ids, cnt, rec = ids.cpu(), cnt.cpu(), rec.cpu()
         all_ids = [torch.empty_like(ids) for _ in range(world)]
         all_cnt = [torch.empty_like(cnt) for _ in range(world)]
         all_rec = [torch.empty_like(rec) for _ in range(world)]
@@ -157,14 +159,22 @@ def main(argv=None):
     ap.add_argument("--data-dir", default="", help="the reference's core.data_dir(): OUTPUT_DIR = <data-dir>/<dataset>/<family>/<config>/"
                                                    "random_seed_<seed>, whose last_checkpoint is loaded (CS:170-182, PI:59-84)")
     ap.add_argument("--weights", default=None, help="overrides MODEL.WEIGHTS (a local .pth / .pkl with detectron2 names)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl = RCCL over xGMI (the real path); gloo for a "
+                                                      "functional run, e.g. several ranks on one GPU with --share-gpu")
+    ap.add_argument("--share-gpu", action="store_true", help="functional check only: every rank uses cuda:0")
     ap.add_argument("--random-init", action="store_true",
                     help="synthetic runs: clear MODEL.WEIGHTS / OUTPUT_DIR and keep the seeded random initialisation")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     cfg = setup_config(args.config_file, args.inference_config, args.random_seed, data_dir=args.data_dir, is_testing=bool(args.data_dir))
     if args.weights is not None:

@@ -16,6 +16,8 @@ SOURCES = ["k1_mc_merge_score.hip", "k2_topk_gather.hip", "k3_decode_cov.hip", "
 HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(CSRC, "pod_candidate.h"), os.path.join(os.path.dirname(HERE), "include", "pod_mi355x.h")]
 # -ffp-contract=off: the CPU reference rounds after every op; index parity needs the same fp32 values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("POD_EXTRA_DEFINES"):     # experiments: e.g. POD_EXTRA_DEFINES="-DPOD_K1_WRITE_THROUGH"
+    FLAGS.extend(os.environ["POD_EXTRA_DEFINES"].split())
 if os.environ.get("POD_TRACE") == "1":      # diagnostics build: phase time stamps inside kernels (csrc/pod_device.h); use --force
     FLAGS.append("-DPOD_TRACE")
 

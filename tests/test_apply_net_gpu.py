@@ -1,0 +1,49 @@
+"""The image-sharded driver as a command (AN:82-102 replaced): one rank, and two gloo ranks sharing the GPU.  Random-init
+weights (explicit --random-init): the detections are meaningless, the plumbing is what is checked -- every image once, in
+order, at most 100 rows each, JSON in the reference's format, binary sidecar equal to the JSON."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from pod_compare_amd import inference_utils
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"image_id", "category_id", "bbox", "score", "cls_prob", "bbox_covar"}
+
+
+def run(tmp_path, name, ranks, extra=()):
+    out, side = str(tmp_path / (name + ".json")), str(tmp_path / (name + ".podr"))
+    cmd = [sys.executable]
+    if ranks > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                "--master-port", str(35500 + os.getpid() % 2000)]
+    cmd += ["-m", "pod_compare_amd.apply_net", "--num-images", "5", "--random-init", "--output", out, "--binary-output", side,
+            "--flush-every", "2"] + list(extra)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call(cmd, cwd=ROOT, env=env, timeout=900)
+    return json.load(open(out)), side
+
+
+def check(dets, side):
+    assert all(set(d) == KEYS for d in dets)
+    ids = [d["image_id"] for d in dets]
+    assert ids == sorted(ids) and set(ids) <= set(range(5))
+    for i in range(5):
+        assert sum(1 for d in dets if d["image_id"] == i) <= 100
+    for d in dets:
+        assert 1 <= d["category_id"] <= 7 and len(d["bbox"]) == 4 and len(d["cls_prob"]) == 7 and len(d["bbox_covar"]) == 4
+    from pod_compare_amd.apply_net import BDD_CAT_MAP
+    assert inference_utils.binary_results_to_json(side, BDD_CAT_MAP) == dets
+
+
+def test_one_rank_and_two_gloo_ranks_on_one_gpu(tmp_path):
+    d1, s1 = run(tmp_path, "one", 1)
+    check(d1, s1)
+    d2, s2 = run(tmp_path, "two", 2, ("--backend", "gloo", "--share-gpu"))
+    check(d2, s2)
+    ids, counts, rec, k = inference_utils.read_binary_results(s2)
+    assert ids == list(range(5)) and k == 7                      # every image exactly once, in order, whichever rank ran it
