@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--images", type=int, default=4, help="distinct planted head-tensor sets kept in HBM")
     ap.add_argument("--synth", default="planted", choices=["planted", "worst"])
+    ap.add_argument("--boxes", type=int, default=24, help="planted objects per image (SURVEY 8d: 24); more objects = more candidates")
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
@@ -245,7 +246,7 @@ def main():
     padded = A.padded_size(*net_hw)                            # 768 x 1344
     n_img = max(1, args.images)
     frames = [synthetic.synthetic_frame(rank * 100003 + i, *FRAME_HW, device=dev) for i in range(n_img)]
-    heads = [synthetic.planted_head_outputs(padded, N, seed=1000 + rank * 100003 + i, num_boxes=24, with_cls_var=spec["cls_var"],
+    heads = [synthetic.planted_head_outputs(padded, N, seed=1000 + rank * 100003 + i, num_boxes=args.boxes, with_cls_var=spec["cls_var"],
                                             with_reg_var=spec["reg_var"], mode=args.synth, device=dev) for i in range(n_img)]
     params = hotpath.PathParams()
     D = 4 if spec["reg_var"] else 0
@@ -330,7 +331,7 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
         "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
-                   "classes": params.num_classes, "synthetic_mode": args.synth, "conv_net_in_timed_region": not args.no_cnn,
+                   "classes": params.num_classes, "synthetic_mode": args.synth, "planted_boxes": args.boxes, "conv_net_in_timed_region": not args.no_cnn,
                    "conv_net_output": "computed and timed, then discarded: the hot path consumes planted head tensors (random-init "
                                       "weights give no detections, SURVEY 8d)",
                    "skip_unused_last_run": bool(mc and params.merge_quirk),

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(64) k3_decode_cov(const K3Params P) {
 struct K23Params {
     K2bParams g;
     K3Params d;
+    int32_t small_max;   // candidate counts up to this use the 4-wavefronts-per-candidate shape
 };
 
 constexpr int K23_THREADS = 256;
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(K23_THREADS) k23_gather_decode(const K23Params
     const int n = *P.g.n_total;
     GatheredCandidate c;
     POD_STAMP(blockIdx.x, 0);
-    if (n > K23_SMALL_MAX) {
+    if (n > P.small_max) {
         float* part = lds + wave * WAVE_SCRATCH;
         float* small = part + 10 * 64;
         float* run_delta = small + 16 + 4 * POD_MAX_RUNS;
@@ -177,6 +178,8 @@ extern "C" int pod_gather_decode(const PodConfig* cfg, const PodLevel* levels, c
     Dp.seed = cfg->philox_seed; Dp.n_total = n_total; Dp.cand_delta = cand_delta; Dp.cand_reg_var = cand_reg_var;
     Dp.cand_anchor = cand_anchor; Dp.cand_run_delta = cand_run_delta; Dp.cand_anchor_idx = cand_anchor_idx;
     Dp.cand_level = cand_level; Dp.eps_prop = nullptr; Dp.boxes = boxes; Dp.cov = cov;
+    P.small_max = pod::K23_SMALL_MAX;   // swept 1024 / 2048 / 3072 / 8192 over n = 490 .. 4594 (tools/sweep_candidates.py): flat up to
+                                        // ~2000, above that the one-wavefront shape wins by up to 30 us
     hipLaunchKernelGGL(pod::k23_gather_decode, dim3(cfg->n_levels * cfg->topk), dim3(pod::K23_THREADS), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;

@@ -6,9 +6,11 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-for synth in planted worst; do
+for synth in planted busy worst; do
+  extra=""; mode=$synth
+  if [ "$synth" = "busy" ]; then mode=planted; extra="--boxes 120"; fi
   raw="gpurun_out/${TAG}/raw_hot_${synth}"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$raw" -o hp -- python bench.py --no-cnn --streams 1 --steps 60 --warmup 5 --synth $synth --no-cpu-baseline --no-diagnostics > "$OUT/bench_hot_$synth.json" 2> "$OUT/bench_hot_$synth.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$raw" -o hp -- python bench.py --no-cnn --streams 1 --steps 60 --warmup 5 --synth $mode $extra --no-cpu-baseline --no-diagnostics > "$OUT/bench_hot_$synth.json" 2> "$OUT/bench_hot_$synth.err"
   f=$(find "$raw" -name '*kernel_trace.csv' | head -1)
   python tools/trace_timeline.py "$f" > "$OUT/hot_${synth}_timeline.txt" 2>&1
   s=$(find "$raw" -name '*kernel_stats.csv' | head -1)
