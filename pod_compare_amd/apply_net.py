@@ -69,6 +69,43 @@ def results_json(ids: Sequence[int], counts: torch.Tensor, records: torch.Tensor
     return out
 
 
+class CocoImages:
+    """The reference's `build_detection_test_loader(cfg, dataset_name)` (AN:83-84) for a COCO-format image list, restated
+    without detectron2: what detectron2's DatasetMapper(is_train=False) hands the predictor for every entry of `images` --
+    the file read with PIL as RGB and flipped to BGR (cfg.INPUT.FORMAT), ResizeShortestEdge(MIN_SIZE_TEST, MAX_SIZE_TEST) applied
+    with PIL's bilinear filter on the uint8 HWC array (detectron2's ResizeTransform does exactly that for uint8 images), then a
+    (3, H, W) uint8 tensor; 'height' / 'width' are the ORIGINAL size from the json (the output resolution, PI:106-107) and
+    'image_id' the dataset's id."""
+
+    def __init__(self, json_path: str, image_root: str, min_size: int = 800, max_size: int = 1333):
+        with open(json_path, "r") as f:
+            data = json.load(f)
+        self.images = list(data["images"])
+        self.root, self.min_size, self.max_size = image_root, int(min_size), int(max_size)
+
+    def __len__(self) -> int:
+        return len(self.images)
+
+    def image_id(self, i: int):
+        return self.images[i]["id"]
+
+    def __getitem__(self, i: int) -> dict:
+        import numpy as np
+        from PIL import Image
+        from . import anchors
+        rec = self.images[i]
+        with Image.open(os.path.join(self.root, rec["file_name"])) as im:
+            im = im.convert("RGB")
+            h, w = im.height, im.width
+            nh, nw = anchors.resize_shortest_edge(h, w, self.min_size, self.max_size)
+            if (nh, nw) != (h, w):
+                im = im.resize((nw, nh), Image.BILINEAR)
+            arr = np.asarray(im)[:, :, ::-1]                       # RGB -> BGR
+        image = torch.as_tensor(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        return {"image": image, "height": int(rec.get("height", h)), "width": int(rec.get("width", w)), "image_id": rec["id"],
+                "file_name": rec["file_name"]}
+
+
 class EnsemblePerGpu:
     """Config 5 (`ensembles_pre_nms.yaml`) on one node: ensemble member s lives on rank s < M, every member rank runs the
     conv net on the SAME image, the dense pre-NMS head tensors meet on the image's merge rank (= the rank that owns the
@@ -146,7 +183,9 @@ def main(argv=None):
     here = os.path.dirname(os.path.abspath(__file__))
     ap.add_argument("--config-file", default=os.path.join(here, "configs/BDD-Detection/retinanet/retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml"))
     ap.add_argument("--inference-config", default=os.path.join(here, "configs/Inference/bayes_od_mc_dropout.yaml"))
-    ap.add_argument("--num-images", type=int, default=8)
+    ap.add_argument("--num-images", type=int, default=8, help="synthetic 1280x720 frames (ignored with --coco-json)")
+    ap.add_argument("--coco-json", default="", help="COCO-format json whose `images` are run (the reference's test data loader, AN:83-84)")
+    ap.add_argument("--image-root", default="", help="directory of the files named in --coco-json")
     ap.add_argument("--random-seed", type=int, default=0)
     ap.add_argument("--output", default="coco_instances_results.json")
     ap.add_argument("--streams", type=int, default=3,
@@ -184,6 +223,11 @@ def main(argv=None):
     cfg.MODEL.DEVICE = "cuda:%d" % local_rank
     K = cfg.MODEL.RETINANET.NUM_CLASSES
     from . import modeling
+    dataset = CocoImages(args.coco_json, args.image_root, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST) if args.coco_json else None
+    if dataset is not None:
+        if args.ensemble_per_gpu:
+            raise SystemExit("--ensemble-per-gpu runs on the synthetic frames only")
+        args.num_images = len(dataset)
     mine = shard_indices(args.num_images, rank, world)
     recs, cnts = [], []
     if args.ensemble_per_gpu:
@@ -225,9 +269,14 @@ def main(argv=None):
                 if j < len(mine):
                     i = mine[j]
                     with torch.cuda.stream(streams[j % len(streams)]):
-                        frame = synthetic.synthetic_frame(i, device=dev)
-                        image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
-                        input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
+                        if dataset is not None:
+                            d = dataset[i]                              # resized on the host exactly as detectron2's mapper does
+                            input_im = [{"image": d["image"].to(dev, non_blocking=True), "height": d["height"], "width": d["width"],
+                                         "image_id": i}]                # position in the list: the dataset's id is restored below
+                        else:
+                            frame = synthetic.synthetic_frame(i, device=dev)
+                            image = modeling.resize_test_image(frame, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+                            input_im = [{"image": image, "height": frame.shape[1], "width": frame.shape[2], "image_id": i}]
                         det = predictor(input_im)
                         chunk_ids.append(i)
                         recs.append(det.records)
@@ -242,6 +291,8 @@ def main(argv=None):
     ids = [ids[q] for q in order]
     cnt = torch.cat(all_cnt)[order] if all_cnt else torch.zeros((0,), dtype=torch.int32)
     rec = torch.cat(all_rec)[order] if all_rec else torch.zeros((0, 128, width))
+    if dataset is not None:
+        ids = [dataset.image_id(i) for i in ids]
     if rank == 0:
         with open(args.output, "w") as fp:
             json.dump(results_json(ids, cnt, rec, K, BDD_CAT_MAP), fp, indent=4, separators=(",", ": "))

@@ -47,3 +47,27 @@ def test_one_rank_and_two_gloo_ranks_on_one_gpu(tmp_path):
     check(d2, s2)
     ids, counts, rec, k = inference_utils.read_binary_results(s2)
     assert ids == list(range(5)) and k == 7                      # every image exactly once, in order, whichever rank ran it
+
+
+def test_coco_image_list_end_to_end(tmp_path):
+    """--coco-json / --image-root: files -> detectron2-style mapped inputs -> predictor -> results keyed by the DATASET's ids."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    images = []
+    for k, (h, w) in enumerate(((180, 320), (200, 300), (180, 320))):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / ("f%d.png" % k))
+        images.append({"id": 7000 + 3 * k, "file_name": "f%d.png" % k, "height": h, "width": w})
+    (tmp_path / "set.json").write_text(json.dumps({"images": images}))
+    out, side = str(tmp_path / "r.json"), str(tmp_path / "r.podr")
+    cmd = [sys.executable, "-m", "pod_compare_amd.apply_net", "--coco-json", str(tmp_path / "set.json"), "--image-root", str(tmp_path),
+           "--random-init", "--output", out, "--binary-output", side]
+    subprocess.check_call(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), timeout=900)
+    dets = json.load(open(out))
+    assert all(set(d) == KEYS for d in dets) and {d["image_id"] for d in dets} <= {7000, 7003, 7006}
+    ids, counts, rec, k = inference_utils.read_binary_results(side)
+    assert ids == [7000, 7003, 7006] and k == 7
+    for d in dets:      # boxes live in the ORIGINAL resolution (PI:106-107)
+        w, h = next((im["width"], im["height"]) for im in images if im["id"] == d["image_id"])
+        x, y, bw, bh = d["bbox"]
+        assert -1e-3 <= x and -1e-3 <= y and x + bw <= w + 1e-3 and y + bh <= h + 1e-3

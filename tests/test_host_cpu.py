@@ -270,3 +270,26 @@ def test_binary_sidecar_round_trip_equals_the_json_records(tmp_path):
     with pytest.raises(ValueError):
         open(path, "r+b").write(b"XXXX")
         inference_utils.read_binary_results(path)
+
+
+def test_coco_image_list_is_mapped_like_detectron2s_test_loader(tmp_path):
+    """AN:83-84 restated (apply_net.CocoImages): RGB file -> BGR uint8 (3, H', W'), ResizeShortestEdge with PIL's bilinear filter on
+    the uint8 array (what detectron2's ResizeTransform does), original height / width and the dataset's image id passed on."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(72, 128, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    Image.fromarray(rgb[:40, :50]).save(tmp_path / "b.png")
+    spec = {"images": [{"id": 901, "file_name": "a.png", "height": 72, "width": 128}, {"id": 17, "file_name": "b.png", "height": 40, "width": 50}]}
+    (tmp_path / "set.json").write_text(json.dumps(spec))
+    ds = apply_net.CocoImages(str(tmp_path / "set.json"), str(tmp_path), min_size=80, max_size=120)
+    assert len(ds) == 2 and ds.image_id(1) == 17
+    a = ds[0]
+    nh, nw = resize_shortest_edge(72, 128, 80, 120)                  # the long side caps the scale: 120 / 128
+    assert (nh, nw) == (68, 120) and tuple(a["image"].shape) == (3, nh, nw) and a["image"].dtype == torch.uint8
+    want = np.asarray(Image.fromarray(rgb).resize((nw, nh), Image.BILINEAR))[:, :, ::-1].transpose(2, 0, 1)
+    assert np.array_equal(a["image"].numpy(), want)
+    assert (a["height"], a["width"], a["image_id"]) == (72, 128, 901)
+    b = ds[1]
+    assert tuple(b["image"].shape) == (3, 80, 100) and (b["height"], b["width"], b["image_id"]) == (40, 50, 17)
