@@ -506,7 +506,9 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
         P.pseg_begin[q] = pb;
         // 4 independent 16-B loads per tensor per lane: measured 34.2 us vs 34.1 (2) and 34.6 (8) per launch
         // (also measured this round, rejected: a persistent grid of 512 / 1024 workgroups looping over the chunks, 23.1 / 22.2 us
-        //  against 21.9; write-through (sc0 sc1) stores of the merged planes instead of non-temporal ones, 22.5 us)
+        //  against 21.9; write-through (sc0 sc1) stores of the merged planes instead of non-temporal ones, 22.5 us; LDS-DMA
+        //  loads (global_load_lds_dwordx4 nt into a per-wavefront slab, then ds_read_b128): 22.9 us here although the bare
+        //  2 x 9-stream merge of tools/membw.hip gains 1 us with them)
         hipLaunchKernelGGL(pod::k1_prune_stream<4>, dim3(pb), dim3(256), 0, (hipStream_t)stream, P);
         POD_CHECK_LAUNCH();
         return POD_OK;

@@ -40,6 +40,36 @@ __global__ void merge4x2(const float4* __restrict__ a, const float4* __restrict_
     *(f4*)(oa + i) = x;
     *(f4*)(ob + i) = y;
 }
+// the same 2 x NR-stream merge with LDS-DMA loads (global_load_lds_dwordx4: global -> LDS without staging VGPRs; the LDS
+// destination of a wave's instruction is base + lane * 16), then one ds_read_b128 per stream
+template <int NR, int AUX>
+__global__ void __launch_bounds__(256) merge4x2_lds(const float4* __restrict__ a, const float4* __restrict__ b, size_t run_stride,
+                                                    float4* __restrict__ oa, float4* __restrict__ ob, size_t n) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char lds[];     // [wave][2*NR streams][64 lanes] x 16 B
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    char* base = lds + (size_t)wave * (2 * NR) * 64 * 16;
+    const size_t ii = i < n ? i : n - 1;                           // every lane issues (the LDS slot is positional)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + ii + r * run_stride),
+                                         (__attribute__((address_space(3))) void*)(base + (size_t)(2 * r) * 64 * 16), 16, 0, AUX);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + ii + r * run_stride),
+                                         (__attribute__((address_space(3))) void*)(base + (size_t)(2 * r + 1) * 64 * 16), 16, 0, AUX);
+    }
+    __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0): the DMA writes have landed in LDS
+    __builtin_amdgcn_wave_barrier();
+    if (i >= n) return;
+    f4 x = *(const f4*)(base + (size_t)lane * 16), y = *(const f4*)(base + (size_t)64 * 16 + (size_t)lane * 16);
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+        x += *(const f4*)(base + (size_t)(2 * r) * 64 * 16 + (size_t)lane * 16);
+        y += *(const f4*)(base + (size_t)(2 * r + 1) * 64 * 16 + (size_t)lane * 16);
+    }
+    __builtin_nontemporal_store(x, (f4*)(oa + i));
+    __builtin_nontemporal_store(y, (f4*)(ob + i));
+}
 template <int NR>
 __global__ void merge4_gs(const float4* __restrict__ a, size_t run_stride, float4* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -88,6 +118,8 @@ int main() {
             float4* b2 = in[0] + re7 * 10;   // second tensor right behind the first (10 runs each)
             timeit("merge 2x9 streams, 7+7 ch, nt", [&](int s) { merge4x2<9, true><<<(re7 + 255) / 256, 256>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
             timeit("merge 2x9 streams, 7+7 ch", [&](int s) { merge4x2<9, false><<<(re7 + 255) / 256, 256>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
+            timeit("merge 2x9 streams, LDS-DMA", [&](int s) { merge4x2_lds<9, 0><<<(re7 + 127) / 128, 128, 2 * 18 * 64 * 16>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
+            timeit("merge 2x9 streams, LDS-DMA nt", [&](int s) { merge4x2_lds<9, 2><<<(re7 + 127) / 128, 128, 2 * 18 * 64 * 16>>>(in[s], in[s] + re7 * 10, re7, out[s], out[s] + re7, re7); }, (double)re7 * 16 * 20);
             timeit("merge 9 streams, 14 ch, stride 14", [&](int s) { merge4<9><<<(re14 + 255) / 256, 256>>>(in[s], re14, out[s], re14); }, (double)re14 * 16 * 10);
             (void)b2;
         }
