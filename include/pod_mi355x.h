@@ -114,7 +114,8 @@ int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels,
 
 /* ---- K1b score_maybe ------------------------------------------------------------------------
  * Sparse companion of K1's prune mode (native RNG + cls_var head): when `maybe_bits`
- * (dev uint64[pod_maybe_words()], all zero on entry; pod_score_maybe leaves it zeroed again) is passed to pod_mc_merge_score, the dense pass
+ * (dev uint64[pod_maybe_words()] = one word per (anchor shape, class, 64 cells), all zero on entry; pod_score_maybe leaves it
+ * zeroed again) is passed to pod_mc_merge_score, the dense pass
  * draws no samples; it writes a bitmap of the anchors that can still reach `score_thresh` under the sampler's
  * hard bound |eps| < 4.9 (an exact superset of the candidates) and this kernel evaluates
  * mean_s sigmoid(logit + eps_s*sigma) (PI:289-295) for those only, appending the keys of the anchors

@@ -41,8 +41,8 @@ struct K1Params {
     uint64_t* cand_keys;
     int32_t* cand_count;
     uint64_t* maybe_bits;    // prune mode: bitmap of the anchors that MAY pass the threshold (exact superset); scored by K1b
-    int32_t word_begin[POD_MAX_LEVELS + 1];   // bitmap: level l owns words [word_begin[l], word_begin[l+1]); anchor shape a owns wpa[l] of them
-    int32_t wpa[POD_MAX_LEVELS];              // words per anchor shape = ceil(H*W / 64); bit (a, hw) = word a*wpa + hw/64, bit hw%64
+    int32_t word_begin[POD_MAX_LEVELS + 1];   // bitmap: level l owns words [word_begin[l], word_begin[l+1]); PLANE (a, k) owns wpa[l] of them
+    int32_t wpa[POD_MAX_LEVELS];              // words per plane = ceil(H*W / 64); bit (a, k, hw) = word (a*K + k)*wpa + hw/64, bit hw%64
     int32_t pseg_begin[3 * POD_MAX_LEVELS + 1];   // workgroup ranges of k1_prune_stream (256 threads): [cls pair l..][delta l..][reg l..]
 };
 
@@ -288,13 +288,17 @@ __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv,
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit) nib |= 1u << j;
-        unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + (plane / (uint32_t)K) * P.wpa[l] + (hw >> 6));
+        // one bitmap word per (plane, 64 cells): the classes of an anchor do NOT share a word.  (They did in round 1: with
+        // every anchor flagged, 7 classes x 8 words hammered each 64-byte line with 56 same-line atomics, and K1 took 48 us
+        // instead of 23 -- the stores, not their being atomic: tools/exp_k1_worst.py.)  K1b ORs the K words of an anchor.
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(bits + plane * P.wpa[l] + (hw >> 6));
         if ((HW & 63) == 0) {
             // planes are whole bitmap words and a wavefront starts on a 256-element boundary: the 16 lanes of a DPP row
-            // own exactly one word -> OR-reduce their nibbles with row rotations (VALU only), one atomic per non-zero word
+            // own exactly one word -> OR-reduce their nibbles with row rotations (VALU only); nobody else writes this word:
+            // a plain store of the non-zero ones (K1b leaves every word zero again)
             const unsigned long long w = (unsigned long long)nib << (hw & 63);
             const uint32_t lo = row_or16((uint32_t)w), hi = row_or16((uint32_t)(w >> 32));
-            if ((threadIdx.x & 15) == 0 && (lo | hi) != 0u) atomicOr(word, ((unsigned long long)hi << 32) | lo);
+            if ((threadIdx.x & 15) == 0 && (lo | hi) != 0u) *word = ((unsigned long long)hi << 32) | lo;
         } else if (nib) {
             atomicOr(word, (unsigned long long)nib << (hw & 63));
         }
@@ -305,7 +309,7 @@ __device__ __forceinline__ void prune_cls(const K1Params& P, const PodLevel& lv,
             if (!(fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) > P.skip_logit)) continue;
             const int plane = (int)((i + j) / HW);
             const int hw = (int)(i + j - (int64_t)plane * HW);
-            atomicOr(reinterpret_cast<unsigned long long*>(bits + (plane / K) * P.wpa[l] + (hw >> 6)), 1ull << (hw & 63));
+            atomicOr(reinterpret_cast<unsigned long long*>(bits + plane * P.wpa[l] + (hw >> 6)), 1ull << (hw & 63));
         }
     }
 }
@@ -341,8 +345,9 @@ __global__ void __launch_bounds__(256) k1_prune_stream(const K1Params P) {
 // butterfly and appends the keys of anchors above the threshold with one aggregated atomic.
 struct K1bParams {
     PodLevel lv[POD_MAX_LEVELS];
-    int32_t word_begin[POD_MAX_LEVELS + 1];   // level l = bitmap words [word_begin[l], word_begin[l+1])
-    int32_t wpa[POD_MAX_LEVELS];              // words per anchor shape: bit (a, hw) = word a*wpa + hw/64, bit hw%64
+    int32_t word_begin[POD_MAX_LEVELS + 1];   // level l = bitmap words [word_begin[l], word_begin[l+1]), K per (anchor shape, 64 cells)
+    int32_t unit_begin[POD_MAX_LEVELS + 1];   // work units (anchor shape a, 64-cell block): level l = [unit_begin[l], unit_begin[l+1])
+    int32_t wpa[POD_MAX_LEVELS];              // words per plane: bit (a, k, hw) = word (a*K + k)*wpa + hw/64, bit hw%64
     int32_t n_levels, n_runs, A, K, cls_samples;
     float score_thresh;
     uint64_t seed;
@@ -363,17 +368,29 @@ __global__ void __launch_bounds__(256) k1b_score_maybe(const K1bParams P) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int L = P.n_levels, K = P.K, A = P.A;
-    const int total_words = P.word_begin[L];
-    for (int w = wave; w < total_words; w += nwaves) {
-        unsigned long long m = P.maybe_bits[w];      // wave-uniform
-        if (m == 0ull) continue;
-        if (lane == 0) P.maybe_bits[w] = 0ull;       // leave the bitmap cleared for the next image
+    const int total_units = P.unit_begin[L];
+    for (int w = wave; w < total_units; w += nwaves) {
         int l = 0;
-        while (l + 1 < L && w >= P.word_begin[l + 1]) ++l;
+        while (l + 1 < L && w >= P.unit_begin[l + 1]) ++l;
         const PodLevel& lv = P.lv[l];
-        const int wl = w - P.word_begin[l];
+        const int wl = w - P.unit_begin[l];
         const int a = wl / P.wpa[l];
-        const int hw_base = (wl - a * P.wpa[l]) * 64;
+        const int blk = wl - a * P.wpa[l];
+        const int hw_base = blk * 64;
+        // the K words of this (anchor shape, 64 cells): lane k < K fetches (and clears) class k's word, OR over the lanes
+        unsigned long long mine = 0ull;
+        uint64_t* wk = P.maybe_bits + P.word_begin[l] + (int64_t)(a * K + (lane < K ? lane : 0)) * P.wpa[l] + blk;
+        if (lane < K) mine = *wk;
+        if (mine != 0ull) *wk = 0ull;                // leave the bitmap cleared for the next image
+        uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+#pragma unroll
+        for (int o = 1; o < POD_MAX_CLASSES; o <<= 1) {
+            lo |= __shfl_xor(lo, o, 64);
+            hi |= __shfl_xor(hi, o, 64);
+        }
+        unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
+                               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);      // wave-uniform
+        if (m == 0ull) continue;
         const int64_t HW = (int64_t)lv.H * lv.W;
         const float* src = P.n_runs > 1 ? P.mean_cls + (int64_t)lv.anchor_base * K : lv.cls;
         const float* srcv = P.n_runs > 1 ? P.mean_cls_var + (int64_t)lv.anchor_base * K : lv.cls_var;
@@ -493,7 +510,7 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
         for (int l = 0; l < L; ++l) {
             P.word_begin[l] = wb;
             P.wpa[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 63) / 64);
-            wb += A * P.wpa[l];
+            wb += A * K * P.wpa[l];
         }
         P.word_begin[L] = wb;
         for (int role = 0; role <= 2; ++role)
@@ -522,7 +539,8 @@ extern "C" int pod_mc_merge_score(const PodConfig* cfg, const PodLevel* levels, 
 extern "C" int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels) {
     if (!cfg || !levels || cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS) return POD_E_INVALID;
     int64_t w = 0;
-    for (int l = 0; l < cfg->n_levels; ++l) w += (int64_t)cfg->num_anchors * (((int64_t)levels[l].H * levels[l].W + 63) / 64);
+    for (int l = 0; l < cfg->n_levels; ++l)
+        w += (int64_t)cfg->num_anchors * cfg->num_classes * (((int64_t)levels[l].H * levels[l].W + 63) / 64);
     return w;
 }
 
@@ -535,19 +553,22 @@ extern "C" int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, con
     if (cfg->n_runs > 1 && (!mean_cls || !mean_cls_var)) return POD_E_INVALID;
     if (cfg->cls_samples < 1 || cfg->cls_samples > POD_MAX_CLS_SAMPLES) return POD_E_INVALID;
     pod::K1bParams P;
-    int32_t wb = 0;
+    int32_t wb = 0, ub = 0;
     for (int l = 0; l < L; ++l) {
         if (!levels[l].cls || !levels[l].cls_var || levels[l].eps_cls) return POD_E_INVALID;
         P.lv[l] = levels[l];
         P.wpa[l] = (int32_t)(((int64_t)levels[l].H * levels[l].W + 63) / 64);
         P.word_begin[l] = wb;
-        wb += cfg->num_anchors * P.wpa[l];
+        P.unit_begin[l] = ub;
+        wb += cfg->num_anchors * K * P.wpa[l];
+        ub += cfg->num_anchors * P.wpa[l];
     }
     P.word_begin[L] = wb;
+    P.unit_begin[L] = ub;
     P.n_levels = L; P.n_runs = cfg->n_runs; P.A = cfg->num_anchors; P.K = K; P.cls_samples = cfg->cls_samples;
     P.score_thresh = cfg->score_thresh; P.seed = cfg->philox_seed; P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var;
     P.maybe_bits = maybe_bits; P.cand_keys = cand_keys; P.cand_count = cand_count; P.probs_dense = probs_dense;
-    const int blocks = (wb + 3) / 4 < 1024 ? (wb + 3) / 4 : 1024;   // one wavefront per bitmap word up to a persistent 4096
+    const int blocks = (ub + 3) / 4 < 1024 ? (ub + 3) / 4 : 1024;   // one wavefront per work unit up to a persistent 4096
     const dim3 grid(blocks), block(256);
     if (K <= 8) hipLaunchKernelGGL(pod::k1b_score_maybe<8>, grid, block, 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(pod::k1b_score_maybe<16>, grid, block, 0, (hipStream_t)stream, P);

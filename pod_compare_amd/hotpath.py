@@ -136,7 +136,7 @@ class HotPath:
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
         self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count, [L:2L] K2's tickets
         self.cand_count = self.counters[: self.L]
-        n_words = sum(A * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words()
+        n_words = sum(A * K * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words(): a word per (plane, 64 cells)
         self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None
         # K2 outputs
         self.sel_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)
