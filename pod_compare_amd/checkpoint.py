@@ -125,7 +125,10 @@ def read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
         if any(k in sd for k in ("conv1_w", "res_conv1_bn_s")):
             sd = caffe2_to_detectron2_keys(sd)
     else:
-        data = torch.load(path, map_location="cpu", weights_only=False)
+        try:        # detectron2 checkpoints hold tensors, numbers and strings only: the restricted unpickler is enough
+            data = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:      # older files pickle numpy scalars / argparse namespaces next to the weights
+            data = torch.load(path, map_location="cpu", weights_only=False)
         sd = data["model"] if isinstance(data, dict) and "model" in data and isinstance(data["model"], dict) else data
     out = {}
     for k, v in sd.items():

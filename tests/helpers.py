@@ -25,7 +25,7 @@ def sha(tensors) -> str:
 
 
 def fixture_paths(prefix=""):
-    skip = ("unit_functions.npz", "eval_matching.npz")      # not whole-predictor fixtures
+    skip = ("unit_functions.npz", "eval_matching.npz", "eval_metrics.npz")     # not whole-predictor fixtures
     return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if not p.endswith(skip))
 
 
