@@ -1,0 +1,279 @@
+// 3x3 / stride 1 / pad 1 fp32 convolution of the probabilistic RetinaNet head's subnets (probabilistic_retinanet.py:403-427:
+// four conv3x3(256 -> 256) + ReLU + Dropout per subnet, evaluated for every MC run on every FPN level) as ONE launch over
+// all levels and all runs: Winograd F(2x2, 3x3) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), bias + ReLU + dropout
+// fused into the store.
+//
+// Why Winograd: a direct fp32 convolution is bounded by the 157 TFLOP/s fp32 MFMA peak (MIOpen's implicit GEMM reaches
+// 0.83 of it on the p3 maps and nothing can reach more than 1.0); F(2x2, 3x3) needs 16 multiplies per 2x2 outputs and
+// (c, k) pair instead of 36, so the same matrix cores deliver up to 2.25x the direct-convolution rate, in fp32 throughout
+// (the transforms only add and subtract; the filter transform has two halvings).  Error vs direct fp32: ~1e-6 relative.
+//
+//   Y = At [ (G g Gt) . (Bt d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs, "." summed over c
+//
+// Data layout (channels-last): activations are [pixel][C] fp32; every (level, run) image of a launch lives in the same
+// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of the image, H, W, by << 16 | bx}) says where.  Filters
+// are transformed once (pod_wino_filter_transform) into the image the kernel's LDS stages want.
+//
+// Workgroup = 256 threads = 4 waves, one per SIMD: 64 tiles (8x8 tiles = 16x16 output pixels) x 64 output channels x the
+// 16 Winograd positions.  Wave (wt, wk) owns 32 tiles x 32 channels: 16 positions x one 32x32 MFMA block = 256
+// accumulator registers, so the output transform At M A is per-lane arithmetic (every position's block has the same
+// lane <-> (tile, channel) map).  Per chunk of 8 input channels the workgroup stages the 18x18-pixel input patch (raw:
+// each wave applies Bt d B in registers, no transformed copy exists anywhere) and the 16 x 8 x 64 filter slab in LDS,
+// double-buffered against the 64 MFMAs of the chunk.  Bank layout: see the address comments.
+//
+// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1 MB
+// for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
+#include <mutex>
+
+#include "pod_device.h"
+
+namespace pod {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k8_model_ops.hip: same mask as pod_bias_act
+
+constexpr int WINO_U_FLOATS = 16 * 2 * 2 * 64 * 2;      // filter slab of a chunk: [p][sp][h][j][2]            32 KB
+constexpr int WINO_R_UNITS = 18 * 20;                    // 8-byte units of one (sp, h) plane of the raw patch
+constexpr int WINO_R_FLOATS = 2 * 2 * WINO_R_UNITS * 2;  // [sp][h][row 18][parity 2][col/2: 9 (+1 pad)][2]    11.25 KB
+constexpr int WINO_STAGE_FLOATS = WINO_U_FLOATS + WINO_R_FLOATS;
+constexpr int WINO_LDS_BYTES = 2 * WINO_STAGE_FLOATS * 4;   // 88 576 B (the 64 KB output staging reuses it)
+
+struct WinoParams {
+    const float* in;
+    float* out;
+    const float* U;
+    const float* bias;
+    const int4* blocks;
+    int32_t n_blocks, C, K, KS, in_stride, out_stride, relu;
+    uint32_t thresh;
+    float scale;
+    uint64_t seed, offset;
+};
+
+// Filter transform U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written as the LDS image of the main kernel:
+// U[ks][chunk][p][sp][h][j][s2] = U_p[c = 8 chunk + 4 h + 2 sp + s2][k = 64 ks + j]; channels >= K are zero.
+__global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w, float* __restrict__ U, int32_t K, int32_t C, int32_t Kpad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Kpad * C) return;
+    const int k = (int)(t / C), c = (int)(t % C);
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = k < K ? w[((int64_t)k * C + c) * 9 + i] : 0.0f;
+    float t0[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t0[0][j] = g[0][j];
+        t0[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        t0[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        t0[3][j] = g[2][j];
+    }
+    const int nchunk = C / 8, ks = k >> 6, j64 = k & 63, ch = c >> 3, cc = c & 7;
+    const int h = cc >> 2, sp = (cc >> 1) & 1, s2 = cc & 1;
+    float* dst = U + ((int64_t)ks * nchunk + ch) * WINO_U_FLOATS + ((sp * 2 + h) * 64 + j64) * 2 + s2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float u0 = t0[a][0], u1 = 0.5f * (t0[a][0] + t0[a][1] + t0[a][2]), u2 = 0.5f * (t0[a][0] - t0[a][1] + t0[a][2]),
+                    u3 = t0[a][2];
+        dst[(a * 4 + 0) * 512] = u0;
+        dst[(a * 4 + 1) * 512] = u1;
+        dst[(a * 4 + 2) * 512] = u2;
+        dst[(a * 4 + 3) * 512] = u3;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave & 1, wk = wave >> 1;
+    const int xcd = blockIdx.x & 7;
+    const int ks = xcd % P.KS;
+    const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
+    if (tb >= P.n_blocks) return;
+    const int4 desc = P.blocks[tb];
+    const int64_t base_px = desc.x;
+    const int H = desc.y, W = desc.z, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
+    const int nchunk = P.C >> 3;
+
+    // ---- global -> LDS plan of a chunk: 8 float4 of the filter slab (a straight copy) + up to 3 float4 of the raw patch
+    const float* usrc = P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS + tid * 4;
+    const float* rsrc[3];
+    int rdst[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int q = tid + 256 * r;              // (pixel of the 18x18 patch, channel half h)
+        const int pix = q >> 1, h = q & 1, py = pix / 18, px = pix - py * 18;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool in_img = q < 648 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        rsrc[r] = in_img ? P.in + (base_px + (int64_t)gy * W + gx) * P.in_stride + 4 * h : nullptr;
+        // 8-byte unit of the pixel inside an (sp, h) plane: rows of 20 units, even columns first -- the 32 lanes of an MFMA
+        // operand read (tile row stride 40 = 8 mod 32, tile column stride 1) hit 32 different units
+        rdst[r] = q < 648 ? (WINO_U_FLOATS + (h * WINO_R_UNITS + py * 20 + (px & 1) * 10 + (px >> 1)) * 2) : -1;
+    }
+    f32x4 gu[8], gr[3];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gu[r] = *reinterpret_cast<const f32x4*>(usrc + (int64_t)ch * WINO_U_FLOATS + r * 1024);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            gr[r] = rsrc[r] ? *reinterpret_cast<const f32x4*>(rsrc[r] + ch * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto stash = [&](float* stage) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<f32x4*>(stage + tid * 4 + r * 1024) = gu[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (rdst[r] >= 0) {
+                *reinterpret_cast<f32x2*>(stage + rdst[r]) = f32x2{gr[r].x, gr[r].y};                          // sp = 0
+                *reinterpret_cast<f32x2*>(stage + rdst[r] + 2 * WINO_R_UNITS * 2) = f32x2{gr[r].z, gr[r].w};   // sp = 1
+            }
+        }
+    };
+
+    // ---- operand addresses of this lane
+    const int i32 = lane & 31, h = lane >> 5;
+    const int ty = 4 * wt + (i32 >> 3), tx = i32 & 7;
+    const int a_base = WINO_U_FLOATS + (h * WINO_R_UNITS + 2 * ty * 20 + tx) * 2;     // + (a*20 + (b&1)*10 + (b>>1))*2 + sp*1440
+    const int b_base = (h * 64 + 32 * wk + i32) * 2;                                   // + p*512 + sp*256
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    fetch(0);
+    stash(lds);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float* stage = lds + (ch & 1) * WINO_STAGE_FLOATS;
+        if (ch + 1 < nchunk) fetch(ch + 1);
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            f32x2 d[4][4], u[16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    d[a][b] = *reinterpret_cast<const f32x2*>(stage + a_base + (a * 20 + (b & 1) * 10 + (b >> 1)) * 2 + sp * (2 * WINO_R_UNITS * 2));
+#pragma unroll
+            for (int p = 0; p < 16; ++p) u[p] = *reinterpret_cast<const f32x2*>(stage + b_base + p * 512 + sp * 256);
+            // V = Bt d B, Bt = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] (two channels at once)
+            f32x2 t[4][4], v[16];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                t[0][b] = d[0][b] - d[2][b];
+                t[1][b] = d[1][b] + d[2][b];
+                t[2][b] = d[2][b] - d[1][b];
+                t[3][b] = d[1][b] - d[3][b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                v[a * 4 + 0] = t[a][0] - t[a][2];
+                v[a * 4 + 1] = t[a][1] + t[a][2];
+                v[a * 4 + 2] = t[a][2] - t[a][1];
+                v[a * 4 + 3] = t[a][1] - t[a][3];
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p].x, u[p].x, acc[p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p].y, u[p].y, acc[p], 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) stash(lds + ((ch + 1) & 1) * WINO_STAGE_FLOATS);
+        __syncthreads();
+    }
+
+    // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]], per lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
+    // column (channel) = lane & 31.  Staged as [pixel of the 16x16 block][64 channels] for 16-byte stores along the channels.
+    {
+        const int kl = 32 * wk + i32;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int tyo = 4 * wt + (reg >> 2), txo = (reg & 3) + 4 * h;
+            float r0[4], r1[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float m0 = acc[a * 4 + 0][reg], m1 = acc[a * 4 + 1][reg], m2 = acc[a * 4 + 2][reg], m3 = acc[a * 4 + 3][reg];
+                r0[a] = m0 + m1 + m2;
+                r1[a] = m1 - m2 - m3;
+            }
+            float* o = lds + ((2 * tyo) * 16 + 2 * txo) * 64 + kl;
+            o[0] = r0[0] + r0[1] + r0[2];
+            o[64] = r1[0] + r1[1] + r1[2];
+            o[16 * 64] = r0[1] - r0[2] - r0[3];
+            o[17 * 64] = r1[1] - r1[2] - r1[3];
+        }
+    }
+    __syncthreads();
+    {
+        const int k4 = (tid & 15) * 4, kg = ks * 64 + k4;
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + kg);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int pix = it * 16 + (tid >> 4), oy = pix >> 4, ox = pix & 15;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (gy >= H || gx >= W) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(lds + pix * 64 + k4) + bias;
+            if (P.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            const int64_t e = (base_px + (int64_t)gy * W + gx) * P.out_stride + kg;
+            if (P.thresh) {
+                const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
+                const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
+                                              (uint32_t)(P.seed >> 32));
+                v.x = r.x >= P.thresh ? v.x * P.scale : 0.f;
+                v.y = r.y >= P.thresh ? v.y * P.scale : 0.f;
+                v.z = r.z >= P.thresh ? v.z * P.scale : 0.f;
+                v.w = r.w >= P.thresh ? v.w * P.scale : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(P.out + e) = v;
+        }
+    }
+}
+
+}  // namespace pod
+
+extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream) {
+    if (!weight || !U || K < 1 || C < 8 || (C & 7) != 0) return POD_E_INVALID;
+    const int32_t Kpad = (K + 63) / 64 * 64;
+    const int64_t n = (int64_t)Kpad * C;
+    hipLaunchKernelGGL(pod::k_wino_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, U, K, C, Kpad);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
+                                int32_t C, int32_t K, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
+    if (!in || !out || in == out || !U || !blocks || n_blocks < 0 || C < 8 || (C & 7) != 0 || K < 64 || (K & 63) != 0 ||
+        !(p >= 0.0f && p < 1.0f))
+        return POD_E_INVALID;
+    const int32_t KS = K / 64;
+    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) |
+          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
+        return POD_E_INVALID;
+    if (n_blocks == 0) return POD_OK;
+    static std::once_flag once;
+    static hipError_t attr = hipSuccess;
+    std::call_once(once, [] {
+        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   pod::WINO_LDS_BYTES);
+    });
+    if (attr != hipSuccess) return POD_E_LAUNCH;
+    pod::WinoParams P;
+    P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
+    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu;
+    P.thresh = (uint32_t)((double)p * 4294967296.0);
+    P.scale = 1.0f / (1.0f - p);
+    P.seed = seed; P.offset = offset;
+    const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
+    const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
+    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
