@@ -302,15 +302,19 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
  * RetinaNetHead.forward's loop over features): ONE launch covers all levels and all runs.  fp32 Winograd F(2x2,3x3) on the
  * fp32 matrix cores, bias + ReLU + dropout fused into the store.
  *
- * Activations are channels-last: in[pixel][C], out[pixel][K]; all images of the launch share the two buffers at the same
- * pixel offsets.  `blocks` (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of the image, H, W,
- * block_row << 16 | block_col}, one per 16x16-pixel output block (ceil(H/16) * ceil(W/16) per image).  C % 8 == 0,
- * K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 16 * round_up(K, 64) * C floats; weight is (K, C, 3, 3),
- * output channels past K are zero (so a K = 63 predictor runs as K = 64).  Dropout: keep iff Philox word >= p * 2^32,
- * counter = offset + (flat index of the output float4), the mask pod_bias_act draws on the same tensor. */
+ * Activations are channels-last: in[pixel][C], out[pixel][K]; all images of the launch live in the two buffers.  `blocks`
+ * (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of the image in `in`, first pixel of the image in
+ * `out`, H << 16 | W, block_row << 16 | block_col}, one per 16x16-pixel output block (ceil(H/16) * ceil(W/16) per image).
+ * C % 8 == 0, K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 16 * round_up(K, 64) * C floats; weight is
+ * (K, C, 3, 3), output channels past K are zero (so a K = 63 predictor runs as K = 64; bias then has round_up(K, 64) entries).
+ * k_planes == 0: out is channels-last.  k_planes > 0 (the predictor convs cls_score / bbox_pred / cls_var / bbox_cov,
+ * PR:430-484): out is NCHW, image = k_planes planes of H*W starting at float `k_planes * first pixel`: the (N, A*K, H, W)
+ * tensors pod_mc_merge_score streams; p must be 0.  Dropout: keep iff Philox word >= p * 2^32, counter = offset + (flat
+ * index of the output float4), the mask pod_bias_act draws on the same tensor. */
 int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                     int32_t C, int32_t K, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+                     int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
+                     pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

@@ -11,8 +11,10 @@
 //   Y = At [ (G g Gt) . (Bt d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs, "." summed over c
 //
 // Data layout (channels-last): activations are [pixel][C] fp32; every (level, run) image of a launch lives in the same
-// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of the image, H, W, by << 16 | bx}) says where.  Filters
-// are transformed once (pod_wino_filter_transform) into the image the kernel's LDS stages want.
+// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of the image in `in`, in `out`, H << 16 | W, by << 16 | bx})
+// says where.  Filters are transformed once (pod_wino_filter_transform) into the image the kernel's LDS stages want.
+// The predictor convolutions (cls_score, bbox_pred, cls_var, bbox_cov: K = 63 / 36 / 90 real channels) write NCHW planes,
+// the layout K1 streams, straight from the staging tile.
 //
 // Workgroup = 256 threads = 4 waves, one per SIMD: 64 tiles (8x8 tiles = 16x16 output pixels) x 64 output channels x the
 // 16 Winograd positions.  Wave (wt, wk) owns 32 tiles x 32 channels: 16 positions x one 32x32 MFMA block = 256
@@ -47,7 +49,7 @@ struct WinoParams {
     const float* U;
     const float* bias;
     const int4* blocks;
-    int32_t n_blocks, C, K, KS, in_stride, out_stride, relu;
+    int32_t n_blocks, C, K, KS, in_stride, out_stride, relu, k_planes;   // k_planes > 0: NCHW planes of k_planes real channels
     uint32_t thresh;
     float scale;
     uint64_t seed, offset;
@@ -93,8 +95,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
     if (tb >= P.n_blocks) return;
     const int4 desc = P.blocks[tb];
-    const int64_t base_px = desc.x;
-    const int H = desc.y, W = desc.z, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
+    const int64_t base_px = desc.x, out_px = desc.y;
+    const int H = desc.z >> 16, W = desc.z & 0xFFFF, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
     const int nchunk = P.C >> 3;
 
     // ---- global -> LDS plan of a chunk: 8 float4 of the filter slab (a straight copy) + up to 3 float4 of the raw patch
@@ -187,6 +189,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 
     // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]], per lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
     // column (channel) = lane & 31.  Staged as [pixel of the 16x16 block][64 channels] for 16-byte stores along the channels.
+    const int LD = P.k_planes > 0 ? 65 : 64;   // staging row: 16-byte reads along k (64) or scalar reads along the pixels (65)
     {
         const int kl = 32 * wk + i32;
 #pragma unroll
@@ -199,15 +202,41 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
                 r0[a] = m0 + m1 + m2;
                 r1[a] = m1 - m2 - m3;
             }
-            float* o = lds + ((2 * tyo) * 16 + 2 * txo) * 64 + kl;
+            float* o = lds + ((2 * tyo) * 16 + 2 * txo) * LD + kl;
             o[0] = r0[0] + r0[1] + r0[2];
-            o[64] = r1[0] + r1[1] + r1[2];
-            o[16 * 64] = r0[1] - r0[2] - r0[3];
-            o[17 * 64] = r1[1] - r1[2] - r1[3];
+            o[LD] = r1[0] + r1[1] + r1[2];
+            o[16 * LD] = r0[1] - r0[2] - r0[3];
+            o[17 * LD] = r1[1] - r1[2] - r1[3];
         }
     }
     __syncthreads();
-    {
+    if (P.k_planes > 0) {
+        // NCHW planes: thread -> (channel, row of the block, 4 pixels along x); 64-byte runs per (channel, row)
+        const int64_t HW = (int64_t)H * W;
+        float* plane0 = P.out + out_px * P.k_planes;
+        const bool vec = (W & 3) == 0 && ((out_px * P.k_planes) & 3) == 0;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid, k = idx >> 6, oy = (idx >> 2) & 15, ox = (idx & 3) * 4;
+            const int kg = ks * 64 + k, gy = y0 + oy, gx = x0 + ox;
+            if (kg >= P.k_planes || gy >= H || gx >= W) continue;
+            const float bias = P.bias ? P.bias[kg] : 0.0f;
+            const float* sp = lds + (oy * 16 + ox) * 65 + k;
+            f32x4 v = f32x4{sp[0], sp[65], sp[130], sp[195]} + bias;
+            if (P.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            float* dst = plane0 + kg * HW + (int64_t)gy * W + gx;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst) = v;      // W % 4 == 0: gx + 3 < W and 16-byte aligned
+            } else {
+                dst[0] = v.x;
+                if (gx + 1 < W) dst[1] = v.y;
+                if (gx + 2 < W) dst[2] = v.z;
+                if (gx + 3 < W) dst[3] = v.w;
+            }
+        }
+    } else {
         const int k4 = (tid & 15) * 4, kg = ks * 64 + k4;
         f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + kg);
@@ -220,7 +249,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            const int64_t e = (base_px + (int64_t)gy * W + gx) * P.out_stride + kg;
+            const int64_t e = (out_px + (int64_t)gy * W + gx) * P.out_stride + kg;
             if (P.thresh) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
                 const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
@@ -247,9 +276,10 @@ extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t 
 }
 
 extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                                int32_t C, int32_t K, int32_t relu, float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {
+                                int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
+                                pod_stream_t stream) {
     if (!in || !out || in == out || !U || !blocks || n_blocks < 0 || C < 8 || (C & 7) != 0 || K < 64 || (K & 63) != 0 ||
-        !(p >= 0.0f && p < 1.0f))
+        !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
         return POD_E_INVALID;
     const int32_t KS = K / 64;
     if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
@@ -266,7 +296,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     if (attr != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
-    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu;
+    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
     P.thresh = (uint32_t)((double)p * 4294967296.0);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;

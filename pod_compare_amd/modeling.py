@@ -149,6 +149,7 @@ def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
     return cached[1]
 
 
+WINO_HEAD = True              # GPU only: the head subnets' 3x3 convs on pod_wino_conv3x3 (all levels, all runs per launch)
 NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run channels-last (p3 of a 768x1344 input: 16128)
 
 
@@ -288,6 +289,58 @@ class ProbabilisticRetinaNetHead(nn.Module):
                 x = self._relu_dropout(conv(x))
         return x
 
+    def _wino(self, conv: nn.Conv2d):
+        """The conv's Winograd-transformed filter (pod_wino_filter_transform), refreshed when the parameters change."""
+        from .wino import WinoConv
+        key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+        cached = getattr(conv, "_pod_wino", None)
+        if cached is None or cached[0] != key:
+            cached = (key, WinoConv(conv.weight, conv.bias))
+            torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
+            conv._pod_wino = cached
+        return cached[1]
+
+    def _trunk_all_levels(self, convs, x0: torch.Tensor, levels, copies: int, dropout: bool):
+        """`copies` evaluations of a subnet on ALL levels: one pod_wino_conv3x3 launch per conv layer (fp32 Winograd on the
+        matrix cores, bias + ReLU + dropout in its store) instead of one MIOpen call + one element-wise pass per level and
+        layer.  x0: (pixels of all levels, C) channels-last, level after level.  Returns per level a (copies | 1, C, H, W)
+        channels-last view of the last activation."""
+        from . import hip
+        from .wino import block_table, level_pixel_offsets
+        lib, C = hip.load(), x0.shape[1]
+        t1 = block_table(levels, 1, x0.device)
+        off1 = level_pixel_offsets(levels, 1)
+        y = self._wino(convs[0])(x0, torch.empty_like(x0), t1, relu=True)          # identical for every copy: computed once
+        if not dropout:
+            for conv in convs[1:]:
+                y = self._wino(conv)(y, torch.empty_like(y), t1, relu=True)
+            return y, 1
+        offn = level_pixel_offsets(levels, copies)
+        a = torch.empty((offn[-1], C), dtype=x0.dtype, device=x0.device)
+        for i, (h, w) in enumerate(levels):                                         # copies x dropout(first activation)
+            self._drop_calls += 1
+            hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies, float(self.dropout_rate),
+                                             self.dropout_seed, self._drop_calls << 34, hip.current_stream()), "pod_expand_dropout")
+        tn = block_table(levels, copies, x0.device)
+        b = torch.empty_like(a)
+        for conv in convs[1:]:
+            self._drop_calls += 1
+            self._wino(conv)(a, b, tn, relu=True, dropout_p=self.dropout_rate, seed=self.dropout_seed, offset=self._drop_calls << 34)
+            a, b = b, a
+        return a, copies
+
+    def _predict_all_levels(self, conv, buf: torch.Tensor, levels, buf_copies: int, first: int, count: int, out_copies: int):
+        """A predictor conv (cls_score / bbox_pred / cls_var / bbox_cov, PR:430-484) on images first .. first+count-1 of every level
+        of a trunk buffer, one launch; returns per level an (out_copies, K, H, W) NCHW tensor -- the planes K1 streams -- whose
+        images past `count` are zero (never uninitialised memory: a consumer without the quirk merge would read them)."""
+        from .wino import block_table, level_pixel_offsets
+        K = conv.out_channels
+        offs = level_pixel_offsets(levels, out_copies)
+        out = (torch.zeros if out_copies > count else torch.empty)(offs[-1] * K, dtype=buf.dtype, device=buf.device)
+        table = block_table(levels, count, buf.device, in_copies=buf_copies, in_first=first, out_copies=out_copies)
+        self._wino(conv)(buf, out, table, planes=True)
+        return [out[offs[i] * K:offs[i + 1] * K].view(out_copies, K, h, w) for i, (h, w) in enumerate(levels)]
+
     def _relu_dropout(self, x: torch.Tensor) -> torch.Tensor:
         """ReLU + Dropout(p) after a subnet conv (PR:403-424).  On the GPU one fused in-place HIP pass
         (pod_relu_dropout) instead of torch's clamp + fused_dropout kernels."""
@@ -323,9 +376,34 @@ class ProbabilisticRetinaNetHead(nn.Module):
             return out                                            # the quirk merge would read it); 1/n of one small tensor
 
         logits, deltas, logit_vars, delta_covs = [], [], [], []
+        cls_copies = m * (2 if self.compute_cls_var else 1)
+        box_copies = n + (m if self.compute_bbox_cov else 0)
+        wino = (WINO_HEAD and self.fused_relu_dropout and FUSE_CONV_TAIL and features[0].is_cuda and features[0].dtype == torch.float32
+                and features[0].shape[0] == 1 and features[0].shape[1] % 8 == 0 and self.cls_subnet[0].out_channels in (64, 128, 256, 512)
+                and max(c.out_channels for c in (self.cls_score, self.bbox_pred, self.cls_var, self.bbox_cov) if c is not None) <= 512)
+        if wino:
+            # every conv of the head on pod_wino_conv3x3: one launch per layer over all levels and all runs
+            levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
+            x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
+            tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
+            tb, nb = self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)
+            if dropout:
+                logits = self._predict_all_levels(self.cls_score, tc, levels, nc, 0, m, n)
+                deltas = self._predict_all_levels(self.bbox_pred, tb, levels, nb, 0, n, n)
+                if self.compute_cls_var:
+                    logit_vars = self._predict_all_levels(self.cls_var, tc, levels, nc, m, m, n)   # independent dropout draw (Q2)
+                if self.compute_bbox_cov:
+                    delta_covs = self._predict_all_levels(self.bbox_cov, tb, levels, nb, n, m, n)
+            else:
+                ex = (lambda ts: [t.expand(n, -1, -1, -1).contiguous() for t in ts]) if n > 1 else (lambda ts: ts)
+                logits = ex(self._predict_all_levels(self.cls_score, tc, levels, 1, 0, 1, 1))
+                deltas = ex(self._predict_all_levels(self.bbox_pred, tb, levels, 1, 0, 1, 1))
+                if self.compute_cls_var:
+                    logit_vars = ex(self._predict_all_levels(self.cls_var, tc, levels, 1, 0, 1, 1))
+                if self.compute_bbox_cov:
+                    delta_covs = ex(self._predict_all_levels(self.bbox_cov, tb, levels, 1, 0, 1, 1))
+            return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
         for f in features:
-            cls_copies = m * (2 if self.compute_cls_var else 1)
-            box_copies = n + (m if self.compute_bbox_cov else 0)
             tc = self._trunk(self.cls_subnet, f, cls_copies, dropout)
             tb = self._trunk(self.bbox_subnet, f, box_copies, dropout)
             if dropout:

@@ -20,23 +20,33 @@ def level_pixel_offsets(levels: Sequence[Tuple[int, int]], copies: int) -> List[
 _TABLES = {}
 
 
-def block_table(levels: Sequence[Tuple[int, int]], copies: int, device) -> torch.Tensor:
-    """int32 (n_blocks, 4) {first pixel of the image, H, W, block_row << 16 | block_col}: one record per 16x16 output block.
-    Blocks of one image are adjacent (their input halos overlap: L2 reuse); big levels first."""
-    key = (tuple(levels), copies, str(device))
+def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copies: Optional[int] = None, in_first: int = 0,
+                out_copies: Optional[int] = None) -> torch.Tensor:
+    """int32 (n_blocks, 4) {first pixel of the image in the input buffer, in the output buffer, H << 16 | W,
+    block_row << 16 | block_col}: one record per 16x16 output block of `copies` images per level.  The input buffer holds
+    `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read; the output buffer
+    holds `out_copies` per level and images 0 .. copies - 1 are written.  Blocks of one image are adjacent (their input halos
+    overlap: L2 reuse)."""
+    in_copies = copies if in_copies is None else in_copies
+    out_copies = copies if out_copies is None else out_copies
+    assert in_first + copies <= in_copies and copies <= out_copies
+    key = (tuple(levels), copies, in_copies, in_first, out_copies, str(device))
     t = _TABLES.get(key)
     if t is None:
-        offs = level_pixel_offsets(levels, copies)
+        ioffs, ooffs = level_pixel_offsets(levels, in_copies), level_pixel_offsets(levels, out_copies)
         rows = []
-        for (h, w), off in zip(levels, offs):
+        for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
+            assert h < 65536 and w < 65536
             by, bx = (h + 15) // 16, (w + 15) // 16
             n = torch.arange(copies, dtype=torch.int64).view(-1, 1, 1)
             y = torch.arange(by, dtype=torch.int64).view(1, -1, 1)
             x = torch.arange(bx, dtype=torch.int64).view(1, 1, -1)
-            rec = torch.stack(torch.broadcast_tensors(off + n * h * w, torch.tensor(h), torch.tensor(w), (y << 16) | x), dim=-1)
+            rec = torch.stack(torch.broadcast_tensors(ioff + (in_first + n) * h * w, ooff + n * h * w, torch.tensor((h << 16) | w),
+                                                      (y << 16) | x), dim=-1)
             rows.append(rec.reshape(-1, 4))
+        assert max(ioffs[-1], ooffs[-1]) < 2 ** 31
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()
-        assert offs[-1] < 2 ** 31
+        t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table
         _TABLES[key] = t
     return t
 
@@ -62,11 +72,12 @@ class WinoConv:
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
 
     def __call__(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, relu: bool = False, dropout_p: float = 0.0,
-                 seed: int = 0, offset: int = 0) -> torch.Tensor:
-        """src: (pixels, C), dst: (pixels, Kpad), both contiguous fp32 on the GPU."""
-        assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and dst.shape[-1] == self.Kpad
-        assert src.shape[0] == dst.shape[0] and src.dtype == dst.dtype == torch.float32
+                 seed: int = 0, offset: int = 0, planes: bool = False) -> torch.Tensor:
+        """src: (pixels, C) channels-last.  dst: (pixels, Kpad) channels-last, or with planes=True any contiguous buffer of
+        NCHW images with K (real) planes each, level-major like the table's output side."""
+        assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and src.dtype == dst.dtype == torch.float32
+        assert planes or dst.shape[-1] == self.Kpad
         hip.check(hip.load().pod_wino_conv3x3(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
-                                              table.shape[0], self.C, self.Kpad, 1 if relu else 0, float(dropout_p), seed, offset,
-                                              hip.current_stream()), "pod_wino_conv3x3")
+                                              table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
+                                              seed, offset, hip.current_stream()), "pod_wino_conv3x3")
         return dst

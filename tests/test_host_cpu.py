@@ -293,3 +293,19 @@ def test_coco_image_list_is_mapped_like_detectron2s_test_loader(tmp_path):
     assert (a["height"], a["width"], a["image_id"]) == (72, 128, 901)
     b = ds[1]
     assert tuple(b["image"].shape) == (3, 80, 100) and (b["height"], b["width"], b["image_id"]) == (40, 50, 17)
+
+
+def test_wino_block_table_lists_every_16x16_block_once():
+    """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {in pixel, out pixel, H<<16|W, by<<16|bx}."""
+    from pod_compare_amd.wino import block_table, level_pixel_offsets
+    levels = [(23, 40), (6, 10)]
+    assert level_pixel_offsets(levels, 3) == [0, 3 * 920, 3 * 920 + 3 * 60]
+    t = block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3)
+    assert t.dtype == torch.int32 and t.shape == (2 * (2 * 3) + 2 * 1, 4)
+    rows = t.tolist()
+    assert rows[0] == [1 * 920, 0, (23 << 16) | 40, 0] and rows[5] == [920, 0, (23 << 16) | 40, (1 << 16) | 2]
+    assert rows[6][:2] == [2 * 920, 920]                                        # second image of the first level
+    assert rows[12] == [5 * 920 + 1 * 60, 3 * 920, (6 << 16) | 10, 0]          # first image of the second level
+    assert rows[13] == [5 * 920 + 2 * 60, 3 * 920 + 60, (6 << 16) | 10, 0]
+    assert len({tuple(r) for r in rows}) == len(rows)
+    assert block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3) is t      # cached

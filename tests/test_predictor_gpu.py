@@ -185,10 +185,17 @@ def test_eval_mode_trunk_sharing_on_the_gpu():
         calls["n"] += 1
         return real(convs, feature, copies, dropout)
 
+    real_all = model.head._trunk_all_levels
+
+    def counting_all(convs, x0, levels, copies, dropout):
+        calls["n"] += len(levels)
+        return real_all(convs, x0, levels, copies, dropout)
+
     model.head._trunk = counting
+    model.head._trunk_all_levels = counting_all
     cls, delta, cls_var, reg_var = model.head(feats, 1, mc_dropout=False)
     assert calls["n"] == 2 * len(feats)                           # one cls trunk + one box trunk per level, not four
-    model.head._trunk = real
+    model.head._trunk, model.head._trunk_all_levels = real, real_all
     for l, f in enumerate(feats):
         tc, tb = f, f
         for conv in model.head.cls_subnet:

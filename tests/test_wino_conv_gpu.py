@@ -1,0 +1,149 @@
+"""pod_wino_conv3x3 (csrc/k11_wino_conv.hip): the head's 3x3 convolutions (probabilistic_retinanet.py:403-484) as fp32 Winograd
+on the matrix cores, against torch's conv2d on the same tensors.  Tolerance 2e-5 of the output's scale (fp32 Winograd F(2x2,3x3)
+differs from a direct fp32 convolution by a few 1e-6 relative at C = 256)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pod_compare_amd import hip, modeling
+from pod_compare_amd.wino import WinoConv, block_table, level_pixel_offsets
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def flat(xs):
+    return torch.cat([x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]) for x in xs]).contiguous()
+
+
+def make(levels, copies, C, K, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    xs = [torch.randn(copies, C, h, wd, device="cuda", generator=g) for h, wd in levels]
+    return w, b, xs
+
+
+@pytest.mark.parametrize("levels,copies,C,K", [
+    ([(16, 16)], 1, 8, 64),                                   # one block, one chunk
+    ([(1, 1), (2, 3), (17, 33)], 2, 16, 64),                  # degenerate maps, partial blocks
+    ([(23, 40), (12, 20), (6, 10)], 3, 64, 128),              # the small FPN levels of a 720p frame (odd sizes, W % 4 != 0)
+    ([(45, 80), (6, 10)], 2, 256, 256),                       # the head's channel counts
+    ([(20, 24)], 1, 32, 512),
+])
+def test_channels_last_output_equals_conv2d(levels, copies, C, K):
+    w, b, xs = make(levels, copies, C, K)
+    conv = WinoConv(w, b)
+    src = flat(xs)
+    dst = torch.full((src.shape[0], K), float("nan"), device="cuda")
+    conv(src, dst, block_table(levels, copies, "cuda"), relu=True)
+    offs = level_pixel_offsets(levels, copies)
+    for i, (x, (h, wd)) in enumerate(zip(xs, levels)):
+        want = F.conv2d(x, w, b, padding=1).relu()
+        got = dst[offs[i]:offs[i + 1]].view(copies, h, wd, K).permute(0, 3, 1, 2)
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("K", [63, 36, 90])
+def test_predictor_planes_of_a_subset_of_the_runs(K):
+    """cls_score / bbox_pred / bbox_cov shapes: K real channels (padded to 64 / 128 inside), NCHW planes out, reading runs
+    first .. first+count-1 of a buffer of 5 runs per level, writing a buffer of 4 runs per level whose last run stays as it was."""
+    levels, in_copies, first, count, out_copies = [(23, 40), (12, 20), (6, 10), (3, 5)], 5, 2, 3, 4
+    w, b, xs = make(levels, in_copies, 64, K, seed=K)
+    conv = WinoConv(w, b)
+    src = flat(xs)
+    offs = level_pixel_offsets(levels, out_copies)
+    out = torch.full((offs[-1] * K,), 7.0, device="cuda")
+    conv(src, out, block_table(levels, count, "cuda", in_copies=in_copies, in_first=first, out_copies=out_copies), planes=True)
+    for i, (x, (h, wd)) in enumerate(zip(xs, levels)):
+        got = out[offs[i] * K:offs[i + 1] * K].view(out_copies, K, h, wd)
+        want = F.conv2d(x[first:first + count], w, b, padding=1)
+        assert float((got[:count] - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+        assert bool((got[count:] == 7.0).all())
+
+
+def test_dropout_mask_is_the_one_pod_bias_act_draws():
+    """bias + ReLU + dropout in the conv's store == the conv without them followed by pod_bias_act on the same channels-last
+    tensor (same Philox counters), bit for bit."""
+    levels, copies, C, K = [(20, 28), (5, 7)], 2, 32, 64
+    w, b, xs = make(levels, copies, C, K, seed=3)
+    src, table = flat(xs), block_table(levels, copies, "cuda")
+    fused = WinoConv(w, b)(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=0.3, seed=1234, offset=5 << 34)
+    plain = WinoConv(w, None)(src, torch.empty(src.shape[0], K, device="cuda"), table)
+    hip.check(hip.load().pod_bias_act(plain.data_ptr(), b.data_ptr(), None, None, plain.numel(), K, 1, 1, 0.3, 1234, 5 << 34,
+                                      hip.current_stream()), "pod_bias_act")
+    assert torch.equal(fused, plain)
+    dropped = float((fused == 0).float().mean())
+    assert 0.5 < dropped < 0.8                                  # ReLU zeroes half, dropout 30 % of the rest
+
+
+def test_invalid_arguments_are_rejected():
+    lib = hip.load()
+    x = torch.zeros(256, 8, device="cuda")
+    y = torch.zeros(256, 64, device="cuda")
+    u = torch.zeros(16 * 64 * 8, device="cuda")
+    t = block_table([(16, 16)], 1, "cuda")
+    s = hip.current_stream()
+    ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)
+    assert ok == 0
+    for args in ((x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 12, 64, 0, 0, 0.0, 0, 0, s),      # C % 8
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 96, 0, 0, 0.0, 0, 0, s),       # K % 64
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 192, 0, 0, 0.0, 0, 0, s),      # K / 64 not in 1,2,4,8
+                 (x.data_ptr(), x.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s),       # in place
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 63, 0, 0.5, 0, 0, s),      # planes + dropout
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 1.0, 0, 0, s),       # p = 1
+                 (x.data_ptr(), y.data_ptr(), None, None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)):
+        assert lib.pod_wino_conv3x3(*args) == -1
+    assert lib.pod_wino_filter_transform(u.data_ptr(), u.data_ptr(), 64, 12, s) == -1
+
+
+@pytest.mark.parametrize("cov_type", ["diagonal", "full"])
+def test_head_on_the_winograd_kernel_equals_the_miopen_head(cov_type):
+    """The whole head (eval mode, so deterministic): every conv on pod_wino_conv3x3 (one launch per layer over all levels)
+    against the per-level MIOpen path."""
+    torch.manual_seed(11)
+    model = modeling.ProbabilisticRetinaNet(dropout_rate=0.1, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                            bbox_cov_loss="negative_log_likelihood", bbox_cov_type=cov_type).cuda().eval()
+    for q in model.parameters():
+        q.requires_grad_(False)
+    for conv in list(model.head.cls_subnet) + list(model.head.bbox_subnet):
+        conv.weight.mul_(8.0)                                    # std 0.01 filters would shrink the activations to nothing
+        conv.bias.normal_(0.0, 0.1)
+    feats = [torch.randn(1, 256, h, w, device="cuda") for h, w in ((23, 40), (12, 20), (6, 10))]
+    try:
+        modeling.WINO_HEAD = True
+        got = model.head(feats, 3, mc_dropout=False)
+        modeling.WINO_HEAD = False
+        want = model.head(feats, 3, mc_dropout=False)
+    finally:
+        modeling.WINO_HEAD = True
+    for g_l, w_l in zip(got, want):
+        for g, w in zip(g_l, w_l):
+            assert g.shape == w.shape and g.is_contiguous()
+            assert float((g - w).abs().max()) <= TOL * max(1.0, float(w.abs().max()))
+
+
+def test_mc_dropout_head_shapes_skipped_run_and_statistics():
+    """MC mode through the Winograd head: (N, A*K, H, W) planes per level; the skipped last run of cls / cls_var / reg_var is
+    zero, box_delta's is not; runs differ (independent masks); the mean over runs stays near the eval-mode output."""
+    torch.manual_seed(12)
+    model = modeling.ProbabilisticRetinaNet(dropout_rate=0.1, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                            bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    for q in model.parameters():
+        q.requires_grad_(False)
+    for conv in list(model.head.cls_subnet) + list(model.head.bbox_subnet):
+        conv.weight.mul_(8.0)
+    feats = [torch.randn(1, 256, h, w, device="cuda") for h, w in ((24, 32), (12, 16))]
+    n = 6
+    cls, delta, cls_var, reg_var = model.head(feats, n, mc_dropout=True, skip_unused_last_run=True)
+    for l, f in enumerate(feats):
+        assert cls[l].shape == (n, 63, f.shape[2], f.shape[3]) and delta[l].shape == (n, 36, f.shape[2], f.shape[3])
+        for t in (cls[l], cls_var[l], reg_var[l]):
+            assert float(t[n - 1].abs().max()) == 0.0 and float(t[n - 2].abs().max()) > 0.0
+        assert float(delta[l][n - 1].abs().max()) > 0.0
+        assert float((delta[l][0] - delta[l][1]).abs().max()) > 0.0
+    ev = model.head(feats, 1, mc_dropout=False)
+    many = model.head(feats, 48, mc_dropout=True)
+    mean, ref = many[1][0].mean(0), ev[1][0][0]
+    assert float((mean - ref).abs().mean()) < 0.35 * float(ref.abs().mean()) + 1e-6

@@ -62,4 +62,21 @@ if __name__ == "__main__":
     run(LEVELS[:1], copies)
     run(LEVELS, copies)
     run(LEVELS, 1)
+    # predictor shape: K = 63 planes from 9 of 18 runs
+    import torch
+    from pod_compare_amd.wino import level_pixel_offsets
+    w = torch.randn(63, 256, 3, 3, device=dev) * 0.05
+    conv = WinoConv(w, None)
+    src = torch.randn(level_pixel_offsets(LEVELS, 18)[-1], 256, device=dev)
+    out = torch.empty(level_pixel_offsets(LEVELS, 10)[-1] * 63, device=dev)
+    tab = block_table(LEVELS, 9, dev, in_copies=18, in_first=9, out_copies=10)
+    conv(src, out, tab, planes=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        conv(src, out, tab, planes=True)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / 5
+    print("predictor K=63, 9 runs, all levels: %.3f ms = %.1f TFLOP/s direct-equivalent (real channels)" % (ms, 2.0 * 9 * 19220 * 256 * 63 * 9 / ms / 1e9))
     print("done in %.1f s" % (time.time() - t0))
