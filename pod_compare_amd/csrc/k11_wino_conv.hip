@@ -21,10 +21,11 @@
 // accumulator registers, so the output transform At M A is per-lane arithmetic (every position's block has the same
 // lane <-> (tile, channel) map).  Per chunk of 8 input channels the workgroup stages the 18x18-pixel input patch (raw:
 // each wave applies Bt d B in registers, no transformed copy exists anywhere) and the 16 x 8 x 64 filter slab in LDS,
-// double-buffered against the 64 MFMAs of the chunk.  Bank layout: see the address comments.
+// triple-buffered against the 64 MFMAs of the chunk.  Bank layout: see the address comments.
 //
 // Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1 MB
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
+#include <cstdlib>
 #include <mutex>
 
 #include "pod_device.h"
@@ -41,7 +42,7 @@ constexpr int WINO_U_FLOATS = 16 * 2 * 2 * 64 * 2;      // filter slab of a chun
 constexpr int WINO_R_UNITS = 18 * 20;                    // 8-byte units of one (sp, h) plane of the raw patch
 constexpr int WINO_R_FLOATS = 2 * 2 * WINO_R_UNITS * 2;  // [sp][h][row 18][parity 2][col/2: 9 (+1 pad)][2]    11.25 KB
 constexpr int WINO_STAGE_FLOATS = WINO_U_FLOATS + WINO_R_FLOATS;
-constexpr int WINO_LDS_BYTES = 2 * WINO_STAGE_FLOATS * 4;   // 88 576 B (the 64 KB output staging reuses it)
+constexpr int WINO_LDS_BYTES = 3 * WINO_STAGE_FLOATS * 4;   // 132 864 B of the CU's 160 KB (the 64 KB output staging reuses it)
 
 struct WinoParams {
     const float* in;
@@ -86,6 +87,14 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
     }
 }
 
+// -DPOD_WINO_EXP (diagnostics only): POD_WINO_EXP=<bits> in the environment drops parts of the main loop to time the rest
+// (results are then wrong): 1 no global fetch, 2 no LDS stash, 4 no barrier, 8 no operand reads / transform, 16 no epilogue.
+#ifdef POD_WINO_EXP
+#define WINO_X(bit) ((EXP & (bit)) != 0)
+template <int EXP>
+#else
+#define WINO_X(bit) false
+#endif
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,38 +108,38 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int H = desc.z >> 16, W = desc.z & 0xFFFF, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
     const int nchunk = P.C >> 3;
 
-    // ---- global -> LDS plan of a chunk: 8 float4 of the filter slab (a straight copy) + up to 3 float4 of the raw patch
-    const float* usrc = P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS + tid * 4;
-    const float* rsrc[3];
-    int rdst[3];
+    // ---- global -> LDS plan of a chunk: 8 float4 of the filter slab (a straight copy) + up to 3 float4 of the raw patch, as
+    // buffer loads: scalar base + 32-bit lane offset + scalar chunk offset (no 64-bit address arithmetic in the loop), and
+    // an out-of-range offset reads as 0.0 -- that IS the zero padding of the convolution (and the "no item" case).
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
+                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0, H * W * P.in_stride * 4,
+                                                          0x00020000);
+    int roff[3], rdst[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int q = tid + 256 * r;              // (pixel of the 18x18 patch, channel half h)
         const int pix = q >> 1, h = q & 1, py = pix / 18, px = pix - py * 18;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool in_img = q < 648 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        rsrc[r] = in_img ? P.in + (base_px + (int64_t)gy * W + gx) * P.in_stride + 4 * h : nullptr;
+        const bool ok = q < 648 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        roff[r] = ok ? ((gy * W + gx) * P.in_stride + 4 * h) * 4 : 0x7FFFFF00;
         // 8-byte unit of the pixel inside an (sp, h) plane: rows of 20 units, even columns first -- the 32 lanes of an MFMA
-        // operand read (tile row stride 40 = 8 mod 32, tile column stride 1) hit 32 different units
-        rdst[r] = q < 648 ? (WINO_U_FLOATS + (h * WINO_R_UNITS + py * 20 + (px & 1) * 10 + (px >> 1)) * 2) : -1;
+        // operand read (tile row stride 40 = 8 mod 32, tile column stride 1) hit 32 different units.  Unit 9 of a row is
+        // padding nobody reads: threads without an item store there (no branch in the loop).
+        rdst[r] = WINO_U_FLOATS + (q < 648 ? (h * WINO_R_UNITS + py * 20 + (px & 1) * 10 + (px >> 1)) : 9) * 2;
     }
+    // A chunk's copy in 11 pieces (loads) / 14 pieces (stores): piece i rides behind the i-th MFMA of a phase.
     f32x4 gu[8], gr[3];
-    auto fetch = [&](int ch) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) gu[r] = *reinterpret_cast<const f32x4*>(usrc + (int64_t)ch * WINO_U_FLOATS + r * 1024);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            gr[r] = rsrc[r] ? *reinterpret_cast<const f32x4*>(rsrc[r] + ch * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch_piece = [&](int ch, int i, f32x4(&su)[8], f32x4(&sr)[3]) {
+        if (i < 8) su[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, tid * 16, ch * (WINO_U_FLOATS * 4) + i * 4096, 0));
+        else if (i < 11) sr[i - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, roff[i - 8], ch * 32, 0));
     };
-    auto stash = [&](float* stage) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) *reinterpret_cast<f32x4*>(stage + tid * 4 + r * 1024) = gu[r];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (rdst[r] >= 0) {
-                *reinterpret_cast<f32x2*>(stage + rdst[r]) = f32x2{gr[r].x, gr[r].y};                          // sp = 0
-                *reinterpret_cast<f32x2*>(stage + rdst[r] + 2 * WINO_R_UNITS * 2) = f32x2{gr[r].z, gr[r].w};   // sp = 1
-            }
+    auto stash_piece = [&](float* stage, int i, const f32x4(&su)[8], const f32x4(&sr)[3]) {
+        if (i < 8) {
+            *reinterpret_cast<f32x4*>(stage + tid * 4 + i * 1024) = su[i];
+        } else if (i < 14) {
+            const int r = (i - 8) >> 1, sp = (i - 8) & 1;
+            *reinterpret_cast<f32x2*>(stage + rdst[r] + sp * (2 * WINO_R_UNITS * 2)) = sp ? f32x2{sr[r].z, sr[r].w} : f32x2{sr[r].x, sr[r].y};
         }
     };
 
@@ -146,46 +155,118 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    fetch(0);
-    stash(lds);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float* stage = lds + (ch & 1) * WINO_STAGE_FLOATS;
-        if (ch + 1 < nchunk) fetch(ch + 1);
+    // Software pipeline.  A chunk is two sub-steps of 2 MFMA k-steps (32 MFMAs, 2048 cycles); sub-step i's block issues the
+    // LDS reads of sub-step i+1 first, transforms them (Bt d B: VALU work the matrix pipe does not see) between its own MFMAs,
+    // and only then needs them.  One barrier per chunk, in the middle: the stage of chunk ch+1 is written during sub-step 0 of
+    // chunk ch (its last readers finished before the previous barrier) from registers fetched one chunk earlier.
+    f32x2 d[16], t[16], uA[16], uB[16], vA[16], vB[16];
+    // operand reads of a sub-step in 16 pieces of two 8-byte reads (one ds_read2): patch first (the transform needs it first)
+    auto read_piece = [&](const float* stage, int sp, f32x2(&u)[16], int i) {
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            f32x2 d[4][4], u[16];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    d[a][b] = *reinterpret_cast<const f32x2*>(stage + a_base + (a * 20 + (b & 1) * 10 + (b >> 1)) * 2 + sp * (2 * WINO_R_UNITS * 2));
-#pragma unroll
-            for (int p = 0; p < 16; ++p) u[p] = *reinterpret_cast<const f32x2*>(stage + b_base + p * 512 + sp * 256);
-            // V = Bt d B, Bt = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] (two channels at once)
-            f32x2 t[4][4], v[16];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                t[0][b] = d[0][b] - d[2][b];
-                t[1][b] = d[1][b] + d[2][b];
-                t[2][b] = d[2][b] - d[1][b];
-                t[3][b] = d[1][b] - d[3][b];
+        for (int e = 2 * i; e < 2 * i + 2; ++e) {
+            if (e < 16) {
+                const int a = e >> 2, b = e & 3;
+                d[e] = *reinterpret_cast<const f32x2*>(stage + a_base + (a * 20 + (b & 1) * 10 + (b >> 1)) * 2 + sp * (2 * WINO_R_UNITS * 2));
+            } else {
+                u[e - 16] = *reinterpret_cast<const f32x2*>(stage + b_base + (e - 16) * 512 + sp * 256);
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                v[a * 4 + 0] = t[a][0] - t[a][2];
-                v[a * 4 + 1] = t[a][1] + t[a][2];
-                v[a * 4 + 2] = t[a][2] - t[a][1];
-                v[a * 4 + 3] = t[a][1] - t[a][3];
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p].x, u[p].x, acc[p], 0, 0, 0);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p].y, u[p].y, acc[p], 0, 0, 0);
         }
-        if (ch + 1 < nchunk) stash(lds + ((ch + 1) & 1) * WINO_STAGE_FLOATS);
-        __syncthreads();
+    };
+    // V = Bt d B, Bt = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] (two channels at once), in 16 pieces of 4 adds:
+    // pieces 0..7 t = Bt d, pieces 8..15 V = t B
+    auto transform_piece = [&](f32x2(&v)[16], int i) {
+#pragma unroll
+        for (int k = 2 * (i & 7); k < 2 * (i & 7) + 2; ++k) {
+            const int a = k >> 2, b = k & 3;
+            if (i < 8) {
+                t[k] = a == 0 ? d[b] - d[8 + b] : a == 1 ? d[4 + b] + d[8 + b] : a == 2 ? d[8 + b] - d[4 + b] : d[4 + b] - d[12 + b];
+            } else {
+                v[k] = b == 0 ? t[a * 4] - t[a * 4 + 2] : b == 1 ? t[a * 4 + 1] + t[a * 4 + 2] : b == 2 ? t[a * 4 + 2] - t[a * 4 + 1]
+                                                                                                        : t[a * 4 + 1] - t[a * 4 + 3];
+            }
+        }
+    };
+    auto read_ops = [&](const float* stage, int sp, f32x2(&u)[16]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) read_piece(stage, sp, u, i);
+    };
+    auto transform = [&](f32x2(&v)[16]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) transform_piece(v, i);
+    };
+
+    // Three LDS stages: chunk ch is read from stage ch % 3 while chunk ch+2 is written to (ch+2) % 3 (last read during chunk
+    // ch-1, i.e. before the barrier that ended it) from registers fetched half a chunk earlier.  Inside the chunk every MFMA
+    // gets at most one memory instruction and a handful of adds behind it (the order is pinned in the source,
+    // sched_barrier after every MFMA + its piece of the other work): the four waves of the workgroup run in lock step, so memory
+    // instructions issued in a burst queue up behind each other at the LDS / the texture path and stall the in-order
+    // instruction streams (measured: bursts cost their full LDS / TA throughput time on top of the MFMA time), while one
+    // per 64-cycle MFMA disappears behind it.  The loop is uniform: the last chunks re-fetch / re-read harmlessly.
+#define WINO_MFMA1(V, U, C, p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].C, U[p].C, acc[p], 0, 0, 0)
+    float* cur = lds;
+    float* nxt = lds + WINO_STAGE_FLOATS;
+    float* nn = lds + 2 * WINO_STAGE_FLOATS;
+    {   // prologue: chunks 0 and 1 in flight together
+        f32x4 hu[8], hr[3];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) fetch_piece(0, i, gu, gr);
+#pragma unroll
+        for (int i = 0; i < 11; ++i) fetch_piece(nchunk > 1 ? 1 : 0, i, hu, hr);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) stash_piece(cur, i, gu, gr);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) stash_piece(nxt, i, hu, hr);
     }
+    __syncthreads();
+    read_ops(cur, 0, uA);
+    transform(vA);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0) here, or the loop header waits for its own new reads
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ch = 0; ch < nchunk; ++ch) {              // branch-free body: 64 MFMAs, one barrier
+        const int fch = ch + 2 < nchunk ? ch + 2 : nchunk - 1;
+        // ---- sub-step 0: MFMAs of (ch, 0); read (ch, 1), transform it; fetch chunk ch+2
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            WINO_MFMA1(vA, uA, x, i);
+            if (!WINO_X(8)) read_piece(cur, 1, uB, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            WINO_MFMA1(vA, uA, y, i);
+            if (!WINO_X(8)) transform_piece(vB, i);
+            if (!WINO_X(1)) fetch_piece(fch, i, gu, gr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- sub-step 1: MFMAs of (ch, 1); read (ch+1, 0), transform it; write chunk ch+2
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            WINO_MFMA1(vB, uB, x, i);
+            if (!WINO_X(8)) read_piece(nxt, 0, uA, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            WINO_MFMA1(vB, uB, y, i);
+            if (!WINO_X(8)) transform_piece(vA, i);
+            if (!WINO_X(2)) stash_piece(nn, i, gu, gr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!WINO_X(4)) __syncthreads();                // (waits for this wave's LDS traffic, so nothing is pending at the header)
+        float* tmp = cur;
+        cur = nxt;
+        nxt = nn;
+        nn = tmp;
+    }
+#undef WINO_MFMA1
+    if (WINO_X(16)) {                                  // (diagnostics: no epilogue, accumulators kept alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) keep += acc[p][p];
+        if (keep == 12345.678f) P.out[0] = keep;
+        return;
+    }
+    __syncthreads();                                   // every wave is done reading the stages: they become the output staging
 
     // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]], per lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
     // column (channel) = lane & 31.  Staged as [pixel of the 16x16 block][64 channels] for 16-byte stores along the channels.
@@ -289,10 +370,12 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     if (n_blocks == 0) return POD_OK;
     static std::once_flag once;
     static hipError_t attr = hipSuccess;
+#ifndef POD_WINO_EXP
     std::call_once(once, [] {
         attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    pod::WINO_LDS_BYTES);
     });
+#endif
     if (attr != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
@@ -303,7 +386,24 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
     const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+#ifdef POD_WINO_EXP
+    {
+        const char* e = getenv("POD_WINO_EXP");
+        const int x = e ? atoi(e) : 0;
+#define WINO_LAUNCH(X)                                                                                                          \
+    case X:                                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3<X>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            pod::WINO_LDS_BYTES);                                                                               \
+        hipLaunchKernelGGL(pod::k_wino_conv3x3<X>, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P); \
+        break;
+        switch (x) {
+            WINO_LAUNCH(0) WINO_LAUNCH(1) WINO_LAUNCH(3) WINO_LAUNCH(15) WINO_LAUNCH(8) WINO_LAUNCH(16) WINO_LAUNCH(31)
+            default: return POD_E_INVALID;
+        }
+    }
+#else
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+#endif
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
