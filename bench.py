@@ -170,6 +170,52 @@ def conv_census(model, img, N, quirk, dev):
     return out
 
 
+def head_conv_roofline(model, net_hw, N, quirk, dev):
+    """pod_wino_conv3x3 on its largest launch of a step (one bbox_subnet layer: every MC run of every FPN level), timed with
+    HIP events on the launch stream.  fp32 Winograd F(2x2,3x3): per 2x2 output tile and (c, k) pair the matrix cores execute
+    16 multiply-adds where the direct convolution has 36, so `achieved` (executed MFMA FLOPs of the real tiles / time) is what
+    to hold against the fp32 MFMA peak, and `direct_equivalent_tflops` is the rate in the model's own arithmetic."""
+    from pod_compare_amd import wino
+    head = model.head
+    from pod_compare_amd import anchors as A
+    levels = [tuple(int(v) for v in hw) for hw in A.level_shapes((net_hw[0] + 31) // 32 * 32, (net_hw[1] + 31) // 32 * 32)]
+    skip = 1 if (quirk and N > 1 and head.dropout_rate > 0.0) else 0
+    copies = N + ((N - skip) if head.compute_bbox_cov else 0)
+    conv = head._wino(head.bbox_subnet[1])
+    table = wino.block_table(levels, copies, dev)
+    src = torch.randn(table.pod_pixels, conv.C, device=dev)
+    dst = torch.empty(table.pod_pixels, conv.Kpad, device=dev)
+    for _ in range(2):
+        conv(src, dst, table, relu=True, dropout_p=head.dropout_rate, seed=1, offset=0)
+    torch.cuda.synchronize()
+    B, nb = 4, 6
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nb)]
+    torch.cuda._sleep(3_000_000)
+    for a, b in evs:
+        a.record()
+        for _ in range(B):
+            conv(src, dst, table, relu=True, dropout_p=head.dropout_rate, seed=1, offset=0)
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) / B for a, b in evs)
+    avg = sum(ms) / len(ms)
+    tiles = copies * sum(((h + 1) // 2) * ((w + 1) // 2) for h, w in levels)
+    mfma_flop = 2.0 * 16 * tiles * conv.C * conv.K
+    direct_flop = 2.0 * 9 * table.pod_pixels * conv.C * conv.K
+    traffic = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wino_traffic.json")), reverse=True):
+        t = json.load(open(path))
+        if t.get("levels") == [list(x) for x in levels] and t.get("copies") == copies:
+            traffic = t.get("traffic_bytes")
+            break
+    return {"kernel": "pod_wino_conv3x3 (k_wino_conv3x3): conv3x3 256->256 + bias + ReLU + dropout, %d runs x %d levels in one launch" % (copies, len(levels)),
+            "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TF, "achieved": mfma_flop / avg / 1e9,
+            "frac": mfma_flop / avg / 1e9 / FP32_MFMA_PEAK_TF, "direct_equivalent_tflops": direct_flop / avg / 1e9,
+            "algorithmic_flop": mfma_flop, "direct_flop": direct_flop, "avg_launch_us": 1e3 * avg, "min_launch_us": 1e3 * ms[0],
+            "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 64, "traffic": traffic,
+            "share_of_step": "12 launches of this kernel are ~93 % of a step's GPU time (conv_roofline.by_kind)"}
+
+
 def run_ensemble_per_gpu(args, spec, world, rank, dev):
     """cfg5 in its BASELINE topology (one seed per GPU): K timed images through apply_net.EnsemblePerGpu."""
     import torch.distributed as dist
@@ -482,7 +528,11 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                    "algorithmic_bytes": kd_bytes, "avg_launch_us": 1e3 * kd_avg_ms, "min_launch_us": 1e3 * kd_min_ms,
                                    "survey_bytes_4RC(N+1)": 4 * R * (K * (2 if spec["cls_var"] else 1) + 4 + D) * (N + 1)}
 
-    # ---- the other 99 % of a step: MIOpen's convs against the fp32 MFMA peak ---------------------------------
+    # ---- the kernel that owns the step: pod_wino_conv3x3 on the head trunk (HIP events per launch) ------------
+    if not args.no_cnn and spec.get("members", 1) == 1 and modeling.WINO_HEAD:
+        out["roofline_head_conv"] = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
+
+    # ---- the whole conv net of a step against the fp32 MFMA peak ---------------------------------------------
     if not args.no_cnn and spec.get("members", 1) == 1:
         census = conv_census(model, modeling.resize_test_image(frames[0]), N, params.merge_quirk, dev)
         gflop = sum(d["gflop"] for d in census.values())
