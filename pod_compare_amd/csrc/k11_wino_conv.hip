@@ -129,15 +129,18 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         rdst[r] = WINO_U_FLOATS + (q < 648 ? (h * WINO_R_UNITS + py * 20 + (px & 1) * 10 + (px >> 1)) : 9) * 2;
     }
     // A chunk's copy in 11 pieces (loads) / 14 pieces (stores): piece i rides behind the i-th MFMA of a phase.
-    f32x4 gu[8], gr[3];
-    auto fetch_piece = [&](int ch, int i, f32x4(&su)[8], f32x4(&sr)[3]) {
-        if (i < 8) su[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, tid * 16, ch * (WINO_U_FLOATS * 4) + i * 4096, 0));
+    f32x4 gr[3];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto fetch_piece = [&](float* stage, int ch, int i, f32x4(&sr)[3]) {
+        // filter slab: LDS-DMA, 1 KB per wavefront instruction straight into the stage (the slab is stored as its LDS image)
+        if (i < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (lds_void*)(stage + i * 1024 + wave_u * 256), 16, tid * 16,
+                                                 ch * (WINO_U_FLOATS * 4) + i * 4096, 0, 0);
         else if (i < 11) sr[i - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, roff[i - 8], ch * 32, 0));
     };
-    auto stash_piece = [&](float* stage, int i, const f32x4(&su)[8], const f32x4(&sr)[3]) {
-        if (i < 8) {
-            *reinterpret_cast<f32x4*>(stage + tid * 4 + i * 1024) = su[i];
-        } else if (i < 14) {
+    auto stash_piece = [&](float* stage, int i, const f32x4(&sr)[3]) {
+        if (i >= 8 && i < 14) {
             const int r = (i - 8) >> 1, sp = (i - 8) & 1;
             *reinterpret_cast<f32x2*>(stage + rdst[r] + sp * (2 * WINO_R_UNITS * 2)) = sp ? f32x2{sr[r].z, sr[r].w} : f32x2{sr[r].x, sr[r].y};
         }
@@ -207,15 +210,15 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     float* nxt = lds + WINO_STAGE_FLOATS;
     float* nn = lds + 2 * WINO_STAGE_FLOATS;
     {   // prologue: chunks 0 and 1 in flight together
-        f32x4 hu[8], hr[3];
+        f32x4 hr[3];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) fetch_piece(0, i, gu, gr);
+        for (int i = 0; i < 11; ++i) fetch_piece(cur, 0, i, gr);
 #pragma unroll
-        for (int i = 0; i < 11; ++i) fetch_piece(nchunk > 1 ? 1 : 0, i, hu, hr);
+        for (int i = 0; i < 11; ++i) fetch_piece(nxt, nchunk > 1 ? 1 : 0, i, hr);
 #pragma unroll
-        for (int i = 0; i < 14; ++i) stash_piece(cur, i, gu, gr);
+        for (int i = 0; i < 14; ++i) stash_piece(cur, i, gr);
 #pragma unroll
-        for (int i = 0; i < 14; ++i) stash_piece(nxt, i, hu, hr);
+        for (int i = 0; i < 14; ++i) stash_piece(nxt, i, hr);
     }
     __syncthreads();
     read_ops(cur, 0, uA);
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int i = 0; i < 16; ++i) {
             WINO_MFMA1(vA, uA, y, i);
             if (!WINO_X(8)) transform_piece(vB, i);
-            if (!WINO_X(1)) fetch_piece(fch, i, gu, gr);
+            if (!WINO_X(1)) fetch_piece(nn, fch, i, gr);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- sub-step 1: MFMAs of (ch, 1); read (ch+1, 0), transform it; write chunk ch+2
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int i = 0; i < 16; ++i) {
             WINO_MFMA1(vB, uB, y, i);
             if (!WINO_X(8)) transform_piece(vA, i);
-            if (!WINO_X(2)) stash_piece(nn, i, gu, gr);
+            if (!WINO_X(2)) stash_piece(nn, i, gr);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!WINO_X(4)) __syncthreads();                // (waits for this wave's LDS traffic, so nothing is pending at the header)
