@@ -147,3 +147,45 @@ def test_mc_dropout_head_shapes_skipped_run_and_statistics():
     many = model.head(feats, 48, mc_dropout=True)
     mean, ref = many[1][0].mean(0), ev[1][0][0]
     assert float((mean - ref).abs().mean()) < 0.35 * float(ref.abs().mean()) + 1e-6
+
+
+def test_bench_frame_launch_equals_conv2d_with_dropout_mask_applied():
+    """The launch shape of the benchmark (five FPN levels of the 768x1344 frame, C = K = 256; 3 runs here), dropout on: the kept
+    elements equal conv2d x 1/(1-p), the dropped fraction is p of the positive ones, and a second launch with the same
+    (seed, offset) is bit-identical while another offset draws another mask."""
+    levels, copies, C, K, p = [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)], 3, 256, 256, 0.1
+    w, b, xs = make(levels, copies, C, K, seed=21)
+    conv, src, table = WinoConv(w, b), flat(xs), block_table(levels, copies, "cuda")
+    out = conv(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=p, seed=77, offset=3 << 34)
+    again = conv(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=p, seed=77, offset=3 << 34)
+    other = conv(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=p, seed=77, offset=4 << 34)
+    assert torch.equal(out, again) and not torch.equal(out, other)
+    offs = level_pixel_offsets(levels, copies)
+    for i, (x, (h, wd)) in enumerate(zip(xs, levels)):
+        want = F.conv2d(x, w, b, padding=1).relu() / (1.0 - p)
+        got = out[offs[i]:offs[i + 1]].view(copies, h, wd, K).permute(0, 3, 1, 2)
+        kept = got != 0
+        assert float(((got - want) * kept).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+        pos = want > 1e-3 * float(want.abs().max())
+        dropped = float((pos & ~kept).sum()) / float(pos.sum())
+        assert abs(dropped - p) < 0.01, dropped
+
+
+def test_concurrent_streams_give_the_serial_result():
+    """Three images in flight on three HIP streams (as bench.py runs them) share the transformed filters and the block tables,
+    nothing else: each stream's output equals the one-stream output."""
+    levels, copies, C, K = [(45, 80), (23, 40)], 4, 256, 256
+    w, b, xs = make(levels, copies, C, K, seed=5)
+    conv, table = WinoConv(w, b), block_table(levels, copies, "cuda")
+    srcs = [flat([x * (1.0 + 0.25 * j) for x in xs]) for j in range(3)]
+    serial = [conv(s, torch.empty(s.shape[0], K, device="cuda"), table, relu=True, dropout_p=0.1, seed=9, offset=j << 34) for j, s in enumerate(srcs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [None] * 3
+    for rep in range(4):
+        for j, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[j] = conv(srcs[j], torch.empty(srcs[j].shape[0], K, device="cuda"), table, relu=True, dropout_p=0.1, seed=9, offset=j << 34)
+        torch.cuda.synchronize()
+        for j in range(3):
+            assert torch.equal(outs[j], serial[j])
