@@ -17,15 +17,17 @@
 // the layout K1 streams, straight from the staging tile.
 //
 // Workgroup = 256 threads = 4 waves, one per SIMD: 64 tiles (8x8 tiles = 16x16 output pixels) x 64 output channels x the
-// 16 Winograd positions.  Wave (wt, wk) owns 32 tiles x 32 channels: 16 positions x one 32x32 MFMA block = 256
-// accumulator registers, so the output transform At M A is per-lane arithmetic (every position's block has the same
-// lane <-> (tile, channel) map).  Per chunk of 8 input channels the workgroup stages the 18x18-pixel input patch (raw:
-// each wave applies Bt d B in registers, no transformed copy exists anywhere) and the 16 x 8 x 64 filter slab in LDS,
-// triple-buffered against the 64 MFMAs of the chunk.  Bank layout: see the address comments.
+// 16 Winograd positions.  Wave a owns ROW a of the 4x4 position grid for all 64 tiles and all 64 channels: 4 positions x
+// (2 tile blocks x 2 channel blocks) of 32x32 = 16 MFMA blocks = 256 accumulator registers.  A row of Bt d is one sum or
+// difference of two patch rows, so a lane transforms its two tiles with 16 packed adds per sub-step, every transformed value
+// and every filter operand feeds two MFMAs (the split "32 tiles x 32 channels x all 16 positions per wave" has no operand
+// reuse and twice the adds: 6 % slower).  Per chunk of 8 input channels the workgroup stages the raw 18x18-pixel input patch
+// (no transformed copy exists anywhere) and the 16 x 8 x 64 filter slab (LDS-DMA) in LDS, triple-buffered against the 64 MFMAs
+// of the chunk.  The output transform reduces each wave's row over its 4 positions in registers, parks the row sums in LDS and
+// combines the four rows in the store pass.  Bank layout: see the address comments.
 //
 // Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1 MB
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
-#include <cstdlib>
 #include <mutex>
 
 #include "pod_device.h"
@@ -42,7 +44,7 @@ constexpr int WINO_U_FLOATS = 16 * 2 * 2 * 64 * 2;      // filter slab of a chun
 constexpr int WINO_R_UNITS = 18 * 20;                    // 8-byte units of one (sp, h) plane of the raw patch
 constexpr int WINO_R_FLOATS = 2 * 2 * WINO_R_UNITS * 2;  // [sp][h][row 18][parity 2][col/2: 9 (+1 pad)][2]    11.25 KB
 constexpr int WINO_STAGE_FLOATS = WINO_U_FLOATS + WINO_R_FLOATS;
-constexpr int WINO_LDS_BYTES = 3 * WINO_STAGE_FLOATS * 4;   // 132 864 B of the CU's 160 KB (the 64 KB output staging reuses it)
+constexpr int WINO_LDS_BYTES = 8 * 64 * 65 * 4;   // 133 120 B of the CU's 160 KB: the output staging (three K-loop stages: 132 864 B)
 
 struct WinoParams {
     const float* in;
@@ -87,18 +89,9 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
     }
 }
 
-// -DPOD_WINO_EXP (diagnostics only): POD_WINO_EXP=<bits> in the environment drops parts of the main loop to time the rest
-// (results are then wrong): 1 no global fetch, 2 no LDS stash, 4 no barrier, 8 no operand reads / transform, 16 no epilogue.
-#ifdef POD_WINO_EXP
-#define WINO_X(bit) ((EXP & (bit)) != 0)
-template <int EXP>
-#else
-#define WINO_X(bit) false
-#endif
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wt = wave & 1, wk = wave >> 1;
     const int xcd = blockIdx.x & 7;
     const int ks = xcd % P.KS;
     const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
@@ -146,66 +139,70 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         }
     };
 
-    // ---- operand addresses of this lane
+    // ---- operand addresses of this lane.  Wavefront `a` owns ROW a of the 4x4 Winograd position grid (positions 4a .. 4a+3) for
+    // all 64 tiles (two 32-tile blocks, tb) and all 64 output channels (two 32-channel blocks, kb): 4 x 2 x 2 MFMA blocks = 256
+    // accumulators.  Row a of Bt d is one sum or difference of two patch rows:
+    //     a = 0: d0 - d2      a = 1: d1 + d2      a = 2: d2 - d1      a = 3: d1 - d3
+    // = x0 + s x1 with wave-uniform row offsets and sign, so each lane transforms its two tiles with 2 x (4 + 4) packed adds per
+    // sub-step (a quarter of Bt d B) and every transformed value feeds TWO MFMAs, every filter operand two as well.
     const int i32 = lane & 31, h = lane >> 5;
-    const int ty = 4 * wt + (i32 >> 3), tx = i32 & 7;
-    const int a_base = WINO_U_FLOATS + (h * WINO_R_UNITS + 2 * ty * 20 + tx) * 2;     // + (a*20 + (b&1)*10 + (b>>1))*2 + sp*1440
-    const int b_base = (h * 64 + 32 * wk + i32) * 2;                                   // + p*512 + sp*256
+    const int a = __builtin_amdgcn_readfirstlane(wave);
+    const int row0 = a == 0 ? 0 : a == 2 ? 2 : 1, row1 = a == 2 ? 1 : a == 3 ? 3 : 2;
+    const float sgn = a == 1 ? 1.0f : -1.0f;
+    const int a_base = WINO_U_FLOATS + (h * WINO_R_UNITS + 2 * (i32 >> 3) * 20 + (i32 & 7)) * 2;   // tile (i32>>3, i32&7) of block tb = 0
+    const int a_r0 = a_base + row0 * 40, a_r1 = a_base + row1 * 40;     // + tb*320 + ((b&1)*10 + (b>>1))*2 + sp*1440
+    const int b_base = (h * 64 + i32) * 2 + a * (4 * 512);              // + b*512 + kb*64 + sp*256
 
-    f32x16 acc[16];
+    f32x16 acc[16];                                                      // [b][tb][kb]
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    // Software pipeline.  A chunk is two sub-steps of 2 MFMA k-steps (32 MFMAs, 2048 cycles); sub-step i's block issues the
-    // LDS reads of sub-step i+1 first, transforms them (Bt d B: VALU work the matrix pipe does not see) between its own MFMAs,
-    // and only then needs them.  One barrier per chunk, in the middle: the stage of chunk ch+1 is written during sub-step 0 of
-    // chunk ch (its last readers finished before the previous barrier) from registers fetched one chunk earlier.
-    f32x2 d[16], t[16], uA[16], uB[16], vA[16], vB[16];
-    // operand reads of a sub-step in 16 pieces of two 8-byte reads (one ds_read2): patch first (the transform needs it first)
-    auto read_piece = [&](const float* stage, int sp, f32x2(&u)[16], int i) {
+    f32x2 x[16], uA[8], uB[8], vA[8], vB[8], t[4];                       // x[tb][row][b], u[b][kb], v[tb][b]
+    // operand reads of a sub-step in 12 pieces of two 8-byte reads (one ds_read2): the patch rows first (the transform needs them)
+    auto read_piece = [&](const float* stage, int sp, f32x2(&u)[8], int i) {
+        if (i < 8) {
+            const int tb = i >> 2, row = (i >> 1) & 1, b0 = (i & 1) * 2;
 #pragma unroll
-        for (int e = 2 * i; e < 2 * i + 2; ++e) {
-            if (e < 16) {
-                const int a = e >> 2, b = e & 3;
-                d[e] = *reinterpret_cast<const f32x2*>(stage + a_base + (a * 20 + (b & 1) * 10 + (b >> 1)) * 2 + sp * (2 * WINO_R_UNITS * 2));
-            } else {
-                u[e - 16] = *reinterpret_cast<const f32x2*>(stage + b_base + (e - 16) * 512 + sp * 256);
-            }
+            for (int b = b0; b < b0 + 2; ++b)
+                x[(tb * 2 + row) * 4 + b] = *reinterpret_cast<const f32x2*>(stage + (row ? a_r1 : a_r0) + tb * 320 + ((b & 1) * 10 + (b >> 1)) * 2 +
+                                                                             sp * (2 * WINO_R_UNITS * 2));
+        } else if (i < 12) {
+            const int b = i - 8;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) u[b * 2 + kb] = *reinterpret_cast<const f32x2*>(stage + b_base + b * 512 + kb * 64 + sp * 256);
         }
     };
-    // V = Bt d B, Bt = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] (two channels at once), in 16 pieces of 4 adds:
-    // pieces 0..7 t = Bt d, pieces 8..15 V = t B
-    auto transform_piece = [&](f32x2(&v)[16], int i) {
+    // row a of V = Bt d B for the lane's two tiles, two channels at once: 4 pieces (tile block x {t = x0 + s x1, V = t B})
+    auto transform_piece = [&](f32x2(&v)[8], int i) {
+        const int tb = i >> 1;
+        if ((i & 1) == 0) {
 #pragma unroll
-        for (int k = 2 * (i & 7); k < 2 * (i & 7) + 2; ++k) {
-            const int a = k >> 2, b = k & 3;
-            if (i < 8) {
-                t[k] = a == 0 ? d[b] - d[8 + b] : a == 1 ? d[4 + b] + d[8 + b] : a == 2 ? d[8 + b] - d[4 + b] : d[4 + b] - d[12 + b];
-            } else {
-                v[k] = b == 0 ? t[a * 4] - t[a * 4 + 2] : b == 1 ? t[a * 4 + 1] + t[a * 4 + 2] : b == 2 ? t[a * 4 + 2] - t[a * 4 + 1]
-                                                                                                        : t[a * 4 + 1] - t[a * 4 + 3];
+            for (int b = 0; b < 4; ++b) {
+                const f32x2 p = x[(tb * 2 + 0) * 4 + b], q = x[(tb * 2 + 1) * 4 + b];
+                t[b] = f32x2{fmaf(sgn, q.x, p.x), fmaf(sgn, q.y, p.y)};
             }
+        } else {
+            v[tb * 4 + 0] = t[0] - t[2];
+            v[tb * 4 + 1] = t[1] + t[2];
+            v[tb * 4 + 2] = t[2] - t[1];
+            v[tb * 4 + 3] = t[1] - t[3];
         }
-    };
-    auto read_ops = [&](const float* stage, int sp, f32x2(&u)[16]) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) read_piece(stage, sp, u, i);
-    };
-    auto transform = [&](f32x2(&v)[16]) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) transform_piece(v, i);
     };
 
     // Three LDS stages: chunk ch is read from stage ch % 3 while chunk ch+2 is written to (ch+2) % 3 (last read during chunk
-    // ch-1, i.e. before the barrier that ended it) from registers fetched half a chunk earlier.  Inside the chunk every MFMA
-    // gets at most one memory instruction and a handful of adds behind it (the order is pinned in the source,
-    // sched_barrier after every MFMA + its piece of the other work): the four waves of the workgroup run in lock step, so memory
-    // instructions issued in a burst queue up behind each other at the LDS / the texture path and stall the in-order
-    // instruction streams (measured: bursts cost their full LDS / TA throughput time on top of the MFMA time), while one
-    // per 64-cycle MFMA disappears behind it.  The loop is uniform: the last chunks re-fetch / re-read harmlessly.
-#define WINO_MFMA1(V, U, C, p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].C, U[p].C, acc[p], 0, 0, 0)
+    // ch-1, i.e. before the barrier that ended it).  Inside the chunk every MFMA gets at most one memory instruction and a few
+    // adds behind it (the order is pinned in the source, sched_barrier after every MFMA + its piece of the other work): the
+    // four waves of the workgroup run in lock step, so memory instructions issued in a burst queue up behind each other at the
+    // LDS / the texture path and stall the in-order instruction streams (measured: bursts cost their full LDS / TA throughput
+    // time on top of the MFMA time), while one per 64-cycle MFMA mostly disappears behind it.  The loop is uniform: the last
+    // chunks re-fetch / re-read harmlessly.
+    // MFMA j of a sub-step: k-step j >> 4, accumulator m = j & 15 = (b, tb, kb)
+#define WINO_MFMA(V, U, j)                                                                                                        \
+    acc[(j) & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                                                         \
+        (j) < 16 ? V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)].x : V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)].y,                 \
+        (j) < 16 ? U[((((j) & 15) >> 2)) * 2 + ((j) & 1)].x : U[((((j) & 15) >> 2)) * 2 + ((j) & 1)].y, acc[(j) & 15], 0, 0, 0)
     float* cur = lds;
     float* nxt = lds + WINO_STAGE_FLOATS;
     float* nn = lds + 2 * WINO_STAGE_FLOATS;
@@ -221,92 +218,79 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int i = 0; i < 14; ++i) stash_piece(nxt, i, hr);
     }
     __syncthreads();
-    read_ops(cur, 0, uA);
-    transform(vA);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) read_piece(cur, 0, uA, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) transform_piece(vA, i);
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0) here, or the loop header waits for its own new reads
     __builtin_amdgcn_sched_barrier(0);
     for (int ch = 0; ch < nchunk; ++ch) {              // branch-free body: 64 MFMAs, one barrier
         const int fch = ch + 2 < nchunk ? ch + 2 : nchunk - 1;
         // ---- sub-step 0: MFMAs of (ch, 0); read (ch, 1), transform it; fetch chunk ch+2
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            WINO_MFMA1(vA, uA, x, i);
-            if (!WINO_X(8)) read_piece(cur, 1, uB, i);
+        for (int j = 0; j < 32; ++j) {
+            WINO_MFMA(vA, uA, j);
+            if (j < 12) read_piece(cur, 1, uB, j);
+            if (j >= 12 && j < 23) fetch_piece(nn, fch, j - 12, gr);
+            if (j >= 24 && j < 28) transform_piece(vB, j - 24);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- sub-step 1: MFMAs of (ch, 1); read (ch+1, 0), transform it; write the patch of chunk ch+2
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            WINO_MFMA1(vA, uA, y, i);
-            if (!WINO_X(8)) transform_piece(vB, i);
-            if (!WINO_X(1)) fetch_piece(nn, fch, i, gr);
+        for (int j = 0; j < 32; ++j) {
+            WINO_MFMA(vB, uB, j);
+            if (j < 12) read_piece(nxt, 0, uA, j);
+            if (j >= 14 && j < 20) stash_piece(nn, j - 14 + 8, gr);
+            if (j >= 24 && j < 28) transform_piece(vA, j - 24);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- sub-step 1: MFMAs of (ch, 1); read (ch+1, 0), transform it; write chunk ch+2
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            WINO_MFMA1(vB, uB, x, i);
-            if (!WINO_X(8)) read_piece(nxt, 0, uA, i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            WINO_MFMA1(vB, uB, y, i);
-            if (!WINO_X(8)) transform_piece(vA, i);
-            if (!WINO_X(2)) stash_piece(nn, i, gr);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!WINO_X(4)) __syncthreads();                // (waits for this wave's LDS traffic, so nothing is pending at the header)
+        __syncthreads();                                // (waits for this wave's LDS traffic, so nothing is pending at the header)
         float* tmp = cur;
         cur = nxt;
         nxt = nn;
         nn = tmp;
     }
-#undef WINO_MFMA1
-    if (WINO_X(16)) {                                  // (diagnostics: no epilogue, accumulators kept alive)
-        float keep = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) keep += acc[p][p];
-        if (keep == 12345.678f) P.out[0] = keep;
-        return;
-    }
+#undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages: they become the output staging
 
-    // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]], per lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
-    // column (channel) = lane & 31.  Staged as [pixel of the 16x16 block][64 channels] for 16-byte stores along the channels.
-    const int LD = P.k_planes > 0 ? 65 : 64;   // staging row: 16-byte reads along k (64) or scalar reads along the pixels (65)
-    {
-        const int kl = 32 * wk + i32;
+    // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]].  Lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
+    // column (channel) = lane & 31.  Every wave reduces its row over b (R0 = m0 + m1 + m2, R1 = m1 - m2 - m3) and parks
+    // R[a][x][tile][channel] in LDS (128 KB); the store pass combines the four rows in a fixed order:
+    //     Y[0][x] = (R[0][x] + R[1][x]) + R[2][x]          Y[1][x] = (R[1][x] - R[2][x]) - R[3][x]
+    const int LD = P.k_planes > 0 ? 65 : 64;   // tile row of the staging: 16-byte reads along k (64) or scalar reads, bank-spread (65)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int tyo = 4 * wt + (reg >> 2), txo = (reg & 3) + 4 * h;
-            float r0[4], r1[4];
+    for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const float m0 = acc[a * 4 + 0][reg], m1 = acc[a * 4 + 1][reg], m2 = acc[a * 4 + 2][reg], m3 = acc[a * 4 + 3][reg];
-                r0[a] = m0 + m1 + m2;
-                r1[a] = m1 - m2 - m3;
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float m0 = acc[0 * 4 + tb * 2 + kb][reg], m1 = acc[1 * 4 + tb * 2 + kb][reg], m2 = acc[2 * 4 + tb * 2 + kb][reg],
+                            m3 = acc[3 * 4 + tb * 2 + kb][reg];
+                const int tile = (4 * tb + (reg >> 2)) * 8 + (reg & 3) + 4 * h;
+                float* o = lds + ((a * 2) * 64 + tile) * LD + kb * 32 + i32;
+                o[0] = m0 + m1 + m2;
+                o[64 * LD] = m1 - m2 - m3;
             }
-            float* o = lds + ((2 * tyo) * 16 + 2 * txo) * LD + kl;
-            o[0] = r0[0] + r0[1] + r0[2];
-            o[LD] = r1[0] + r1[1] + r1[2];
-            o[16 * LD] = r0[1] - r0[2] - r0[3];
-            o[17 * LD] = r1[1] - r1[2] - r1[3];
-        }
-    }
     __syncthreads();
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x); 64-byte runs per (channel, row)
         const int64_t HW = (int64_t)H * W;
         float* plane0 = P.out + out_px * P.k_planes;
         const bool vec = (W & 3) == 0 && ((out_px * P.k_planes) & 3) == 0;
-#pragma unroll 4
+#pragma unroll 2
         for (int it = 0; it < 16; ++it) {
             const int idx = it * 256 + tid, k = idx >> 6, oy = (idx >> 2) & 15, ox = (idx & 3) * 4;
             const int kg = ks * 64 + k, gy = y0 + oy, gx = x0 + ox;
             if (kg >= P.k_planes || gy >= H || gx >= W) continue;
             const float bias = P.bias ? P.bias[kg] : 0.0f;
-            const float* sp = lds + (oy * 16 + ox) * 65 + k;
-            f32x4 v = f32x4{sp[0], sp[65], sp[130], sp[195]} + bias;
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tile = (oy >> 1) * 8 + ((ox + e) >> 1), xx = e & 1;
+                const float* r = lds + (xx * 64 + tile) * 65 + k;              // R[a][xx][tile][k] at + a * 2 * 64 * 65
+                y[e] = (oy & 1) == 0 ? (r[0] + r[2 * 64 * 65]) + r[4 * 64 * 65] : (r[2 * 64 * 65] - r[4 * 64 * 65]) - r[6 * 64 * 65];
+            }
+            f32x4 v = f32x4{y[0], y[1], y[2], y[3]} + bias;
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
@@ -329,19 +313,23 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             const int pix = it * 16 + (tid >> 4), oy = pix >> 4, ox = pix & 15;
             const int gy = y0 + oy, gx = x0 + ox;
             if (gy >= H || gx >= W) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(lds + pix * 64 + k4) + bias;
+            const float* r = lds + ((ox & 1) * 64 + (oy >> 1) * 8 + (ox >> 1)) * 64 + k4;      // R[a][ox & 1][tile][k4] at + a * 8192
+            const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 8192 : 0));
+            const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 16384 : 8192));
+            const f32x4 rc = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 24576 : 16384));
+            f32x4 v = ((oy & 1) ? (ra - rb) - rc : (ra + rb) + rc) + bias;
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             const int64_t e = (out_px + (int64_t)gy * W + gx) * P.out_stride + kg;
             if (P.thresh) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
-                const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
-                                              (uint32_t)(P.seed >> 32));
-                v.x = r.x >= P.thresh ? v.x * P.scale : 0.f;
-                v.y = r.y >= P.thresh ? v.y * P.scale : 0.f;
-                v.z = r.z >= P.thresh ? v.z * P.scale : 0.f;
-                v.w = r.w >= P.thresh ? v.w * P.scale : 0.f;
+                const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
+                                               (uint32_t)(P.seed >> 32));
+                v.x = r4.x >= P.thresh ? v.x * P.scale : 0.f;
+                v.y = r4.y >= P.thresh ? v.y * P.scale : 0.f;
+                v.z = r4.z >= P.thresh ? v.z * P.scale : 0.f;
+                v.w = r4.w >= P.thresh ? v.w * P.scale : 0.f;
             }
             *reinterpret_cast<f32x4*>(P.out + e) = v;
         }
@@ -373,12 +361,10 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     if (n_blocks == 0) return POD_OK;
     static std::once_flag once;
     static hipError_t attr = hipSuccess;
-#ifndef POD_WINO_EXP
     std::call_once(once, [] {
         attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    pod::WINO_LDS_BYTES);
     });
-#endif
     if (attr != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
@@ -389,24 +375,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
     const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-#ifdef POD_WINO_EXP
-    {
-        const char* e = getenv("POD_WINO_EXP");
-        const int x = e ? atoi(e) : 0;
-#define WINO_LAUNCH(X)                                                                                                          \
-    case X:                                                                                                                     \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3<X>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            pod::WINO_LDS_BYTES);                                                                               \
-        hipLaunchKernelGGL(pod::k_wino_conv3x3<X>, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P); \
-        break;
-        switch (x) {
-            WINO_LAUNCH(0) WINO_LAUNCH(1) WINO_LAUNCH(3) WINO_LAUNCH(15) WINO_LAUNCH(8) WINO_LAUNCH(16) WINO_LAUNCH(31)
-            default: return POD_E_INVALID;
-        }
-    }
-#else
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
-#endif
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
