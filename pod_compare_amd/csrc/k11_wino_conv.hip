@@ -40,11 +40,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k8_model_ops.hip: same mask as pod_bias_act
 
-constexpr int WINO_U_FLOATS = 16 * 2 * 2 * 64 * 2;      // filter slab of a chunk: [p][sp][h][j][2]            32 KB
-constexpr int WINO_R_UNITS = 18 * 20;                    // 8-byte units of one (sp, h) plane of the raw patch
-constexpr int WINO_R_FLOATS = 2 * 2 * WINO_R_UNITS * 2;  // [sp][h][row 18][parity 2][col/2: 9 (+1 pad)][2]    11.25 KB
-constexpr int WINO_STAGE_FLOATS = WINO_U_FLOATS + WINO_R_FLOATS;
-constexpr int WINO_LDS_BYTES = 8 * 64 * 65 * 4;   // 133 120 B of the CU's 160 KB: the output staging (three K-loop stages: 132 864 B)
+constexpr int WINO_U_FLOATS = 16 * 2 * 64 * 4;          // filter slab of a chunk: [p][h][j][4 channels]            32 KB
+constexpr int WINO_R_SLOTS = 18 * 20;                    // 16-byte slots of one channel-half plane of the raw patch
+constexpr int WINO_STAGE_FLOATS = 12 * 64 * 4;           // raw patch stage: [h][row 18][parity 2][col/2: 9 (+1 pad)][4]: 720 slots, 12 KB
+constexpr int WINO_LDS_BYTES = 8 * 64 * 65 * 4;          // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
 
 struct WinoParams {
     const float* in;
@@ -58,8 +57,8 @@ struct WinoParams {
     uint64_t seed, offset;
 };
 
-// Filter transform U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written as the LDS image of the main kernel:
-// U[ks][chunk][p][sp][h][j][s2] = U_p[c = 8 chunk + 4 h + 2 sp + s2][k = 64 ks + j]; channels >= K are zero.
+// Filter transform U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written in the order the main kernel's lanes load it:
+// U[ks][chunk][p][h][j][s] = U_p[c = 8 chunk + 4 h + s][k = 64 ks + j] (16 bytes per lane and position); channels >= K are zero.
 __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w, float* __restrict__ U, int32_t K, int32_t C, int32_t Kpad) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)Kpad * C) return;
@@ -76,8 +75,8 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
         t0[3][j] = g[2][j];
     }
     const int nchunk = C / 8, ks = k >> 6, j64 = k & 63, ch = c >> 3, cc = c & 7;
-    const int h = cc >> 2, sp = (cc >> 1) & 1, s2 = cc & 1;
-    float* dst = U + ((int64_t)ks * nchunk + ch) * WINO_U_FLOATS + ((sp * 2 + h) * 64 + j64) * 2 + s2;
+    const int h = cc >> 2, sc = cc & 3;
+    float* dst = U + ((int64_t)ks * nchunk + ch) * WINO_U_FLOATS + (h * 64 + j64) * 4 + sc;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float u0 = t0[a][0], u1 = 0.5f * (t0[a][0] + t0[a][1] + t0[a][2]), u2 = 0.5f * (t0[a][0] - t0[a][1] + t0[a][2]),
@@ -101,57 +100,43 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int H = desc.z >> 16, W = desc.z & 0xFFFF, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
     const int nchunk = P.C >> 3;
 
-    // ---- global -> LDS plan of a chunk: 8 float4 of the filter slab (a straight copy) + up to 3 float4 of the raw patch, as
-    // buffer loads: scalar base + 32-bit lane offset + scalar chunk offset (no 64-bit address arithmetic in the loop), and
-    // an out-of-range offset reads as 0.0 -- that IS the zero padding of the convolution (and the "no item" case).
-    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
-                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
-    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0, H * W * P.in_stride * 4,
-                                                          0x00020000);
-    int roff[3], rdst[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int q = tid + 256 * r;              // (pixel of the 18x18 patch, channel half h)
-        const int pix = q >> 1, h = q & 1, py = pix / 18, px = pix - py * 18;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool ok = q < 648 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        roff[r] = ok ? ((gy * W + gx) * P.in_stride + 4 * h) * 4 : 0x7FFFFF00;
-        // 8-byte unit of the pixel inside an (sp, h) plane: rows of 20 units, even columns first -- the 32 lanes of an MFMA
-        // operand read (tile row stride 40 = 8 mod 32, tile column stride 1) hit 32 different units.  Unit 9 of a row is
-        // padding nobody reads: threads without an item store there (no branch in the loop).
-        rdst[r] = WINO_U_FLOATS + (q < 648 ? (h * WINO_R_UNITS + py * 20 + (px & 1) * 10 + (px >> 1)) : 9) * 2;
-    }
-    // A chunk's copy in 11 pieces (loads) / 14 pieces (stores): piece i rides behind the i-th MFMA of a phase.
-    f32x4 gr[3];
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto fetch_piece = [&](float* stage, int ch, int i, f32x4(&sr)[3]) {
-        // filter slab: LDS-DMA, 1 KB per wavefront instruction straight into the stage (the slab is stored as its LDS image)
-        if (i < 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, (lds_void*)(stage + i * 1024 + wave_u * 256), 16, tid * 16,
-                                                 ch * (WINO_U_FLOATS * 4) + i * 4096, 0, 0);
-        else if (i < 11) sr[i - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, roff[i - 8], ch * 32, 0));
-    };
-    auto stash_piece = [&](float* stage, int i, const f32x4(&sr)[3]) {
-        if (i >= 8 && i < 14) {
-            const int r = (i - 8) >> 1, sp = (i - 8) & 1;
-            *reinterpret_cast<f32x2*>(stage + rdst[r] + sp * (2 * WINO_R_UNITS * 2)) = sp ? f32x2{sr[r].z, sr[r].w} : f32x2{sr[r].x, sr[r].y};
-        }
-    };
-
-    // ---- operand addresses of this lane.  Wavefront `a` owns ROW a of the 4x4 Winograd position grid (positions 4a .. 4a+3) for
-    // all 64 tiles (two 32-tile blocks, tb) and all 64 output channels (two 32-channel blocks, kb): 4 x 2 x 2 MFMA blocks = 256
-    // accumulators.  Row a of Bt d is one sum or difference of two patch rows:
+    // ---- operands.  Wavefront `a` owns ROW a of the 4x4 Winograd position grid (positions 4a .. 4a+3) for all 64 tiles (two
+    // 32-tile blocks, tb) and all 64 output channels (two 32-channel blocks, kb): 4 x 2 x 2 MFMA blocks = 256 accumulators.
+    // Row a of Bt d is one sum or difference of two patch rows:
     //     a = 0: d0 - d2      a = 1: d1 + d2      a = 2: d2 - d1      a = 3: d1 - d3
-    // = x0 + s x1 with wave-uniform row offsets and sign, so each lane transforms its two tiles with 2 x (4 + 4) packed adds per
-    // sub-step (a quarter of Bt d B) and every transformed value feeds TWO MFMAs, every filter operand two as well.
+    // = x0 + s x1 with wave-uniform row offsets and sign, so a lane transforms its two tiles with 2 x (4 + 4) four-channel adds
+    // per chunk (a quarter of Bt d B), and every transformed value and every filter operand feeds TWO MFMAs.
+    //   * filter operands never touch LDS: a lane needs U_p[its 4 channels][its output channel] for its row's 4 positions and
+    //     both channel blocks = 8 x 16 bytes per chunk, loaded straight from L2 (the filter slice of this XCD) one chunk ahead;
+    //     the four waves together read each slab byte exactly once;
+    //   * the raw 18x18-pixel patch goes global -> LDS by LDS-DMA (buffer_load ... lds), 16-byte slots [h][row][col parity][col/2]:
+    //     the 16 lanes of a ds_read_b128 group (tile-row stride 40 = 8 mod 16 slots, tile-column stride 1) hit 16 different
+    //     slots; out-of-range buffer offsets return 0.0 -- that IS the zero padding of the convolution; pad slots load nothing.
     const int i32 = lane & 31, h = lane >> 5;
     const int a = __builtin_amdgcn_readfirstlane(wave);
     const int row0 = a == 0 ? 0 : a == 2 ? 2 : 1, row1 = a == 2 ? 1 : a == 3 ? 3 : 2;
     const float sgn = a == 1 ? 1.0f : -1.0f;
-    const int a_base = WINO_U_FLOATS + (h * WINO_R_UNITS + 2 * (i32 >> 3) * 20 + (i32 & 7)) * 2;   // tile (i32>>3, i32&7) of block tb = 0
-    const int a_r0 = a_base + row0 * 40, a_r1 = a_base + row1 * 40;     // + tb*320 + ((b&1)*10 + (b>>1))*2 + sp*1440
-    const int b_base = (h * 64 + i32) * 2 + a * (4 * 512);              // + b*512 + kb*64 + sp*256
+    const int a_base = (h * WINO_R_SLOTS + 2 * (i32 >> 3) * 20 + (i32 & 7)) * 4;      // tile (i32>>3, i32&7) of block tb = 0
+    const int a_r0 = a_base + row0 * 80, a_r1 = a_base + row1 * 80;                     // + tb*640 + ((b&1)*10 + (b>>1))*4
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
+                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0, H * W * P.in_stride * 4,
+                                                          0x00020000);
+    const int u_off = ((a * 4 * 2 + h) * 64 + i32) * 16;                               // + (b*2*64 + kb*32)*16 bytes, + chunk*32 KB
+    int roff[3];                                                                       // this lane's three patch slots
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int slot = (a * 3 + r) * 64 + lane;
+        const int hh = slot >= WINO_R_SLOTS ? 1 : 0, rem = slot - hh * WINO_R_SLOTS, py = rem / 20, q = rem - py * 20;
+        const int px = 2 * (q >= 10 ? q - 10 : q) + (q >= 10 ? 1 : 0);
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = slot < 2 * WINO_R_SLOTS && q != 9 && q != 19 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        roff[r] = ok ? ((gy * W + gx) * P.in_stride + 4 * hh) * 4 : 0x7FFFFF00;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto patch_piece = [&](float* stage, int ch, int r) {    // 1 KB of the patch of chunk ch, straight into LDS
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 3 + r) * 256), 16, roff[r], ch * 32, 0, 0);
+    };
 
     f32x16 acc[16];                                                      // [b][tb][kb]
 #pragma unroll
@@ -159,97 +144,74 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    f32x2 x[16], uA[8], uB[8], vA[8], vB[8], t[4];                       // x[tb][row][b], u[b][kb], v[tb][b]
-    // operand reads of a sub-step in 12 pieces of two 8-byte reads (one ds_read2): the patch rows first (the transform needs them)
-    auto read_piece = [&](const float* stage, int sp, f32x2(&u)[8], int i) {
-        if (i < 8) {
-            const int tb = i >> 2, row = (i >> 1) & 1, b0 = (i & 1) * 2;
-#pragma unroll
-            for (int b = b0; b < b0 + 2; ++b)
-                x[(tb * 2 + row) * 4 + b] = *reinterpret_cast<const f32x2*>(stage + (row ? a_r1 : a_r0) + tb * 320 + ((b & 1) * 10 + (b >> 1)) * 2 +
-                                                                             sp * (2 * WINO_R_UNITS * 2));
-        } else if (i < 12) {
-            const int b = i - 8;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) u[b * 2 + kb] = *reinterpret_cast<const f32x2*>(stage + b_base + b * 512 + kb * 64 + sp * 256);
-        }
+    f32x4 x[16], uA[8], uB[8], vA[8], vB[8], t[4];                       // x[tb][row][b], u[b][kb], v[tb][b]: 4 channels each
+    auto read_piece = [&](const float* stage, int i) {                   // 16 pieces: one ds_read_b128 each
+        const int tb = i >> 3, row = (i >> 2) & 1, b = i & 3;
+        x[i] = *reinterpret_cast<const f32x4*>(stage + (row ? a_r1 : a_r0) + tb * 640 + ((b & 1) * 10 + (b >> 1)) * 4);
     };
-    // row a of V = Bt d B for the lane's two tiles, two channels at once: 4 pieces (tile block x {t = x0 + s x1, V = t B})
-    auto transform_piece = [&](f32x2(&v)[8], int i) {
-        const int tb = i >> 1;
-        if ((i & 1) == 0) {
+    auto filter_piece = [&](int ch, f32x4(&u)[8], int i) {               // 8 pieces: one buffer_load_dwordx4 each
+        u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
+    };
+    // row a of V = Bt d B for the lane's two tiles: 8 pieces (tile block x {t0 t1, t2 t3, V0 V1, V2 V3})
+    auto transform_piece = [&](f32x4(&v)[8], int i) {
+        const int tb = i >> 2, part = i & 3;
+        if (part < 2) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x2 p = x[(tb * 2 + 0) * 4 + b], q = x[(tb * 2 + 1) * 4 + b];
-                t[b] = f32x2{fmaf(sgn, q.x, p.x), fmaf(sgn, q.y, p.y)};
+            for (int b = 2 * part; b < 2 * part + 2; ++b) {
+                const f32x4 p = x[(tb * 2 + 0) * 4 + b], q = x[(tb * 2 + 1) * 4 + b];
+                t[b] = f32x4{fmaf(sgn, q.x, p.x), fmaf(sgn, q.y, p.y), fmaf(sgn, q.z, p.z), fmaf(sgn, q.w, p.w)};
             }
-        } else {
+        } else if (part == 2) {
             v[tb * 4 + 0] = t[0] - t[2];
             v[tb * 4 + 1] = t[1] + t[2];
+        } else {
             v[tb * 4 + 2] = t[2] - t[1];
             v[tb * 4 + 3] = t[1] - t[3];
         }
     };
 
-    // Three LDS stages: chunk ch is read from stage ch % 3 while chunk ch+2 is written to (ch+2) % 3 (last read during chunk
-    // ch-1, i.e. before the barrier that ended it).  Inside the chunk every MFMA gets at most one memory instruction and a few
-    // adds behind it (the order is pinned in the source, sched_barrier after every MFMA + its piece of the other work): the
-    // four waves of the workgroup run in lock step, so memory instructions issued in a burst queue up behind each other at the
-    // LDS / the texture path and stall the in-order instruction streams (measured: bursts cost their full LDS / TA throughput
-    // time on top of the MFMA time), while one per 64-cycle MFMA mostly disappears behind it.  The loop is uniform: the last
-    // chunks re-fetch / re-read harmlessly.
-    // MFMA j of a sub-step: k-step j >> 4, accumulator m = j & 15 = (b, tb, kb)
-#define WINO_MFMA(V, U, j)                                                                                                        \
-    acc[(j) & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                                                         \
-        (j) < 16 ? V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)].x : V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)].y,                 \
-        (j) < 16 ? U[((((j) & 15) >> 2)) * 2 + ((j) & 1)].x : U[((((j) & 15) >> 2)) * 2 + ((j) & 1)].y, acc[(j) & 15], 0, 0, 0)
-    float* cur = lds;
-    float* nxt = lds + WINO_STAGE_FLOATS;
-    float* nn = lds + 2 * WINO_STAGE_FLOATS;
-    {   // prologue: chunks 0 and 1 in flight together
-        f32x4 hr[3];
+    // One chunk = 64 MFMAs (k-step j >> 4 = channel j >> 4 of the lane's four, accumulator j & 15 = (b, tb, kb)) with the next
+    // chunk's work slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four
+    // waves of the workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the
+    // in-order instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and the
+    // LDS-DMA of the patch of chunk ch+2 into the stage chunk ch was read from.  Two stages; one barrier per chunk.
+#define WINO_MFMA(V, U, j)                                                                                                          \
+    acc[(j) & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)][(j) >> 4],                      \
+                                                         U[(((j) & 15) >> 2) * 2 + ((j) & 1)][(j) >> 4], acc[(j) & 15], 0, 0, 0)
+    float* st0 = lds;
+    float* st1 = lds + WINO_STAGE_FLOATS;
+    const int last = nchunk - 1;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) fetch_piece(cur, 0, i, gr);
+    for (int r = 0; r < 3; ++r) patch_piece(st0, 0, r);
 #pragma unroll
-        for (int i = 0; i < 11; ++i) fetch_piece(nxt, nchunk > 1 ? 1 : 0, i, hr);
+    for (int r = 0; r < 3; ++r) patch_piece(st1, last < 1 ? last : 1, r);
 #pragma unroll
-        for (int i = 0; i < 14; ++i) stash_piece(cur, i, gr);
-#pragma unroll
-        for (int i = 0; i < 14; ++i) stash_piece(nxt, i, hr);
-    }
+    for (int i = 0; i < 8; ++i) filter_piece(0, uA, i);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 12; ++i) read_piece(cur, 0, uA, i);
+    for (int i = 0; i < 16; ++i) read_piece(st0, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) transform_piece(vA, i);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0) here, or the loop header waits for its own new reads
-    __builtin_amdgcn_sched_barrier(0);
-    for (int ch = 0; ch < nchunk; ++ch) {              // branch-free body: 64 MFMAs, one barrier
-        const int fch = ch + 2 < nchunk ? ch + 2 : nchunk - 1;
-        // ---- sub-step 0: MFMAs of (ch, 0); read (ch, 1), transform it; fetch chunk ch+2
+    for (int i = 0; i < 8; ++i) transform_piece(vA, i);
+    __syncthreads();                                   // every wave has read chunk 0's patch: its stage may be overwritten
+    auto chunk = [&](int ch, f32x4(&vC)[8], f32x4(&uC)[8], f32x4(&vN)[8], f32x4(&uN)[8], const float* rd, float* wr) {
+        const int c1 = ch + 1 < nchunk ? ch + 1 : last, c2 = ch + 2 < nchunk ? ch + 2 : last;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            WINO_MFMA(vA, uA, j);
-            if (j < 12) read_piece(cur, 1, uB, j);
-            if (j >= 12 && j < 23) fetch_piece(nn, fch, j - 12, gr);
-            if (j >= 24 && j < 28) transform_piece(vB, j - 24);
+        for (int j = 0; j < 64; ++j) {
+            WINO_MFMA(vC, uC, j);
+            if (j < 16) read_piece(rd, j);
+            else if (j < 24) filter_piece(c1, uN, j - 16);
+            else if (j < 27) patch_piece(wr, c2, j - 24);
+            else if (j >= 32 && j < 40) transform_piece(vN, j - 32);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- sub-step 1: MFMAs of (ch, 1); read (ch+1, 0), transform it; write the patch of chunk ch+2
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            WINO_MFMA(vB, uB, j);
-            if (j < 12) read_piece(nxt, 0, uA, j);
-            if (j >= 14 && j < 20) stash_piece(nn, j - 14 + 8, gr);
-            if (j >= 24 && j < 28) transform_piece(vA, j - 24);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                // (waits for this wave's LDS traffic, so nothing is pending at the header)
-        float* tmp = cur;
-        cur = nxt;
-        nxt = nn;
-        nn = tmp;
+        __syncthreads();                               // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
+    };
+    int ch = 0;
+    for (; ch + 1 < nchunk; ch += 2) {
+        chunk(ch, vA, uA, vB, uB, st1, st0);
+        chunk(ch + 1, vB, uB, vA, uA, st0, st1);
     }
+    if (ch < nchunk) chunk(ch, vA, uA, vB, uB, st1, st0);
 #undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages: they become the output staging
 
