@@ -12,19 +12,21 @@
 //
 // Data layout (channels-last): activations are [pixel][C] fp32; every (level, run) image of a launch lives in the same
 // buffer, a table of 16x16-pixel output blocks (int4 {first pixel of the image in `in`, in `out`, H << 16 | W, by << 16 | bx})
-// says where.  Filters are transformed once (pod_wino_filter_transform) into the image the kernel's LDS stages want.
+// says where.  Filters are transformed once (pod_wino_filter_transform) into the order the kernel's lanes load them in.
 // The predictor convolutions (cls_score, bbox_pred, cls_var, bbox_cov: K = 63 / 36 / 90 real channels) write NCHW planes,
 // the layout K1 streams, straight from the staging tile.
 //
 // Workgroup = 256 threads = 4 waves, one per SIMD: 64 tiles (8x8 tiles = 16x16 output pixels) x 64 output channels x the
 // 16 Winograd positions.  Wave a owns ROW a of the 4x4 position grid for all 64 tiles and all 64 channels: 4 positions x
 // (2 tile blocks x 2 channel blocks) of 32x32 = 16 MFMA blocks = 256 accumulator registers.  A row of Bt d is one sum or
-// difference of two patch rows, so a lane transforms its two tiles with 16 packed adds per sub-step, every transformed value
-// and every filter operand feeds two MFMAs (the split "32 tiles x 32 channels x all 16 positions per wave" has no operand
-// reuse and twice the adds: 6 % slower).  Per chunk of 8 input channels the workgroup stages the raw 18x18-pixel input patch
-// (no transformed copy exists anywhere) and the 16 x 8 x 64 filter slab (LDS-DMA) in LDS, triple-buffered against the 64 MFMAs
-// of the chunk.  The output transform reduces each wave's row over its 4 positions in registers, parks the row sums in LDS and
-// combines the four rows in the store pass.  Bank layout: see the address comments.
+// difference of two patch rows, so a lane transforms its two tiles with 16 four-channel adds per chunk, and every transformed
+// value and every filter operand feeds two MFMAs.  Per chunk of 8 input channels (64 MFMAs per wave) the raw 18x18-pixel
+// input patch is staged in LDS by LDS-DMA (no transformed copy exists anywhere; two 12 KB stages) and the filter operands go
+// from L2 straight into registers (each wave needs only its row's positions: the four waves read each slab byte once).
+// With one wave per SIMD every non-MFMA instruction costs issue time on top of the MFMA time (fp32 MFMA and the other pipes
+// do not overlap within a wave: measured), so the design minimises them: 27 memory instructions and ~70 VALU per 64 MFMAs.
+// The output transform reduces each wave's row over its 4 positions in registers, parks the row sums in LDS (128 KB) and
+// combines the four rows in the store pass.
 //
 // Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1 MB
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
