@@ -303,8 +303,11 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
  * fp32 matrix cores, bias + ReLU + dropout fused into the store.
  *
  * Activations are channels-last: in[pixel][C], out[pixel][K]; all images of the launch live in the two buffers.  `blocks`
- * (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of the image in `in`, first pixel of the image in
- * `out`, H << 16 | W, block_row << 16 | block_col}, one per 16x16-pixel output block (ceil(H/16) * ceil(W/16) per image).
+ * (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of image 0 in `in`, first pixel of image 0 in `out`,
+ * H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS of n_images (1..127)
+ * consecutive H x W images standing side by side: image n occupies canvas columns n*Wv .. n*Wv + W - 1, Wv = (W rounded up to
+ * even) + 2, the spare columns are zero padding; block (r, c) covers canvas rows 16r.. and columns 16c.. (n_images = 1: the plain
+ * ceil(H/16) x ceil(W/16) tiling of one image).
  * C % 8 == 0, K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 16 * round_up(K, 64) * C floats; weight is
  * (K, C, 3, 3), output channels past K are zero (so a K = 63 predictor runs as K = 64; bias then has round_up(K, 64) entries).
  * k_planes == 0: out is channels-last.  k_planes > 0 (the predictor convs cls_score / bbox_pred / cls_var / bbox_cov,

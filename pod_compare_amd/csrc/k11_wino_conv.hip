@@ -97,9 +97,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int ks = xcd % P.KS;
     const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
     if (tb >= P.n_blocks) return;
+    // block record: the images of a (level, launch) stand SIDE BY SIDE on a virtual canvas, image n at columns n*Wv .. n*Wv+W-1
+    // with Wv = W rounded up to even + 2: the two spare columns are the zero padding between neighbours (reads outside an
+    // image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- a partial block at the
+    // right edge is paid once per level instead of once per image.
     const int4 desc = P.blocks[tb];
-    const int64_t base_px = desc.x, out_px = desc.y;
-    const int H = desc.z >> 16, W = desc.z & 0xFFFF, y0 = (desc.w >> 16) * 16, x0 = (desc.w & 0xFFFF) * 16;
+    const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
+    const int H = desc.z >> 16, W = desc.z & 0xFFFF, n_img = (desc.w >> 24) & 0xFF;
+    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = ((W + 1) & ~1) + 2, HWi = H * W;
     const int nchunk = P.C >> 3;
 
     // ---- operands.  Wavefront `a` owns ROW a of the 4x4 Winograd position grid (positions 4a .. 4a+3) for all 64 tiles (two
@@ -122,8 +127,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int a_r0 = a_base + row0 * 80, a_r1 = a_base + row1 * 80;                     // + tb*640 + ((b&1)*10 + (b>>1))*4
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
                                                           nchunk * WINO_U_FLOATS * 4, 0x00020000);
-    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0, H * W * P.in_stride * 4,
-                                                          0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
+                                                          n_img * HWi * P.in_stride * 4, 0x00020000);
     const int u_off = ((a * 4 * 2 + h) * 64 + i32) * 16;                               // + (b*2*64 + kb*32)*16 bytes, + chunk*32 KB
     int roff[3];                                                                       // this lane's three patch slots
 #pragma unroll
@@ -131,9 +136,9 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         const int slot = (a * 3 + r) * 64 + lane;
         const int hh = slot >= WINO_R_SLOTS ? 1 : 0, rem = slot - hh * WINO_R_SLOTS, py = rem / 20, q = rem - py * 20;
         const int px = 2 * (q >= 10 ? q - 10 : q) + (q >= 10 ? 1 : 0);
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool ok = slot < 2 * WINO_R_SLOTS && q != 9 && q != 19 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        roff[r] = ok ? ((gy * W + gx) * P.in_stride + 4 * hh) * 4 : 0x7FFFFF00;
+        const int gy = y0 - 1 + py, vx = x0 - 1 + px, n = vx >= 0 ? vx / Wv : 0, gx = vx - n * Wv;
+        const bool ok = slot < 2 * WINO_R_SLOTS && q != 9 && q != 19 && gy >= 0 && gy < H && vx >= 0 && n < n_img && gx < W;
+        roff[r] = ok ? ((n * HWi + gy * W + gx) * P.in_stride + 4 * hh) * 4 : 0x7FFFFF00;
     }
     typedef __attribute__((address_space(3))) void lds_void;
     auto patch_piece = [&](float* stage, int ch, int r) {    // 1 KB of the patch of chunk ch, straight into LDS
@@ -238,14 +243,18 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     __syncthreads();
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x); 64-byte runs per (channel, row)
-        const int64_t HW = (int64_t)H * W;
-        float* plane0 = P.out + out_px * P.k_planes;
-        const bool vec = (W & 3) == 0 && ((out_px * P.k_planes) & 3) == 0;
+        const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4, gy = y0 + oy;
+        int64_t px0[4];                                   // output pixel (of plane 0) per column, -1: not a pixel of any image
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int vx = x0 + ox + e, n = vx / Wv, gx = vx - n * Wv;
+            px0[e] = (n < n_img && gx < W && gy < H) ? (out_px + (int64_t)n * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
+        }
+        const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (HWi & 3) == 0;
 #pragma unroll 2
         for (int it = 0; it < 16; ++it) {
-            const int idx = it * 256 + tid, k = idx >> 6, oy = (idx >> 2) & 15, ox = (idx & 3) * 4;
-            const int kg = ks * 64 + k, gy = y0 + oy, gx = x0 + ox;
-            if (kg >= P.k_planes || gy >= H || gx >= W) continue;
+            const int k = it * 4 + (tid >> 6), kg = ks * 64 + k;
+            if (kg >= P.k_planes) continue;
             const float bias = P.bias ? P.bias[kg] : 0.0f;
             float y[4];
 #pragma unroll
@@ -258,25 +267,27 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            float* dst = plane0 + kg * HW + (int64_t)gy * W + gx;
+            float* plane = P.out + (int64_t)kg * HWi;
             if (vec) {
-                *reinterpret_cast<f32x4*>(dst) = v;      // W % 4 == 0: gx + 3 < W and 16-byte aligned
+                *reinterpret_cast<f32x4*>(plane + px0[0]) = v;
             } else {
-                dst[0] = v.x;
-                if (gx + 1 < W) dst[1] = v.y;
-                if (gx + 2 < W) dst[2] = v.z;
-                if (gx + 3 < W) dst[3] = v.w;
+                if (px0[0] >= 0) plane[px0[0]] = v.x;
+                if (px0[1] >= 0) plane[px0[1]] = v.y;
+                if (px0[2] >= 0) plane[px0[2]] = v.z;
+                if (px0[3] >= 0) plane[px0[3]] = v.w;
             }
         }
     } else {
         const int k4 = (tid & 15) * 4, kg = ks * 64 + k4;
         f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + kg);
+        const int ox = tid >> 4, vx = x0 + ox, n = vx / Wv, gx = vx - n * Wv;        // this thread's column of the block
+        const bool col_ok = n < n_img && gx < W;
+        const int64_t col_px = out_px + (int64_t)n * HWi + gx;
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int pix = it * 16 + (tid >> 4), oy = pix >> 4, ox = pix & 15;
-            const int gy = y0 + oy, gx = x0 + ox;
-            if (gy >= H || gx >= W) continue;
+        for (int oy = 0; oy < 16; ++oy) {
+            const int gy = y0 + oy;
+            if (!col_ok || gy >= H) continue;
             const float* r = lds + ((ox & 1) * 64 + (oy >> 1) * 8 + (ox >> 1)) * 64 + k4;      // R[a][ox & 1][tile][k4] at + a * 8192
             const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 8192 : 0));
             const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 16384 : 8192));
@@ -285,7 +296,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            const int64_t e = (out_px + (int64_t)gy * W + gx) * P.out_stride + kg;
+            const int64_t e = (col_px + (int64_t)gy * W) * P.out_stride + kg;
             if (P.thresh) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,

@@ -22,11 +22,13 @@ _TABLES = {}
 
 def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copies: Optional[int] = None, in_first: int = 0,
                 out_copies: Optional[int] = None) -> torch.Tensor:
-    """int32 (n_blocks, 4) {first pixel of the image in the input buffer, in the output buffer, H << 16 | W,
-    block_row << 16 | block_col}: one record per 16x16 output block of `copies` images per level.  The input buffer holds
-    `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read; the output buffer
-    holds `out_copies` per level and images 0 .. copies - 1 are written.  Blocks of one image are adjacent (their input halos
-    overlap: L2 reuse)."""
+    """int32 (n_blocks, 4) records of pod_wino_conv3x3: {first pixel of image 0 in the input buffer, in the output buffer,
+    H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS: the `copies` images of a level
+    stand side by side, image n at canvas columns n*Wv .. n*Wv+W-1 with Wv = W rounded up to even + 2 (the spare columns are the
+    zero padding between neighbours), so a partial block at the right edge is paid once per level, not once per image -- where that
+    saves blocks; otherwise every image is its own canvas.  The input
+    buffer holds `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read; the output
+    buffer holds `out_copies` per level and images 0 .. copies - 1 are written."""
     in_copies = copies if in_copies is None else in_copies
     out_copies = copies if out_copies is None else out_copies
     assert in_first + copies <= in_copies and copies <= out_copies
@@ -37,13 +39,20 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         rows = []
         for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
             assert h < 65536 and w < 65536
-            by, bx = (h + 15) // 16, (w + 15) // 16
-            n = torch.arange(copies, dtype=torch.int64).view(-1, 1, 1)
-            y = torch.arange(by, dtype=torch.int64).view(1, -1, 1)
-            x = torch.arange(bx, dtype=torch.int64).view(1, 1, -1)
-            rec = torch.stack(torch.broadcast_tensors(ioff + (in_first + n) * h * w, ooff + n * h * w, torch.tensor((h << 16) | w),
-                                                      (y << 16) | x), dim=-1)
-            rows.append(rec.reshape(-1, 4))
+            wv = (w + 1) // 2 * 2 + 2
+            # side by side only where that needs fewer blocks (a width that is a multiple of 16 is better off one image per canvas)
+            group = 127 if ((copies - 1) * wv + w + 15) // 16 < copies * ((w + 15) // 16) else 1
+            done = 0
+            while done < copies:                            # canvases of at most 127 images (the count sits in the top byte of an int32)
+                n = min(group, copies - done)
+                by, bx = (h + 15) // 16, ((n - 1) * wv + w + 15) // 16
+                assert by < 4096 and bx < 4096
+                y = torch.arange(by, dtype=torch.int64).view(-1, 1)
+                x = torch.arange(bx, dtype=torch.int64).view(1, -1)
+                rec = torch.stack(torch.broadcast_tensors(torch.tensor(ioff + (in_first + done) * h * w), torch.tensor(ooff + done * h * w),
+                                                          torch.tensor((h << 16) | w), (n << 24) | (y << 12) | x), dim=-1)
+                rows.append(rec.reshape(-1, 4))
+                done += n
         assert max(ioffs[-1], ooffs[-1]) < 2 ** 31
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()
         t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table

@@ -295,17 +295,26 @@ def test_coco_image_list_is_mapped_like_detectron2s_test_loader(tmp_path):
     assert tuple(b["image"].shape) == (3, 80, 100) and (b["height"], b["width"], b["image_id"]) == (40, 50, 17)
 
 
-def test_wino_block_table_lists_every_16x16_block_once():
-    """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {in pixel, out pixel, H<<16|W, by<<16|bx}."""
+def test_wino_block_table_canvases():
+    """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {in pixel, out pixel, H<<16|W,
+    n_images<<24 | by<<12 | bx}: images of a level side by side on one canvas where that saves blocks, else one canvas per image."""
     from pod_compare_amd.wino import block_table, level_pixel_offsets
-    levels = [(23, 40), (6, 10)]
-    assert level_pixel_offsets(levels, 3) == [0, 3 * 920, 3 * 920 + 3 * 60]
+    levels = [(23, 40), (6, 10), (16, 32)]
+    assert level_pixel_offsets(levels, 3) == [0, 3 * 920, 3 * 920 + 3 * 60, 3 * 920 + 3 * 60 + 3 * 512]
     t = block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3)
-    assert t.dtype == torch.int32 and t.shape == (2 * (2 * 3) + 2 * 1, 4)
+    assert t.dtype == torch.int32
     rows = t.tolist()
-    assert rows[0] == [1 * 920, 0, (23 << 16) | 40, 0] and rows[5] == [920, 0, (23 << 16) | 40, (1 << 16) | 2]
-    assert rows[6][:2] == [2 * 920, 920]                                        # second image of the first level
-    assert rows[12] == [5 * 920 + 1 * 60, 3 * 920, (6 << 16) | 10, 0]          # first image of the second level
-    assert rows[13] == [5 * 920 + 2 * 60, 3 * 920 + 60, (6 << 16) | 10, 0]
+    # level 0: W = 40 -> Wv = 42, canvas of 2 images = 82 columns = 6 block columns (3 + 3 apart), 2 block rows: no saving -> per image
+    assert rows[0] == [1 * 920, 0, (23 << 16) | 40, (1 << 24) | 0] and rows[5] == [920, 0, (23 << 16) | 40, (1 << 24) | (1 << 12) | 2]
+    assert rows[6][:2] == [2 * 920, 920]
+    # level 1: W = 10 -> Wv = 12, 2 images = 22 columns = 2 block columns instead of 2 x 1: no saving either
+    l1 = [r for r in rows if r[2] == (6 << 16) | 10]
+    assert [r[:2] for r in l1] == [[5 * 920 + 1 * 60, 3 * 920], [5 * 920 + 2 * 60, 3 * 920 + 60]]
+    # level 2: W = 32 is a multiple of 16: one canvas per image
+    l2 = [r for r in rows if r[2] == (16 << 16) | 32]
+    assert len(l2) == 2 * 2 and all((r[3] >> 24) == 1 for r in l2)
     assert len({tuple(r) for r in rows}) == len(rows)
     assert block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3) is t      # cached
+    # the benchmark frame: 19 runs side by side save 97 of 1767 blocks
+    big = block_table([(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)], 19, "cpu")
+    assert big.shape[0] == 1670 and int(big[0, 3]) >> 24 == 19
