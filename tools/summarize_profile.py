@@ -133,7 +133,7 @@ if os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
     lines += ["PMC counters per launch (separate `rocprofv3 --pmc` passes):", "", "| counter | mean per launch |", "|---|---|"]
     lines += ["| %s | %.6g |" % (k, v) for k, v in sorted(pm.items())]
     avg_ns = float(rows[0]["AverageNs"])
-    tiles, padded = 102144, 113088
+    tiles, padded = 102144, 106880
     fetch, write = 2 * pm.get("FETCH_SIZE", 0) * 1024, pm.get("WRITE_SIZE", 0) * 1024
     mfma_busy = pm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (pm.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024)
     lines += ["", "Derived: executed MFMA FLOPs of the real tiles 2*16*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the 157.3 TFLOP/s fp32 MFMA peak;" % (
