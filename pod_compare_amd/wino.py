@@ -42,6 +42,7 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
             wv = (w + 1) // 2 * 2 + 2
             # side by side only where that needs fewer blocks (a width that is a multiple of 16 is better off one image per canvas)
             group = 127 if ((copies - 1) * wv + w + 15) // 16 < copies * ((w + 15) // 16) else 1
+            group = max(1, min(group, (2 ** 31 - 1) // (h * w * 512 * 4), 65535 // wv))   # 32-bit byte offsets (C <= 512), 12-bit block columns
             done = 0
             while done < copies:                            # canvases of at most 127 images (the count sits in the top byte of an int32)
                 n = min(group, copies - done)
