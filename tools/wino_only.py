@@ -19,12 +19,12 @@ tab = block_table(levels, copies, dev)
 src = torch.randn(tab.pod_pixels, 256, device=dev)
 dst = torch.empty_like(src)
 for _ in range(n):
-    conv(src, dst, tab, relu=True, dropout_p=0.1, seed=1)
+    conv(src, dst, tab, relu=True, dropout_p=float(__import__("os").environ.get("WP", "0.1")), seed=1)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(n):
-    conv(src, dst, tab, relu=True, dropout_p=0.1, seed=1)
+    conv(src, dst, tab, relu=True, dropout_p=float(__import__("os").environ.get("WP", "0.1")), seed=1)
 ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / n
