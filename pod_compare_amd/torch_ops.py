@@ -13,6 +13,9 @@ no second implementation and no CPU kernel (calling them with CPU tensors raises
                  dense head tensors (per level, NCHW planes `(n_runs, A*C, H, W)`, the conv head's own layout) -> detections
     nms_cluster  detectron2 batched_nms as called at PI:554-560 / IU:31-36 -> keep indices
     reg_nll      compute_reg_scores' per-row NLL, scoring_rules.py:68-74
+    wino_filter_transform / wino_conv3x3
+                 the head's `Conv2d(C, K, 3, padding=1) [+ ReLU + Dropout]` (PR:403-484) for all MC runs and FPN levels in one
+                 launch: channels-last activations in, channels-last (trunk) or NCHW planes (predictors) out
 """
 from typing import List, Tuple
 
@@ -28,6 +31,9 @@ _LIB.define("predict(Tensor[] box_cls, Tensor[] box_delta, Tensor[] box_cls_var,
             "-> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _LIB.define("nms_cluster(Tensor boxes, Tensor scores, Tensor classes, float nms_thresh, int max_detections, int num_classes) -> Tensor")
 _LIB.define("reg_nll(Tensor means, Tensor covs, Tensor gt) -> Tensor")
+_LIB.define("wino_filter_transform(Tensor weight) -> Tensor")
+_LIB.define("wino_conv3x3(Tensor src, Tensor U, Tensor? bias, Tensor blocks, int K, int out_elements, bool planes=False, bool relu=False, "
+            "float dropout_p=0.0, int seed=0, int offset=0) -> Tensor")
 
 _PATHS = {}
 
@@ -112,7 +118,41 @@ def _reg_nll(means, covs, gt) -> torch.Tensor:
     return out
 
 
+def _wino_filter_transform(weight) -> torch.Tensor:
+    torch._check(weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3),
+                 lambda: "weight: CUDA fp32 (K, C, 3, 3)")
+    K, C = int(weight.shape[0]), int(weight.shape[1])
+    torch._check(C % 8 == 0 and (K + 63) // 64 in (1, 2, 4, 8), lambda: "C % 8 == 0 and K <= 512 in {64, 128, 256, 512} after padding")
+    U = torch.empty(16 * ((K + 63) // 64 * 64) * C, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        hip.check(hip.load().pod_wino_filter_transform(hip.ptr(weight.contiguous()), hip.ptr(U), K, C, hip.current_stream()),
+                  "pod_wino_filter_transform")
+    return U
+
+
+def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=False, dropout_p=0.0, seed=0, offset=0) -> torch.Tensor:
+    """src (pixels, C) channels-last; blocks: the int32 (n, 4) records of include/pod_mi355x.h (pod_compare_amd.wino.block_table builds
+    them); K real output channels; the result has out_elements floats: (pixels, round_up(K, 64)) channels-last, or with planes=True the
+    NCHW images of K planes each the records' output side describes (pixels nobody writes stay zero)."""
+    torch._check(src.is_cuda and src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous(), lambda: "src: contiguous CUDA fp32 (pixels, C)")
+    C, Kpad = int(src.shape[1]), (int(K) + 63) // 64 * 64
+    torch._check(U.is_cuda and U.dtype == torch.float32 and U.numel() == 16 * Kpad * C, lambda: "U: wino_filter_transform of a (K, C, 3, 3) weight")
+    torch._check(blocks.is_cuda and blocks.dtype == torch.int32 and blocks.dim() == 2 and blocks.shape[1] == 4 and blocks.is_contiguous(),
+                 lambda: "blocks: contiguous CUDA int32 (n, 4)")
+    torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == Kpad), lambda: "bias: round_up(K, 64) fp32 values")
+    torch._check(planes or out_elements == src.shape[0] * Kpad, lambda: "channels-last output: out_elements == pixels * round_up(K, 64)")
+    out = torch.zeros(int(out_elements), dtype=torch.float32, device=src.device) if planes else \
+        torch.empty((src.shape[0], Kpad), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        hip.check(hip.load().pod_wino_conv3x3(hip.ptr(src), hip.ptr(out), hip.ptr(U), hip.ptr(bias), hip.ptr(blocks), int(blocks.shape[0]), C, Kpad,
+                                              int(K) if planes else 0, 1 if relu else 0, float(dropout_p), int(seed), int(offset),
+                                              hip.current_stream()), "pod_wino_conv3x3")
+    return out
+
+
 _IMPL = torch.library.Library("pod_mi355x", "IMPL")
 _IMPL.impl("predict", _predict, "CUDA")
 _IMPL.impl("nms_cluster", _nms_cluster, "CUDA")
 _IMPL.impl("reg_nll", _reg_nll, "CUDA")
+_IMPL.impl("wino_filter_transform", _wino_filter_transform, "CUDA")
+_IMPL.impl("wino_conv3x3", _wino_conv3x3, "CUDA")

@@ -56,3 +56,31 @@ def test_operators_reject_bad_arguments():
     with pytest.raises(RuntimeError):
         torch.ops.pod_mi355x.nms_cluster(torch.zeros(4, 4, device="cuda", dtype=torch.float64), torch.zeros(4, device="cuda"),
                                          torch.zeros(4, device="cuda"), 0.5, 100, 3)
+
+
+def test_wino_conv_operator_equals_conv2d():
+    """torch.ops.pod_mi355x.wino_conv3x3: the head's convolution as an operator (channels-last and plane outputs)."""
+    import torch.nn.functional as F
+    from pod_compare_amd.wino import block_table, level_pixel_offsets
+    levels, copies, C, K = [(23, 40), (6, 10)], 2, 64, 63
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * 0.06
+    b = torch.zeros(64, device="cuda")
+    b[:K] = torch.randn(K, device="cuda", generator=g)
+    xs = [torch.randn(copies, C, h, wd, device="cuda", generator=g) for h, wd in levels]
+    src = torch.cat([x.permute(0, 2, 3, 1).reshape(-1, C) for x in xs]).contiguous()
+    U = torch.ops.pod_mi355x.wino_filter_transform(w)
+    table = block_table(levels, copies, "cuda")
+    offs = level_pixel_offsets(levels, copies)
+    nhwc = torch.ops.pod_mi355x.wino_conv3x3(src, U, b, table, K, src.shape[0] * 64, relu=True)
+    planes = torch.ops.pod_mi355x.wino_conv3x3(src, U, b, table, K, offs[-1] * K, planes=True)
+    for i, (x, (h, wd)) in enumerate(zip(xs, levels)):
+        want = F.conv2d(x, w, b[:K], padding=1)
+        got_p = planes[offs[i] * K:offs[i + 1] * K].view(copies, K, h, wd)
+        got_n = nhwc[offs[i]:offs[i + 1]].view(copies, h, wd, 64).permute(0, 3, 1, 2)[:, :K]
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got_p - want).abs().max()) <= 2e-5 * scale and float((got_n - want.relu()).abs().max()) <= 2e-5 * scale
+    with pytest.raises(Exception):
+        torch.ops.pod_mi355x.wino_conv3x3(src.cpu(), U, b, table, K, src.shape[0] * 64)
+    with pytest.raises(Exception):
+        torch.ops.pod_mi355x.wino_conv3x3(src, U[:-1], b, table, K, src.shape[0] * 64)
