@@ -160,20 +160,39 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
     };
     // row a of V = Bt d B for the lane's two tiles: 8 pieces (tile block x {t0 t1, t2 t3, V0 V1, V2 V3})
+    const f32x2 sgn2 = f32x2{sgn, sgn};
+    auto pk_fma = [](f32x2 s2, f32x2 q, f32x2 p) {
+        f32x2 r;
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(s2), "v"(q), "v"(p));
+        return r;
+    };
+    auto pk_add = [](f32x2 p, f32x2 q) {
+        f32x2 r;
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
+        return r;
+    };
+    auto pk_sub = [](f32x2 p, f32x2 q) {
+        f32x2 r;
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+        return r;
+    };
+    auto add4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_add(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_add(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
+    auto sub4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_sub(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_sub(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
     auto transform_piece = [&](f32x4(&v)[8], int i) {
         const int tb = i >> 2, part = i & 3;
         if (part < 2) {
 #pragma unroll
             for (int b = 2 * part; b < 2 * part + 2; ++b) {
                 const f32x4 p = x[(tb * 2 + 0) * 4 + b], q = x[(tb * 2 + 1) * 4 + b];
-                t[b] = f32x4{fmaf(sgn, q.x, p.x), fmaf(sgn, q.y, p.y), fmaf(sgn, q.z, p.z), fmaf(sgn, q.w, p.w)};
+                const f32x2 l = pk_fma(sgn2, f32x2{q.x, q.y}, f32x2{p.x, p.y}), hq = pk_fma(sgn2, f32x2{q.z, q.w}, f32x2{p.z, p.w});
+                t[b] = f32x4{l.x, l.y, hq.x, hq.y};
             }
         } else if (part == 2) {
-            v[tb * 4 + 0] = t[0] - t[2];
-            v[tb * 4 + 1] = t[1] + t[2];
+            v[tb * 4 + 0] = sub4(t[0], t[2]);
+            v[tb * 4 + 1] = add4(t[1], t[2]);
         } else {
-            v[tb * 4 + 2] = t[2] - t[1];
-            v[tb * 4 + 3] = t[1] - t[3];
+            v[tb * 4 + 2] = sub4(t[2], t[1]);
+            v[tb * 4 + 3] = sub4(t[1], t[3]);
         }
     };
 
