@@ -189,3 +189,25 @@ def test_concurrent_streams_give_the_serial_result():
         torch.cuda.synchronize()
         for j in range(3):
             assert torch.equal(outs[j], serial[j])
+
+
+def test_transformed_filters_follow_the_parameters():
+    """The head caches pod_wino_filter_transform per conv; an in-place parameter update (checkpoint load, BN fold) must refresh it."""
+    torch.manual_seed(13)
+    head = modeling.ProbabilisticRetinaNetHead(256, 9, 7, 4, 0.01, 0.0, False, False, 4).cuda().eval()
+    for q in head.parameters():
+        q.requires_grad_(False)
+    feats = [torch.randn(1, 256, 12, 20, device="cuda")]
+    before = head(feats, 1)[0][0].clone()
+    first = head._wino(head.cls_subnet[0])
+    assert head._wino(head.cls_subnet[0]) is first                      # cached while the parameters are untouched
+    head.cls_subnet[0].weight.mul_(3.0)                                  # in place: _version changes
+    assert head._wino(head.cls_subnet[0]) is not first
+    after = head(feats, 1)[0][0]
+    modeling.WINO_HEAD = False
+    try:
+        want = head(feats, 1)[0][0]
+    finally:
+        modeling.WINO_HEAD = True
+    assert float((after - before).abs().max()) > 0.0
+    assert float((after - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
