@@ -211,3 +211,30 @@ def test_transformed_filters_follow_the_parameters():
         modeling.WINO_HEAD = True
     assert float((after - before).abs().max()) > 0.0
     assert float((after - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+
+
+def test_full_frame_model_forward_winograd_head_equals_miopen_head():
+    """BASELINE geometry (1280x720 frame -> 750x1333 -> padded 768x1344, R = 193 374 anchors), eval mode (deterministic): the whole
+    model forward with the head on pod_wino_conv3x3 against the same model with the head on MIOpen."""
+    from pod_compare_amd import synthetic
+    torch.manual_seed(17)
+    model = modeling.ProbabilisticRetinaNet(dropout_rate=0.1, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                            bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    modeling.fold_frozen_bn(model)
+    for q in model.parameters():
+        q.requires_grad_(False)
+    for conv in list(model.head.cls_subnet) + list(model.head.bbox_subnet):
+        conv.weight.mul_(8.0)
+    img = modeling.resize_test_image(synthetic.synthetic_frame(3, 720, 1280, device="cuda"))
+    try:
+        modeling.WINO_HEAD = True
+        got = model(img, num_mc_dropout_runs=1)
+        modeling.WINO_HEAD = False
+        want = model(img, num_mc_dropout_runs=1)
+    finally:
+        modeling.WINO_HEAD = True
+    assert sum(t.shape[0] * 0 + t.shape[2] * t.shape[3] * 9 for t in got.cls) == 193374
+    for name in ("cls", "delta", "cls_var", "reg_var"):
+        for g, w in zip(getattr(got, name), getattr(want, name)):
+            assert g.shape == w.shape
+            assert float((g - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max())), name      # (the backbone is MIOpen in both)
