@@ -303,8 +303,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
     def _trunk_all_levels(self, convs, x0: torch.Tensor, levels, copies: int, dropout: bool):
         """`copies` evaluations of a subnet on ALL levels: one pod_wino_conv3x3 launch per conv layer (fp32 Winograd on the
         matrix cores, bias + ReLU + dropout in its store) instead of one MIOpen call + one element-wise pass per level and
-        layer.  x0: (pixels of all levels, C) channels-last, level after level.  Returns per level a (copies | 1, C, H, W)
-        channels-last view of the last activation."""
+        layer.  x0: (pixels of all levels, C) channels-last, level after level.  Returns (buffer, images per level): the last
+        activation as (pixels of all levels x images, C) channels-last, level after level -- `copies` images per level with
+        dropout, one without (every copy would be identical)."""
         from . import hip
         from .wino import block_table, level_pixel_offsets
         lib, C = hip.load(), x0.shape[1]
