@@ -299,16 +299,16 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
 /* ---- conv-net side: the head subnets' 3x3 convolutions -------------------------------------------------
  * Replaces: the `nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(), nn.Dropout(p)` triples of cls_subnet / bbox_subnet
  * (probabilistic_retinanet.py:403-427) and their evaluation "for every MC run, for every FPN level" (PR:95-108, detectron2
- * RetinaNetHead.forward's loop over features): ONE launch covers all levels and all runs.  fp32 Winograd F(2x2,3x3) on the
- * fp32 matrix cores, bias + ReLU + dropout fused into the store.
+ * RetinaNetHead.forward's loop over features): ONE launch covers all levels and all runs.  fp32 Winograd (F(2,3) down the rows, F(4,3) along
+ * the columns: 24 multiply-adds per 2x4 outputs where the direct form has 72) on the fp32 matrix cores, bias + ReLU + dropout fused into the store.
  *
  * Activations are channels-last: in[pixel][C], out[pixel][K]; all images of the launch live in the two buffers.  `blocks`
  * (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of image 0 in `in`, first pixel of image 0 in `out`,
  * H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS of n_images (1..127)
- * consecutive H x W images standing side by side: image n occupies canvas columns n*Wv .. n*Wv + W - 1, Wv = (W rounded up to
- * even) + 2, the spare columns are zero padding; block (r, c) covers canvas rows 16r.. and columns 16c.. (n_images = 1: the plain
+ * consecutive H x W images standing side by side: image n occupies canvas columns n*Wv .. n*Wv + W - 1, Wv = W + 1 rounded up
+ * to a multiple of 4, the spare columns are zero padding; block (r, c) covers canvas rows 16r.. and columns 16c.. (n_images = 1: the plain
  * ceil(H/16) x ceil(W/16) tiling of one image).
- * C % 8 == 0, K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 16 * round_up(K, 64) * C floats; weight is
+ * C % 8 == 0, K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 24 * round_up(K, 64) * C floats; weight is
  * (K, C, 3, 3), output channels past K are zero (so a K = 63 predictor runs as K = 64; bias then has round_up(K, 64) entries).
  * k_planes == 0: out is channels-last.  k_planes > 0 (the predictor convs cls_score / bbox_pred / cls_var / bbox_cov,
  * PR:430-484): out is NCHW, image = k_planes planes of H*W starting at float `k_planes * first pixel`: the (N, A*K, H, W)

@@ -42,10 +42,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k8_model_ops.hip: same mask as pod_bias_act
 
-constexpr int WINO_U_FLOATS = 16 * 2 * 64 * 4;          // filter slab of a chunk: [p][h][j][4 channels]            32 KB
+constexpr int WINO_U_FLOATS = 24 * 2 * 64 * 4;          // filter slab of a chunk: [24 positions][h][j][4 channels]  48 KB
 constexpr int WINO_R_SLOTS = 18 * 20;                    // 16-byte slots of one channel-half plane of the raw patch
 constexpr int WINO_STAGE_FLOATS = 12 * 64 * 4;           // raw patch stage: [h][row 18][parity 2][col/2: 9 (+1 pad)][4]: 720 slots, 12 KB
-constexpr int WINO_LDS_BYTES = 8 * 64 * 65 * 4;          // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
+constexpr int WINO_LDS_BYTES = 4 * 32 * 4 * 65 * 4;      // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
 
 struct WinoParams {
     const float* in;
@@ -59,8 +59,10 @@ struct WinoParams {
     uint64_t seed, offset;
 };
 
-// Filter transform U = G g Gt, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written in the order the main kernel's lanes load it:
-// U[ks][chunk][p][h][j][s] = U_p[c = 8 chunk + 4 h + s][k = 64 ks + j] (16 bytes per lane and position); channels >= K are zero.
+// Filter transform U = G4 g G6t (4 x 6 positions: F(2,3) down the rows, F(4,3) along the columns),
+//   G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],  G6 = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]],
+// written in the order the main kernel's lanes load it:
+// U[ks][chunk][q = 6 a + p][h][j][s] = U_q[c = 8 chunk + 4 h + s][k = 64 ks + j] (16 bytes per lane and position); channels >= K are zero.
 __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w, float* __restrict__ U, int32_t K, int32_t C, int32_t Kpad) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)Kpad * C) return;
@@ -81,12 +83,16 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
     float* dst = U + ((int64_t)ks * nchunk + ch) * WINO_U_FLOATS + (h * 64 + j64) * 4 + sc;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const float u0 = t0[a][0], u1 = 0.5f * (t0[a][0] + t0[a][1] + t0[a][2]), u2 = 0.5f * (t0[a][0] - t0[a][1] + t0[a][2]),
-                    u3 = t0[a][2];
-        dst[(a * 4 + 0) * 512] = u0;
-        dst[(a * 4 + 1) * 512] = u1;
-        dst[(a * 4 + 2) * 512] = u2;
-        dst[(a * 4 + 3) * 512] = u3;
+        const float x0 = t0[a][0], x1 = t0[a][1], x2 = t0[a][2];
+        float u[6];
+        u[0] = 0.25f * x0;
+        u[1] = (-1.0f / 6.0f) * (x0 + x1 + x2);
+        u[2] = (-1.0f / 6.0f) * (x0 - x1 + x2);
+        u[3] = (1.0f / 24.0f) * x0 + (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
+        u[4] = (1.0f / 24.0f) * x0 - (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
+        u[5] = x2;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dst[(a * 6 + p) * 512] = u[p];
     }
 }
 
@@ -98,38 +104,39 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
     if (tb >= P.n_blocks) return;
     // block record: the images of a (level, launch) stand SIDE BY SIDE on a virtual canvas, image n at columns n*Wv .. n*Wv+W-1
-    // with Wv = W rounded up to even + 2: the two spare columns are the zero padding between neighbours (reads outside an
-    // image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- a partial block at the
+    // with Wv = W + 1 rounded up to a multiple of 4 (tiles are 4 pixels wide): the spare columns are the zero padding between
+    // neighbours (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- a partial block at the
     // right edge is paid once per level instead of once per image.
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int H = desc.z >> 16, W = desc.z & 0xFFFF, n_img = (desc.w >> 24) & 0xFF;
-    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = ((W + 1) & ~1) + 2, HWi = H * W;
+    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = (W + 4) & ~3, HWi = H * W;
     const int nchunk = P.C >> 3;
 
-    // ---- operands.  Wavefront `a` owns ROW a of the 4x4 Winograd position grid (positions 4a .. 4a+3) for all 64 tiles (two
-    // 32-tile blocks, tb) and all 64 output channels (two 32-channel blocks, kb): 4 x 2 x 2 MFMA blocks = 256 accumulators.
-    // Row a of Bt d is one sum or difference of two patch rows:
+    // ---- operands.  Tiles are 2 rows x 4 columns of outputs (F(2,3) down the rows: 4 patch rows; F(4,3) along the columns: 6
+    // patch columns), 24 Winograd positions per tile and (c, k) pair where the direct convolution has 72 multiply-adds.  A
+    // 16x16-pixel block is 8 x 4 = 32 tiles = one MFMA block of rows.  Wavefront `a` owns ROW a of the 4 x 6 position grid
+    // (positions 6a .. 6a+5) for the 32 tiles and all 64 output channels (two 32-channel blocks, kb): 6 x 2 = 12 MFMA blocks =
+    // 192 accumulators.  Row a of Bt4 d is one sum or difference of two patch rows:
     //     a = 0: d0 - d2      a = 1: d1 + d2      a = 2: d2 - d1      a = 3: d1 - d3
-    // = x0 + s x1 with wave-uniform row offsets and sign, so a lane transforms its two tiles with 2 x (4 + 4) four-channel adds
-    // per chunk (a quarter of Bt d B), and every transformed value and every filter operand feeds TWO MFMAs.
-    //   * filter operands never touch LDS: a lane needs U_p[its 4 channels][its output channel] for its row's 4 positions and
-    //     both channel blocks = 8 x 16 bytes per chunk, loaded straight from L2 (the filter slice of this XCD) one chunk ahead;
+    // = x0 + s x1 with wave-uniform row offsets and sign (6 columns), followed by the 6-point column transform Bt6; every
+    // transformed value feeds two MFMAs (kb).
+    //   * filter operands never touch LDS: a lane needs U_q[its 4 channels][its output channel] for its row's 6 positions and
+    //     both channel blocks = 12 x 16 bytes per chunk, loaded straight from L2 (the filter slice of this XCD) one chunk ahead;
     //     the four waves together read each slab byte exactly once;
-    //   * the raw 18x18-pixel patch goes global -> LDS by LDS-DMA (buffer_load ... lds), 16-byte slots [h][row][col parity][col/2]:
-    //     the 16 lanes of a ds_read_b128 group (tile-row stride 40 = 8 mod 16 slots, tile-column stride 1) hit 16 different
-    //     slots; out-of-range buffer offsets return 0.0 -- that IS the zero padding of the convolution; pad slots load nothing.
+    //   * the raw 18x18-pixel patch goes global -> LDS by LDS-DMA (buffer_load ... lds), 16-byte slots [h][row][col parity][col/2];
+    //     out-of-range buffer offsets return 0.0 -- that IS the zero padding of the convolution; pad slots load nothing.
     const int i32 = lane & 31, h = lane >> 5;
     const int a = __builtin_amdgcn_readfirstlane(wave);
     const int row0 = a == 0 ? 0 : a == 2 ? 2 : 1, row1 = a == 2 ? 1 : a == 3 ? 3 : 2;
     const float sgn = a == 1 ? 1.0f : -1.0f;
-    const int a_base = (h * WINO_R_SLOTS + 2 * (i32 >> 3) * 20 + (i32 & 7)) * 4;      // tile (i32>>3, i32&7) of block tb = 0
-    const int a_r0 = a_base + row0 * 80, a_r1 = a_base + row1 * 80;                     // + tb*640 + ((b&1)*10 + (b>>1))*4
+    const int a_base = (h * WINO_R_SLOTS + 2 * (i32 >> 2) * 20 + 2 * (i32 & 3)) * 4;  // tile (i32>>2, i32&3): patch row 2 ty, column 4 tx
+    const int a_r0 = a_base + row0 * 80, a_r1 = a_base + row1 * 80;                     // + ((c&1)*10 + (c>>1))*4, c = 0..5
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
                                                           nchunk * WINO_U_FLOATS * 4, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
                                                           n_img * HWi * P.in_stride * 4, 0x00020000);
-    const int u_off = ((a * 4 * 2 + h) * 64 + i32) * 16;                               // + (b*2*64 + kb*32)*16 bytes, + chunk*32 KB
+    const int u_off = ((a * 6 * 2 + h) * 64 + i32) * 16;                               // + (p*2*64 + kb*32)*16 bytes, + chunk*48 KB
     int roff[3];                                                                       // this lane's three patch slots
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -145,25 +152,24 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 3 + r) * 256), 16, roff[r], ch * 32, 0, 0);
     };
 
-    f32x16 acc[16];                                                      // [b][tb][kb]
+    f32x16 acc[12];                                                      // [p][kb]
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 12; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    f32x4 x[16], uA[8], uB[8], vA[8], vB[8], t[4];                       // x[tb][row][b], u[b][kb], v[tb][b]: 4 channels each
-    auto read_piece = [&](const float* stage, int i) {                   // 16 pieces: one ds_read_b128 each
-        const int tb = i >> 3, row = (i >> 2) & 1, b = i & 3;
-        x[i] = *reinterpret_cast<const f32x4*>(stage + (row ? a_r1 : a_r0) + tb * 640 + ((b & 1) * 10 + (b >> 1)) * 4);
+    f32x4 x[12], uA[12], uB[12], vA[6], vB[6], t[6], w6[4];              // x[row][c], u[p][kb], v[p]: 4 channels each
+    auto read_piece = [&](const float* stage, int i) {                   // 12 pieces: one ds_read_b128 each
+        const int row = i / 6, c = i % 6;
+        x[i] = *reinterpret_cast<const f32x4*>(stage + (row ? a_r1 : a_r0) + ((c & 1) * 10 + (c >> 1)) * 4);
     };
-    auto filter_piece = [&](int ch, f32x4(&u)[8], int i) {               // 8 pieces: one buffer_load_dwordx4 each
+    auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
         u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
     };
-    // row a of V = Bt d B for the lane's two tiles: 8 pieces (tile block x {t0 t1, t2 t3, V0 V1, V2 V3})
-    const f32x2 sgn2 = f32x2{sgn, sgn};
-    auto pk_fma = [](f32x2 s2, f32x2 q, f32x2 p) {
+    // packed fp32 arithmetic on the halves of a 4-channel value: r = q * k + p
+    auto pk_fma = [](f32x2 k2, f32x2 q, f32x2 p) {
         f32x2 r;
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(s2), "v"(q), "v"(p));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(k2), "v"(q), "v"(p));
         return r;
     };
     auto pk_add = [](f32x2 p, f32x2 q) {
@@ -176,34 +182,49 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));
         return r;
     };
+    auto fma4 = [&](float k, f32x4 q, f32x4 p) {   // q * k + p
+        const f32x2 k2 = f32x2{k, k};
+        const f32x2 l = pk_fma(k2, f32x2{q.x, q.y}, f32x2{p.x, p.y}), hq = pk_fma(k2, f32x2{q.z, q.w}, f32x2{p.z, p.w});
+        return f32x4{l.x, l.y, hq.x, hq.y};
+    };
     auto add4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_add(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_add(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
     auto sub4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_sub(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_sub(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
-    auto transform_piece = [&](f32x4(&v)[8], int i) {
-        const int tb = i >> 2, part = i & 3;
-        if (part < 2) {
+    // row a of V = Bt4 d Bt6^T for the lane's tile, 10 pieces of two 4-channel operations:
+    //   t_c = x0_c + s x1_c (6);  V0 = 4 t0 - 5 t2 + t4;  V5 = 4 t1 - 5 t3 + t5;  e = t4 - 4 t2, o = t3 - 4 t1: V1 = e + o, V2 = e - o;
+    //   f = t4 - t2, g = 2 (t3 - t1): V3 = f + g, V4 = f - g
+    auto transform_piece = [&](f32x4(&v)[6], int i) {
+        if (i < 3) {
 #pragma unroll
-            for (int b = 2 * part; b < 2 * part + 2; ++b) {
-                const f32x4 p = x[(tb * 2 + 0) * 4 + b], q = x[(tb * 2 + 1) * 4 + b];
-                const f32x2 l = pk_fma(sgn2, f32x2{q.x, q.y}, f32x2{p.x, p.y}), hq = pk_fma(sgn2, f32x2{q.z, q.w}, f32x2{p.z, p.w});
-                t[b] = f32x4{l.x, l.y, hq.x, hq.y};
-            }
-        } else if (part == 2) {
-            v[tb * 4 + 0] = sub4(t[0], t[2]);
-            v[tb * 4 + 1] = add4(t[1], t[2]);
-        } else {
-            v[tb * 4 + 2] = sub4(t[2], t[1]);
-            v[tb * 4 + 3] = sub4(t[1], t[3]);
+            for (int c = 2 * i; c < 2 * i + 2; ++c) t[c] = fma4(sgn, x[6 + c], x[c]);
+        } else if (i == 3) {
+            w6[0] = fma4(-5.0f, t[2], t[4]);          // t4 - 5 t2
+            w6[1] = fma4(-5.0f, t[3], t[5]);          // t5 - 5 t3
+        } else if (i == 4) {
+            v[0] = fma4(4.0f, t[0], w6[0]);
+            v[5] = fma4(4.0f, t[1], w6[1]);
+        } else if (i == 5) {
+            w6[0] = fma4(-4.0f, t[2], t[4]);          // e
+            w6[1] = fma4(-4.0f, t[1], t[3]);          // o
+        } else if (i == 6) {
+            v[1] = add4(w6[0], w6[1]);
+            v[2] = sub4(w6[0], w6[1]);
+        } else if (i == 7) {
+            w6[2] = sub4(t[4], t[2]);                 // f
+            w6[3] = sub4(t[3], t[1]);                 // g / 2
+        } else if (i == 8) {
+            v[3] = fma4(2.0f, w6[3], w6[2]);
+        } else if (i == 9) {
+            v[4] = fma4(-2.0f, w6[3], w6[2]);
         }
     };
 
-    // One chunk = 64 MFMAs (k-step j >> 4 = channel j >> 4 of the lane's four, accumulator j & 15 = (b, tb, kb)) with the next
-    // chunk's work slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four
-    // waves of the workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the
-    // in-order instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and the
-    // LDS-DMA of the patch of chunk ch+2 into the stage chunk ch was read from.  Two stages; one barrier per chunk.
-#define WINO_MFMA(V, U, j)                                                                                                          \
-    acc[(j) & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(((j) >> 1) & 1) * 4 + (((j) & 15) >> 2)][(j) >> 4],                      \
-                                                         U[(((j) & 15) >> 2) * 2 + ((j) & 1)][(j) >> 4], acc[(j) & 15], 0, 0, 0)
+    // One chunk = 48 MFMAs (k-step j / 12 = channel of the lane's four, accumulator j % 12 = (p, kb)) with the next chunk's work
+    // slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four waves of the
+    // workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the in-order
+    // instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and the LDS-DMA of
+    // the patch of chunk ch+2 into the stage chunk ch was read from.  Two stages; one barrier per chunk.
+#define WINO_MFMA(V, U, j)                                                                                                   \
+    acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((j) % 12) >> 1][(j) / 12], U[(j) % 12][(j) / 12], acc[(j) % 12], 0, 0, 0)
     float* st0 = lds;
     float* st1 = lds + WINO_STAGE_FLOATS;
     const int last = nchunk - 1;
@@ -212,22 +233,22 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) patch_piece(st1, last < 1 ? last : 1, r);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) filter_piece(0, uA, i);
+    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) read_piece(st0, i);
+    for (int i = 0; i < 12; ++i) read_piece(st0, i);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) transform_piece(vA, i);
+    for (int i = 0; i < 10; ++i) transform_piece(vA, i);
     __syncthreads();                                   // every wave has read chunk 0's patch: its stage may be overwritten
-    auto chunk = [&](int ch, f32x4(&vC)[8], f32x4(&uC)[8], f32x4(&vN)[8], f32x4(&uN)[8], const float* rd, float* wr) {
+    auto chunk = [&](int ch, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12], const float* rd, float* wr) {
         const int c1 = ch + 1 < nchunk ? ch + 1 : last, c2 = ch + 2 < nchunk ? ch + 2 : last;
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
+        for (int j = 0; j < 48; ++j) {
             WINO_MFMA(vC, uC, j);
-            if (j < 16) read_piece(rd, j);
-            else if (j < 24) filter_piece(c1, uN, j - 16);
+            if (j < 12) read_piece(rd, j);
+            else if (j < 24) filter_piece(c1, uN, j - 12);
             else if (j < 27) patch_piece(wr, c2, j - 24);
-            else if (j >= 32 && j < 40) transform_piece(vN, j - 32);
+            else if (j >= 28 && j < 38) transform_piece(vN, j - 28);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                               // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
@@ -241,27 +262,29 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages: they become the output staging
 
-    // ---- output transform Y = At M A, At = [[1,1,1,0],[0,1,-1,-1]].  Lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5),
-    // column (channel) = lane & 31.  Every wave reduces its row over b (R0 = m0 + m1 + m2, R1 = m1 - m2 - m3) and parks
-    // R[a][x][tile][channel] in LDS (128 KB); the store pass combines the four rows in a fixed order:
-    //     Y[0][x] = (R[0][x] + R[1][x]) + R[2][x]          Y[1][x] = (R[1][x] - R[2][x]) - R[3][x]
-    const int LD = P.k_planes > 0 ? 65 : 64;   // tile row of the staging: 16-byte reads along k (64) or scalar reads, bank-spread (65)
+    // ---- output transform Y = At2 M At4^T, At2 = [[1,1,1,0],[0,1,-1,-1]], At4 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].
+    // Lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5), column (channel) = lane & 31.  Every wave applies At4 to its
+    // row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS (128 KB); the store pass
+    // combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],  Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
+    const int LD = P.k_planes > 0 ? 65 : 64;   // one (tile, column) line of the staging: 16-byte reads along k (64) or scalar reads, bank-spread (65)
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float m0 = acc[0 * 4 + tb * 2 + kb][reg], m1 = acc[1 * 4 + tb * 2 + kb][reg], m2 = acc[2 * 4 + tb * 2 + kb][reg],
-                            m3 = acc[3 * 4 + tb * 2 + kb][reg];
-                const int tile = (4 * tb + (reg >> 2)) * 8 + (reg & 3) + 4 * h;
-                float* o = lds + ((a * 2) * 64 + tile) * LD + kb * 32 + i32;
-                o[0] = m0 + m1 + m2;
-                o[64 * LD] = m1 - m2 - m3;
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const float m0 = acc[0 * 2 + kb][reg], m1 = acc[1 * 2 + kb][reg], m2 = acc[2 * 2 + kb][reg], m3 = acc[3 * 2 + kb][reg],
+                        m4 = acc[4 * 2 + kb][reg], m5 = acc[5 * 2 + kb][reg];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            const int tile = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float* o = lds + ((a * 32 + tile) * 4) * LD + kb * 32 + i32;
+            o[0] = (m0 + s1) + s2;
+            o[LD] = fmaf(2.0f, d2, d1);
+            o[2 * LD] = fmaf(4.0f, s2, s1);
+            o[3 * LD] = fmaf(8.0f, d2, d1) + m5;
+        }
     __syncthreads();
+    const int ZA = 32 * 4 * LD;                // floats per position row a
     if (P.k_planes > 0) {
-        // NCHW planes: thread -> (channel, row of the block, 4 pixels along x); 64-byte runs per (channel, row)
+        // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4, gy = y0 + oy;
         int64_t px0[4];                                   // output pixel (of plane 0) per column, -1: not a pixel of any image
 #pragma unroll
@@ -270,6 +293,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             px0[e] = (n < n_img && gx < W && gy < H) ? (out_px + (int64_t)n * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
         }
         const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (HWi & 3) == 0;
+        const int tile = (oy >> 1) * 4 + (tid & 3);
 #pragma unroll 2
         for (int it = 0; it < 16; ++it) {
             const int k = it * 4 + (tid >> 6), kg = ks * 64 + k;
@@ -278,9 +302,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int tile = (oy >> 1) * 8 + ((ox + e) >> 1), xx = e & 1;
-                const float* r = lds + (xx * 64 + tile) * 65 + k;              // R[a][xx][tile][k] at + a * 2 * 64 * 65
-                y[e] = (oy & 1) == 0 ? (r[0] + r[2 * 64 * 65]) + r[4 * 64 * 65] : (r[2 * 64 * 65] - r[4 * 64 * 65]) - r[6 * 64 * 65];
+                const float* r = lds + (tile * 4 + e) * 65 + k;                // Z[a][tile][e][k] at + a * ZA
+                y[e] = (oy & 1) == 0 ? (r[0] + r[ZA]) + r[2 * ZA] : (r[ZA] - r[2 * ZA]) - r[3 * ZA];
             }
             f32x4 v = f32x4{y[0], y[1], y[2], y[3]} + bias;
             if (P.relu) {
@@ -307,10 +330,10 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int oy = 0; oy < 16; ++oy) {
             const int gy = y0 + oy;
             if (!col_ok || gy >= H) continue;
-            const float* r = lds + ((ox & 1) * 64 + (oy >> 1) * 8 + (ox >> 1)) * 64 + k4;      // R[a][ox & 1][tile][k4] at + a * 8192
-            const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 8192 : 0));
-            const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 16384 : 8192));
-            const f32x4 rc = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 24576 : 16384));
+            const float* r = lds + (((oy >> 1) * 4 + (ox >> 2)) * 4 + (ox & 3)) * 64 + k4;      // Z[a][tile][ox & 3][k4] at + a * ZA
+            const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? ZA : 0));
+            const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 2 * ZA : ZA));
+            const f32x4 rc = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 3 * ZA : 2 * ZA));
             f32x4 v = ((oy & 1) ? (ra - rb) - rc : (ra + rb) + rc) + bias;
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);

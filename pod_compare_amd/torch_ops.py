@@ -123,7 +123,7 @@ def _wino_filter_transform(weight) -> torch.Tensor:
                  lambda: "weight: CUDA fp32 (K, C, 3, 3)")
     K, C = int(weight.shape[0]), int(weight.shape[1])
     torch._check(C % 8 == 0 and (K + 63) // 64 in (1, 2, 4, 8), lambda: "C % 8 == 0 and K <= 512 in {64, 128, 256, 512} after padding")
-    U = torch.empty(16 * ((K + 63) // 64 * 64) * C, dtype=torch.float32, device=weight.device)
+    U = torch.empty(24 * ((K + 63) // 64 * 64) * C, dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
         hip.check(hip.load().pod_wino_filter_transform(hip.ptr(weight.contiguous()), hip.ptr(U), K, C, hip.current_stream()),
                   "pod_wino_filter_transform")
@@ -136,7 +136,7 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     NCHW images of K planes each the records' output side describes (pixels nobody writes stay zero)."""
     torch._check(src.is_cuda and src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous(), lambda: "src: contiguous CUDA fp32 (pixels, C)")
     C, Kpad = int(src.shape[1]), (int(K) + 63) // 64 * 64
-    torch._check(U.is_cuda and U.dtype == torch.float32 and U.numel() == 16 * Kpad * C, lambda: "U: wino_filter_transform of a (K, C, 3, 3) weight")
+    torch._check(U.is_cuda and U.dtype == torch.float32 and U.numel() == 24 * Kpad * C, lambda: "U: wino_filter_transform of a (K, C, 3, 3) weight")
     torch._check(blocks.is_cuda and blocks.dtype == torch.int32 and blocks.dim() == 2 and blocks.shape[1] == 4 and blocks.is_contiguous(),
                  lambda: "blocks: contiguous CUDA int32 (n, 4)")
     torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == Kpad), lambda: "bias: round_up(K, 64) fp32 values")

@@ -24,8 +24,8 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
                 out_copies: Optional[int] = None) -> torch.Tensor:
     """int32 (n_blocks, 4) records of pod_wino_conv3x3: {first pixel of image 0 in the input buffer, in the output buffer,
     H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS: the `copies` images of a level
-    stand side by side, image n at canvas columns n*Wv .. n*Wv+W-1 with Wv = W rounded up to even + 2 (the spare columns are the
-    zero padding between neighbours), so a partial block at the right edge is paid once per level, not once per image -- where that
+    stand side by side, image n at canvas columns n*Wv .. n*Wv+W-1 with Wv = W + 1 rounded up to a multiple of 4 (the spare columns are
+    the zero padding between neighbours), so a partial block at the right edge is paid once per level, not once per image -- where that
     saves blocks; otherwise every image is its own canvas.  The input
     buffer holds `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read; the output
     buffer holds `out_copies` per level and images 0 .. copies - 1 are written."""
@@ -39,7 +39,7 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         rows = []
         for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
             assert h < 65536 and w < 65536
-            wv = (w + 1) // 2 * 2 + 2
+            wv = (w + 4) // 4 * 4
             # side by side only where that needs fewer blocks (a width that is a multiple of 16 is better off one image per canvas)
             group = 127 if ((copies - 1) * wv + w + 15) // 16 < copies * ((w + 15) // 16) else 1
             group = max(1, min(group, (2 ** 31 - 1) // (h * w * 512 * 4), 65535 // wv))   # 32-bit byte offsets (C <= 512), 12-bit block columns
@@ -72,7 +72,7 @@ class WinoConv:
         if self.C % 8 or self.Kpad not in (64, 128, 256, 512):
             raise ValueError("pod_wino_conv3x3: C %% 8 == 0 and K <= 512 in steps of 64 required, got C=%d K=%d" % (self.C, self.K))
         lib = hip.load()
-        self.U = torch.empty(16 * self.Kpad * self.C, dtype=torch.float32, device=weight.device)
+        self.U = torch.empty(24 * self.Kpad * self.C, dtype=torch.float32, device=weight.device)
         hip.check(lib.pod_wino_filter_transform(weight.detach().contiguous().data_ptr(), self.U.data_ptr(), self.K, self.C, hip.current_stream()),
                   "pod_wino_filter_transform")
         self.bias = None

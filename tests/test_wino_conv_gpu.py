@@ -82,7 +82,7 @@ def test_invalid_arguments_are_rejected():
     lib = hip.load()
     x = torch.zeros(256, 8, device="cuda")
     y = torch.zeros(256, 64, device="cuda")
-    u = torch.zeros(16 * 64 * 8, device="cuda")
+    u = torch.zeros(24 * 64 * 8, device="cuda")
     t = block_table([(16, 16)], 1, "cuda")
     s = hip.current_stream()
     ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)
