@@ -163,17 +163,17 @@ def conv_census(model, img, N, quirk, dev):
         d["ms"] /= reps
         d["tflops"] = d["gflop"] / d["ms"] if d["ms"] > 0 else None
     w = out.get("3x3_head_winograd_hip")
-    if w:   # F(2x2,3x3): 16 multiplies where the direct form has 36, tiles of partial 16x16 blocks included in the time only
+    if w:   # F(2,3) x F(4,3): 24 multiplies where the direct form has 72, tiles of partial 16x16 blocks included in the time only
         w["note"] = ("pod_wino_conv3x3; gflop / tflops are DIRECT-convolution FLOPs (the model's arithmetic), the matrix cores "
-                     "execute 16/36 of them: mfma_tflops_executed is what to hold against the 157.3 TFLOP/s peak")
-        w["mfma_tflops_executed"] = w["tflops"] * 16.0 / 36.0 if w["tflops"] else None
+                     "execute 24/72 of them: mfma_tflops_executed is what to hold against the 157.3 TFLOP/s peak")
+        w["mfma_tflops_executed"] = w["tflops"] * 24.0 / 72.0 if w["tflops"] else None
     return out
 
 
 def head_conv_roofline(model, net_hw, N, quirk, dev):
     """pod_wino_conv3x3 on its largest launch of a step (one bbox_subnet layer: every MC run of every FPN level), timed with
-    HIP events on the launch stream.  fp32 Winograd F(2x2,3x3): per 2x2 output tile and (c, k) pair the matrix cores execute
-    16 multiply-adds where the direct convolution has 36, so `achieved` (executed MFMA FLOPs of the real tiles / time) is what
+    HIP events on the launch stream.  fp32 Winograd, F(2,3) down the rows x F(4,3) along the columns: per 2x4 output tile and (c, k)
+    pair the matrix cores execute 24 multiply-adds where the direct convolution has 72, so `achieved` (executed MFMA FLOPs of the real tiles / time) is what
     to hold against the fp32 MFMA peak, and `direct_equivalent_tflops` is the rate in the model's own arithmetic."""
     from pod_compare_amd import wino
     head = model.head
@@ -199,8 +199,8 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) / B for a, b in evs)
     avg = sum(ms) / len(ms)
-    tiles = copies * sum(((h + 1) // 2) * ((w + 1) // 2) for h, w in levels)
-    mfma_flop = 2.0 * 16 * tiles * conv.C * conv.K
+    tiles = copies * sum(((h + 1) // 2) * ((w + 3) // 4) for h, w in levels)        # 2 x 4 output tiles, 24 Winograd positions each
+    mfma_flop = 2.0 * 24 * tiles * conv.C * conv.K
     direct_flop = 2.0 * 9 * table.pod_pixels * conv.C * conv.K
     traffic = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wino_traffic.json")), reverse=True):
@@ -212,7 +212,7 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
             "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TF, "achieved": mfma_flop / avg / 1e9,
             "frac": mfma_flop / avg / 1e9 / FP32_MFMA_PEAK_TF, "direct_equivalent_tflops": direct_flop / avg / 1e9,
             "algorithmic_flop": mfma_flop, "direct_flop": direct_flop, "avg_launch_us": 1e3 * avg, "min_launch_us": 1e3 * ms[0],
-            "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 64, "traffic": traffic,
+            "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 32, "traffic": traffic,
             "share_of_step": "12 launches of this kernel are ~93 % of a step's GPU time (conv_roofline.by_kind)"}
 
 
@@ -543,7 +543,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
         out["conv_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TF, "dtype": "f32",
                                 "gflop_per_image": gflop, "achieved": step_tf, "frac": step_tf / FP32_MFMA_PEAK_TF,
                                 "basis": "direct-convolution FLOPs of one image (2*N*Cout*Hout*Wout*Cin*kh*kw of every conv call, MIOpen's and "
-                                         "pod_wino_conv3x3's) / ms_per_step; the head's Winograd kernel executes 16/36 of its share, so "
+                                         "pod_wino_conv3x3's) / ms_per_step; the head's Winograd kernel executes 24/72 of its share, so "
                                          "this fraction is not bounded by 1",
                                 "conv_ms_per_image_one_stream": conv_ms,
                                 "one_stream_frac": gflop / conv_ms / FP32_MFMA_PEAK_TF if conv_ms > 0 else None,

@@ -1,34 +1,35 @@
 // 3x3 / stride 1 / pad 1 fp32 convolution of the probabilistic RetinaNet head's subnets (probabilistic_retinanet.py:403-427:
-// four conv3x3(256 -> 256) + ReLU + Dropout per subnet, evaluated for every MC run on every FPN level) as ONE launch over
-// all levels and all runs: Winograd F(2x2, 3x3) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), bias + ReLU + dropout
-// fused into the store.
+// four conv3x3(256 -> 256) + ReLU + Dropout per subnet, evaluated for every MC run on every FPN level) and predictors
+// (PR:430-484) as ONE launch per conv layer over all levels and all runs: fp32 Winograd on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), bias + ReLU + dropout fused into the store.
 //
 // Why Winograd: a direct fp32 convolution is bounded by the 157 TFLOP/s fp32 MFMA peak (MIOpen's implicit GEMM reaches
-// 0.83 of it on the p3 maps and nothing can reach more than 1.0); F(2x2, 3x3) needs 16 multiplies per 2x2 outputs and
-// (c, k) pair instead of 36, so the same matrix cores deliver up to 2.25x the direct-convolution rate, in fp32 throughout
-// (the transforms only add and subtract; the filter transform has two halvings).  Error vs direct fp32: ~1e-6 relative.
+// 0.83 of it on the p3 maps and nothing can reach more than 1.0).  F(2,3) down the rows x F(4,3) along the columns needs
+// 4 x 6 = 24 multiply-adds per 2x4 outputs and (c, k) pair instead of 72, so the same matrix cores deliver up to 3x the
+// direct-convolution rate, in fp32 throughout.  Error vs a direct fp32 convolution: ~4e-6 of the output scale at C = 256
+// (F(2x2,3x3), the first version: 2e-6 and 16 / 36 of the multiply-adds).
 //
-//   Y = At [ (G g Gt) . (Bt d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs, "." summed over c
+//   Y = At2 [ (G4 g G6^T) . (Bt4 d Bt6^T) ] At4^T     d: 4x6 input patch, g: 3x3 filter, Y: 2x4 outputs, "." summed over c
 //
 // Data layout (channels-last): activations are [pixel][C] fp32; every (level, run) image of a launch lives in the same
-// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of the image in `in`, in `out`, H << 16 | W, by << 16 | bx})
-// says where.  Filters are transformed once (pod_wino_filter_transform) into the order the kernel's lanes load them in.
-// The predictor convolutions (cls_score, bbox_pred, cls_var, bbox_cov: K = 63 / 36 / 90 real channels) write NCHW planes,
-// the layout K1 streams, straight from the staging tile.
+// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of image 0 in `in`, in `out`, H << 16 | W,
+// n_images << 24 | by << 12 | bx}) says where.  Filters are transformed once (pod_wino_filter_transform) into the order the
+// kernel's lanes load them in.  The predictor convolutions (cls_score, bbox_pred, cls_var, bbox_cov: K = 63 / 36 / 90 real
+// channels) write NCHW planes, the layout K1 streams, straight from the staging tile.
 //
-// Workgroup = 256 threads = 4 waves, one per SIMD: 64 tiles (8x8 tiles = 16x16 output pixels) x 64 output channels x the
-// 16 Winograd positions.  Wave a owns ROW a of the 4x4 position grid for all 64 tiles and all 64 channels: 4 positions x
-// (2 tile blocks x 2 channel blocks) of 32x32 = 16 MFMA blocks = 256 accumulator registers.  A row of Bt d is one sum or
-// difference of two patch rows, so a lane transforms its two tiles with 16 four-channel adds per chunk, and every transformed
-// value and every filter operand feeds two MFMAs.  Per chunk of 8 input channels (64 MFMAs per wave) the raw 18x18-pixel
-// input patch is staged in LDS by LDS-DMA (no transformed copy exists anywhere; two 12 KB stages) and the filter operands go
-// from L2 straight into registers (each wave needs only its row's positions: the four waves read each slab byte once).
+// Workgroup = 256 threads = 4 waves, one per SIMD: 32 tiles (8 x 4 tiles of 2x4 = 16x16 output pixels) x 64 output
+// channels x the 24 Winograd positions.  Wave a owns ROW a of the 4x6 position grid for the 32 tiles and all 64 channels:
+// 6 positions x 2 channel blocks of 32x32 = 12 MFMA blocks = 192 accumulator registers.  A row of Bt4 d is one sum or
+// difference of two patch rows, then the 6-point column transform: 20 four-channel operations per chunk, and every
+// transformed value feeds two MFMAs.  Per chunk of 8 input channels (48 MFMAs per wave) the raw 18x18-pixel input patch is
+// staged in LDS by LDS-DMA (no transformed copy exists anywhere; two 12 KB stages) and the filter operands go from L2
+// straight into registers (each wave needs only its row's positions: the four waves read each slab byte once).
 // With one wave per SIMD every non-MFMA instruction costs issue time on top of the MFMA time (fp32 MFMA and the other pipes
-// do not overlap within a wave: measured), so the design minimises them: 27 memory instructions and ~70 VALU per 64 MFMAs.
-// The output transform reduces each wave's row over its 4 positions in registers, parks the row sums in LDS (128 KB) and
-// combines the four rows in the store pass.
+// do not overlap within a wave: measured), so the design minimises them: 27 memory instructions and 40 packed VALU per 48
+// MFMAs.  The output transform applies At4 to each wave's row in registers, parks the result in LDS (128 KB) and combines the
+// four rows (At2) in the store pass.
 //
-// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1 MB
+// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1.5 MB
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
 #include <mutex>
 

@@ -133,11 +133,11 @@ if os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
     lines += ["PMC counters per launch (separate `rocprofv3 --pmc` passes):", "", "| counter | mean per launch |", "|---|---|"]
     lines += ["| %s | %.6g |" % (k, v) for k, v in sorted(pm.items())]
     avg_ns = float(rows[0]["AverageNs"])
-    tiles, padded = 102144, 106880
+    tiles, padded = 19 * (48 * 42 + 24 * 21 + 12 * 11 + 6 * 6 + 3 * 3), 1689 * 32        # 2 x 4 output tiles of the bench launch
     fetch, write = 2 * pm.get("FETCH_SIZE", 0) * 1024, pm.get("WRITE_SIZE", 0) * 1024
     mfma_busy = pm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (pm.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024)
-    lines += ["", "Derived: executed MFMA FLOPs of the real tiles 2*16*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the 157.3 TFLOP/s fp32 MFMA peak;" % (
-                  tiles, 2 * 16 * tiles * 65536 / 1e9, 2 * 16 * tiles * 65536 / avg_ns / 1e3, 2 * 16 * tiles * 65536 / avg_ns / 1e3 / 157.3),
+    lines += ["", "Derived: executed MFMA FLOPs of the real 2x4 tiles 2*24*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the 157.3 TFLOP/s fp32 MFMA peak;" % (
+                  tiles, 2 * 24 * tiles * 65536 / 1e9, 2 * 24 * tiles * 65536 / avg_ns / 1e3, 2 * 24 * tiles * 65536 / avg_ns / 1e3 / 157.3),
               "matrix pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = %.2f (it also works on the %d padding tiles of partial 16x16 blocks);" % (mfma_busy, padded - tiles),
               "direct-convolution rate 2*9*pixels*256*256 / t = %.1f TFLOP/s.  HBM-side traffic (FETCH_SIZE x 2 on gfx950, KB units) %.2f GB read + %.2f GB written" % (
                   2 * 9 * 19 * 21486 * 65536 / avg_ns / 1e3, fetch / 1e9, write / 1e9),

@@ -29,6 +29,6 @@ ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / n
 direct = 2.0 * 9 * tab.pod_pixels * 256 * 256
-tiles = copies * sum(((h + 1) // 2) * ((w + 1) // 2) for h, w in levels)
+tiles = copies * sum(((h + 1) // 2) * ((w + 3) // 4) for h, w in levels)      # 2 x 4 output tiles
 print("wino %s x%d: %.3f ms/launch = %.1f TFLOP/s direct-equivalent, %.1f executed on the matrix cores (%d tiles, %d with block padding)" % (
-    mode, copies, ms, direct / ms / 1e9, 2.0 * 16 * tiles * 256 * 256 / ms / 1e9, tiles, tab.shape[0] * 64))
+    mode, copies, ms, direct / ms / 1e9, 2.0 * 24 * tiles * 256 * 256 / ms / 1e9, tiles, tab.shape[0] * 32))
