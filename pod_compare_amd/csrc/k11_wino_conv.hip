@@ -32,6 +32,7 @@
 // Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1.5 MB
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
 #include <mutex>
+#include <type_traits>
 
 #include "pod_device.h"
 
@@ -153,11 +154,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 3 + r) * 256), 16, roff[r], ch * 32, 0, 0);
     };
 
-    f32x16 acc[12];                                                      // [p][kb]
-#pragma unroll
-    for (int p = 0; p < 12; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
 
     f32x4 x[12], uA[12], uB[12], vA[6], vB[6], t[6], w6[4];              // x[row][c], u[p][kb], v[p]: 4 channels each
     auto read_piece = [&](const float* stage, int i) {                   // 12 pieces: one ds_read_b128 each
@@ -241,11 +238,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) transform_piece(vA, i);
     __syncthreads();                                   // every wave has read chunk 0's patch: its stage may be overwritten
-    auto chunk = [&](int ch, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12], const float* rd, float* wr) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](auto first, int ch, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12], const float* rd, float* wr) {
         const int c1 = ch + 1 < nchunk ? ch + 1 : last, c2 = ch + 2 < nchunk ? ch + 2 : last;
 #pragma unroll
         for (int j = 0; j < 48; ++j) {
-            WINO_MFMA(vC, uC, j);
+            if (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vC[j >> 1][0], uC[j][0], zero16, 0, 0, 0);
+            else WINO_MFMA(vC, uC, j);
             if (j < 12) read_piece(rd, j);
             else if (j < 24) filter_piece(c1, uN, j - 12);
             else if (j < 27) patch_piece(wr, c2, j - 24);
@@ -254,12 +253,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         }
         __syncthreads();                               // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
     };
-    int ch = 0;
+    chunk(std::true_type{}, 0, vA, uA, vB, uB, st1, st0);
+    int ch = 1;
     for (; ch + 1 < nchunk; ch += 2) {
-        chunk(ch, vA, uA, vB, uB, st1, st0);
-        chunk(ch + 1, vB, uB, vA, uA, st0, st1);
+        chunk(std::false_type{}, ch, vB, uB, vA, uA, st0, st1);
+        chunk(std::false_type{}, ch + 1, vA, uA, vB, uB, st1, st0);
     }
-    if (ch < nchunk) chunk(ch, vA, uA, vB, uB, st1, st0);
+    if (ch < nchunk) chunk(std::false_type{}, ch, vB, uB, vA, uA, st0, st1);
 #undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages: they become the output staging
 
