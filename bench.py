@@ -530,9 +530,13 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
 
     # ---- the kernel that owns the step: pod_wino_conv3x3 on the head trunk (HIP events per launch) ------------
     if not args.no_cnn and spec.get("members", 1) == 1 and modeling.WINO_HEAD:
-        out["roofline_head_conv"] = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
-        out["roofline"]["scope"] = ("dominant kernel of the post-processing chain K1..K7 (SURVEY 8d's merge + score, HBM-bound); by time the "
-                                    "step's dominant kernel is pod_wino_conv3x3 (the head's convolutions, ~90 % of the GPU time): roofline_head_conv")
+        # `roofline` is the step's dominant kernel by time (pod_wino_conv3x3: ~90 % of the GPU time, MFMA-bound); the dominant kernel of the
+        # post-processing chain K1..K7 (SURVEY 8d's merge + score, HBM-bound; `roofline` of round 1) is kept as `roofline_k1`
+        out["roofline_k1"] = out["roofline"]
+        out["roofline_k1"]["scope"] = "dominant kernel of the post-processing chain K1..K7 (SURVEY 8d's merge + score)"
+        out["roofline"] = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
+        out["roofline"]["scope"] = "dominant kernel of the step by time (the head's convolutions); K1's roofline: roofline_k1"
+        out["roofline_head_conv"] = out["roofline"]
 
     # ---- the whole conv net of a step against the fp32 MFMA peak ---------------------------------------------
     if not args.no_cnn and spec.get("members", 1) == 1:

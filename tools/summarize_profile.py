@@ -112,7 +112,7 @@ if bench:
         l = d["line"]
         f = lambda x: "" if x is None else ("%.4g" % x)
         lines.append("| %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (d["file"], l.get("n_gpus"), f(l.get("value")), l.get("unit"), f(l.get("ms_per_step")),
-                     f(l.get("hot_path_ms_per_image")), f(l.get("hot_path_worst_ms")), f((l.get("roofline") or {}).get("frac")),
+                     f(l.get("hot_path_ms_per_image")), f(l.get("hot_path_worst_ms")), f((l.get("roofline_k1") or l.get("roofline") or {}).get("frac")),
                      f((l.get("conv_roofline") or {}).get("frac"))))
     lines.append("")
 # ---- pod_wino_conv3x3 (tools/profile_wino.sh <tag>w)
