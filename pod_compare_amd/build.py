@@ -16,10 +16,17 @@ SOURCES = ["k1_mc_merge_score.hip", "k2_topk_gather.hip", "k3_decode_cov.hip", "
 HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(CSRC, "pod_candidate.h"), os.path.join(os.path.dirname(HERE), "include", "pod_mi355x.h")]
 # -ffp-contract=off: the CPU reference rounds after every op; index parity needs the same fp32 values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
-if os.environ.get("POD_EXTRA_DEFINES"):     # experiments: e.g. POD_EXTRA_DEFINES="-DPOD_K1_WRITE_THROUGH"
-    FLAGS.extend(os.environ["POD_EXTRA_DEFINES"].split())
-if os.environ.get("POD_TRACE") == "1":      # diagnostics build: phase time stamps inside kernels (csrc/pod_device.h); use --force
-    FLAGS.append("-DPOD_TRACE")
+
+
+def _flags(tagged: bool):
+    """Experiment / diagnostics defines apply to TAGGED builds only: the shipped library is always the plain source.
+    POD_EXTRA_DEFINES="-DPOD_WINO_ELIM=3 ..."; POD_TRACE=1: phase time stamps inside kernels (csrc/pod_device.h, k11)."""
+    f = list(FLAGS)
+    if tagged and os.environ.get("POD_EXTRA_DEFINES"):
+        f.extend(os.environ["POD_EXTRA_DEFINES"].split())
+    if tagged and os.environ.get("POD_TRACE") == "1":
+        f.append("-DPOD_TRACE")
+    return f
 
 
 def _hipcc() -> str:
@@ -36,24 +43,37 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, tag: str = "") -> str:
+    """tag (or env POD_BUILD_TAG): an experiment / diagnostics build kept beside the shipped one in lib/<tag>/ (load it with
+    POD_MI355X_LIB=pod_compare_amd/lib/<tag>/libpod_mi355x.so); the shipped library is only ever built without a tag.
+    POD_TAG_SOURCES="k11_wino_conv.hip ..." limits what a tagged build recompiles (with its extra defines); the other
+    objects are the shipped ones."""
+    tag = "" if tag == "__shipped__" else (tag or os.environ.get("POD_BUILD_TAG", ""))
+    libdir = os.path.join(LIBDIR, tag) if tag else LIBDIR
+    lib = os.path.join(libdir, "libpod_mi355x.so")
+    os.makedirs(libdir, exist_ok=True)
+    only = os.environ.get("POD_TAG_SOURCES", "").split() if tag else []
+    if only:
+        build_library(verbose=verbose, tag="__shipped__")
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(libdir if (not only or src in only) else LIBDIR, src.replace(".hip", ".o"))
+        if only and src not in only:
+            objs.append(o)
+            continue
         if force or _stale(o, [s] + HEADERS):
-            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+            cmd = [_hipcc()] + _flags(bool(tag)) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

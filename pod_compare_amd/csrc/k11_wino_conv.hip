@@ -49,6 +49,27 @@ constexpr int WINO_R_SLOTS = 18 * 20;                    // 16-byte slots of one
 constexpr int WINO_STAGE_FLOATS = 12 * 64 * 4;           // raw patch stage: [h][row 18][parity 2][col/2: 9 (+1 pad)][4]: 720 slots, 12 KB
 constexpr int WINO_LDS_BYTES = 4 * 32 * 4 * 65 * 4;      // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
 
+// -DPOD_TRACE (diagnostics build, tools/wino_trace.py): s_memtime stamps of every workgroup's phases
+#ifdef POD_TRACE
+__device__ long long g_wino_trace[8192 * 8];
+#define WINO_STAMP(k)                                                                                          \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define WINO_STAMP(k)
+#endif
+
+// -DPOD_WINO_ELIM=<bits> (tagged experiment builds only, tools/wino_elim.sh): parts of the kernel compiled out to price them --
+// results are then wrong, only the time is of interest.  1 patch reads, 2 filter loads, 4 patch DMA, 8 input transform,
+// 16 chunk barrier, 32 store pass, 64 dropout mask, 128 accumulator dump + store pass.
+#ifndef POD_WINO_ELIM
+#define POD_WINO_ELIM 0
+#endif
+#ifndef POD_WINO_VAR
+#define POD_WINO_VAR 0
+#endif
+
 struct WinoParams {
     const float* in;
     float* out;
@@ -109,6 +130,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // with Wv = W + 1 rounded up to a multiple of 4 (tiles are 4 pixels wide): the spare columns are the zero padding between
     // neighbours (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- a partial block at the
     // right edge is paid once per level instead of once per image.
+    WINO_STAMP(0);
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int H = desc.z >> 16, W = desc.z & 0xFFFF, n_img = (desc.w >> 24) & 0xFF;
@@ -157,6 +179,12 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
 
     f32x4 x[12], uA[12], uB[12], vA[6], vB[6], t[6], w6[4];              // x[row][c], u[p][kb], v[p]: 4 channels each
+#if POD_WINO_ELIM
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = uA[i] = uB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vA[i] = vB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane - i);
+#endif
     auto read_piece = [&](const float* stage, int i) {                   // 12 pieces: one ds_read_b128 each
         const int row = i / 6, c = i % 6;
         x[i] = *reinterpret_cast<const f32x4*>(stage + (row ? a_r1 : a_r0) + ((c & 1) * 10 + (c >> 1)) * 4);
@@ -233,11 +261,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
     __syncthreads();
+    WINO_STAMP(1);
 #pragma unroll
     for (int i = 0; i < 12; ++i) read_piece(st0, i);
 #pragma unroll
     for (int i = 0; i < 10; ++i) transform_piece(vA, i);
     __syncthreads();                                   // every wave has read chunk 0's patch: its stage may be overwritten
+    WINO_STAMP(2);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto chunk = [&](auto first, int ch, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12], const float* rd, float* wr) {
         const int c1 = ch + 1 < nchunk ? ch + 1 : last, c2 = ch + 2 < nchunk ? ch + 2 : last;
@@ -245,13 +275,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int j = 0; j < 48; ++j) {
             if (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vC[j >> 1][0], uC[j][0], zero16, 0, 0, 0);
             else WINO_MFMA(vC, uC, j);
-            if (j < 12) read_piece(rd, j);
-            else if (j < 24) filter_piece(c1, uN, j - 12);
-            else if (j < 27) patch_piece(wr, c2, j - 24);
-            else if (j >= 28 && j < 38) transform_piece(vN, j - 28);
+            constexpr int D0 = (POD_WINO_VAR & 1) ? 0 : 24, R0 = (POD_WINO_VAR & 1) ? 3 : 0, F0 = (POD_WINO_VAR & 1) ? 15 : 12;
+            if (j >= R0 && j < R0 + 12) { if (!(POD_WINO_ELIM & 1)) read_piece(rd, j - R0); }
+            else if (j >= F0 && j < F0 + 12) { if (!(POD_WINO_ELIM & 2)) filter_piece(c1, uN, j - F0); }
+            else if (j >= D0 && j < D0 + 3) { if (!(POD_WINO_ELIM & 4)) patch_piece(wr, c2, j - D0); }
+            else if (j >= 28 && j < 38) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 28); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                               // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
+        if (!(POD_WINO_ELIM & 16)) __syncthreads();    // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
     };
     chunk(std::true_type{}, 0, vA, uA, vB, uB, st1, st0);
     int ch = 1;
@@ -262,11 +293,17 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     if (ch < nchunk) chunk(std::false_type{}, ch, vB, uB, vA, uA, st0, st1);
 #undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages: they become the output staging
+    WINO_STAMP(3);
 
     // ---- output transform Y = At2 M At4^T, At2 = [[1,1,1,0],[0,1,-1,-1]], At4 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].
     // Lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5), column (channel) = lane & 31.  Every wave applies At4 to its
     // row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS (128 KB); the store pass
     // combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],  Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
+#if POD_WINO_ELIM & 128
+#pragma unroll
+    for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
+    return;
+#endif
     const int LD = P.k_planes > 0 ? 65 : 64;   // one (tile, column) line of the staging: 16-byte reads along k (64) or scalar reads, bank-spread (65)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -283,6 +320,10 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             o[3 * LD] = fmaf(8.0f, d2, d1) + m5;
         }
     __syncthreads();
+    WINO_STAMP(4);
+#if POD_WINO_ELIM & 32
+    return;
+#endif
     const int ZA = 32 * 4 * LD;                // floats per position row a
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
@@ -340,7 +381,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             const int64_t e = (col_px + (int64_t)gy * W) * P.out_stride + kg;
-            if (P.thresh) {
+            if (P.thresh && !(POD_WINO_ELIM & 64)) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
                                                (uint32_t)(P.seed >> 32));
@@ -352,9 +393,29 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             *reinterpret_cast<f32x4*>(P.out + e) = v;
         }
     }
+#ifdef POD_TRACE
+    __builtin_amdgcn_s_waitcnt(0);                      // the stores have left
+    WINO_STAMP(5);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wino_trace[blockIdx.x * 8 + 6] = ((long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 }  // namespace pod
+
+#ifdef POD_TRACE
+extern "C" int pod_wino_trace_dump(long long* host, int32_t n_workgroups) {   // diagnostics build only (not in include/pod_mi355x.h)
+    if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
+    if (n_workgroups > 8192) n_workgroups = 8192;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pod::g_wino_trace), (size_t)n_workgroups * 8 * sizeof(long long)) != hipSuccess) return POD_E_LAUNCH;
+    return POD_OK;
+}
+#endif
 
 extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream) {
     if (!weight || !U || K < 1 || C < 8 || (C & 7) != 0) return POD_E_INVALID;
