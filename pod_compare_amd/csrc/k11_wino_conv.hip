@@ -33,6 +33,7 @@
 // for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "pod_device.h"
 
@@ -45,16 +46,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k8_model_ops.hip: same mask as pod_bias_act
 
 constexpr int WINO_U_FLOATS = 24 * 2 * 64 * 4;          // filter slab of a chunk: [24 positions][h][j][4 channels]  48 KB
-constexpr int WINO_R_SLOTS = 18 * 20;                    // 16-byte slots of one channel-half plane of the raw patch
-constexpr int WINO_STAGE_FLOATS = 12 * 64 * 4;           // raw patch stage: [h][row 18][parity 2][col/2: 9 (+1 pad)][4]: 720 slots, 12 KB
+constexpr int WINO_SB_FLOATS = 384 * 32;                 // raw patch stage of a SUPER-CHUNK (32 input channels): [pixel slot 360 (+24: 48 whole DMA instructions)][8 parts of 16 B], 48 KB
 constexpr int WINO_LDS_BYTES = 4 * 32 * 4 * 65 * 4;      // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
 
 // -DPOD_TRACE (diagnostics build, tools/wino_trace.py): s_memtime stamps of every workgroup's phases
 #ifdef POD_TRACE
-__device__ long long g_wino_trace[8192 * 8];
+__device__ long long g_wino_trace[8192 * 16];
 #define WINO_STAMP(k)                                                                                          \
     do {                                                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define WINO_STAMP(k)
@@ -69,6 +69,9 @@ __device__ long long g_wino_trace[8192 * 8];
 #ifndef POD_WINO_VAR
 #define POD_WINO_VAR 0
 #endif
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14): lgkmcnt(0) with vmcnt(4) / vmcnt(0)
+constexpr int WINO_WAIT_VM4 = 0x0074, WINO_WAIT_VM0 = 0x0070, WINO_WAIT_VM16 = 0x4070, WINO_WAIT_LGKM0 = 0xC07F;
 
 struct WinoParams {
     const float* in;
@@ -119,6 +122,26 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
     }
 }
 
+// What lane l3 = pixel slot, q = sub-slot of an LDS-DMA instruction fetches (see the layout in the kernel): per pixel slot 0..383
+// (py 18 + px) | rot << 16 (pixel 324: the slot holds no pixel), computed at compile time.
+struct WinoSlotTable {
+    uint32_t v[384];
+    constexpr WinoSlotTable() : v() {
+        for (int p = 0; p < 384; ++p) {
+            const int cls = p & 1, k = p >> 1, rr = k / 18, px = k - rr * 18;
+            const int py = cls ? (rr < 4 ? rr + 4 : rr + 8) : (rr < 4 ? rr : rr < 8 ? rr + 4 : rr + 8);
+            const bool ok = cls ? rr < 8 : rr < 10;
+            v[p] = ok ? (uint32_t)((py * 18 + px) | ((((px >> 2) & 3) + 4 * ((py >> 1) & 1)) << 16)) : 324u;
+        }
+    }
+};
+__device__ const WinoSlotTable g_wino_slots{};
+
+template <typename F, int... Js>
+__device__ __forceinline__ void wino_static_for(F&& f, std::integer_sequence<int, Js...>) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,15 +149,33 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int ks = xcd % P.KS;
     const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
     if (tb >= P.n_blocks) return;
-    // block record: the images of a (level, launch) stand SIDE BY SIDE on a virtual canvas, image n at columns n*Wv .. n*Wv+W-1
-    // with Wv = W + 1 rounded up to a multiple of 4 (tiles are 4 pixels wide): the spare columns are the zero padding between
-    // neighbours (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- a partial block at the
-    // right edge is paid once per level instead of once per image.
+    // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
+    // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
+    // both (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- the
+    // partial blocks at the right and bottom edges are paid once per level instead of once per image.
     WINO_STAMP(0);
+    uint32_t slot_e[12];                                                  // this lane's 12 pixel slots of a stage fill (constant table: asked for first, so
+#pragma unroll                                                            // that nothing queues behind the patch loads that follow)
+    for (int i = 0; i < 12; ++i) slot_e[i] = g_wino_slots.v[96 * (tid >> 6) + 8 * i + ((tid & 63) >> 3)];
+    int mini_pidx[3];                                                     // ... and the patch pixel of its 3 slots of a mini-stage fill (324: none)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int pp = (((tid >> 6) * 3 + r) * 64 + (tid & 63)) >> 1, py = pp / 21, pi = pp - py * 21, px = 4 * (pi % 5) + pi / 5;
+        mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
+    }
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
-    const int H = desc.z >> 16, W = desc.z & 0xFFFF, n_img = (desc.w >> 24) & 0xFF;
-    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = (W + 4) & ~3, HWi = H * W;
+    const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
+    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = W + 1, Hv = H + 1, HWi = H * W;
+    const float rWv = 1.0f / (float)Wv, rHv = 1.0f / (float)Hv;
+    // canvas coordinate v >= 0 -> (grid index, coordinate inside the cell); canvas extents < 2^16: exact after the fix-up
+    auto cell = [](int v, int step, float rstep, int& idx) {
+        int n = (int)((float)v * rstep);
+        n -= n * step > v ? 1 : 0;
+        n += (n + 1) * step <= v ? 1 : 0;
+        idx = n;
+        return v - n * step;
+    };
     const int nchunk = P.C >> 3;
 
     // ---- operands.  Tiles are 2 rows x 4 columns of outputs (F(2,3) down the rows: 4 patch rows; F(4,3) along the columns: 6
@@ -154,26 +195,75 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int a = __builtin_amdgcn_readfirstlane(wave);
     const int row0 = a == 0 ? 0 : a == 2 ? 2 : 1, row1 = a == 2 ? 1 : a == 3 ? 3 : 2;
     const float sgn = a == 1 ? 1.0f : -1.0f;
-    const int a_base = (h * WINO_R_SLOTS + 2 * (i32 >> 2) * 20 + 2 * (i32 & 3)) * 4;  // tile (i32>>2, i32&3): patch row 2 ty, column 4 tx
-    const int a_r0 = a_base + row0 * 80, a_r1 = a_base + row1 * 80;                     // + ((c&1)*10 + (c>>1))*4, c = 0..5
+    // Patch in LDS, one stage per SUPER-CHUNK of 32 input channels = the 128-byte line a pixel owns in the channels-last source:
+    // [pixel slot][8 parts of 16 B], so that 8 consecutive lanes of an LDS-DMA instruction fetch ONE full line (measured,
+    // tools/mfma_fillers.hip: a pixel per lane -- 64 lines per instruction, each line fetched again by the next three 8-channel
+    // chunks -- stalls the in-order instruction streams by ~400 cycles per chunk once the lines come from HBM; full lines cost 55).
+    // Pixel slot of patch pixel (py, px): 2 (rank(py) 18 + px) + ((py >> 2) & 1), rank = (py & 3) + 4 (py >> 3) (rows 0-3, 8-11, 16, 17
+    // on the even slots, rows 4-7, 12-15 on the odd ones); part P of that pixel sits at sub-slot (P + rot) & 7,
+    // rot = ((px >> 2) & 3) + 4 ((py >> 1) & 1): the 16 lanes a ds_read_b128 serves per LDS cycle (4 tile rows x 4 tile columns,
+    // one part) then hit 16 different 16-byte bank groups -- conflict-free for every (row, column, chunk).
+    const int ty = i32 >> 2, tx = i32 & 3;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    uint32_t areg[2][2][4];                                               // LDS byte address in stage 0: [row0 / row1][columns 0-3 / 4-5][chunk of the super-chunk]
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+        const int py = 2 * ty + (rs ? row1 : row0);
+        const int p0 = 2 * (((py & 3) + 4 * (py >> 3)) * 18 + 4 * tx) + ((py >> 2) & 1);   // slot of column 0 of the tile; column c: + 2 c
+#pragma unroll
+        for (int cl = 0; cl < 2; ++cl) {
+            const int rot = ((tx + cl) & 3) + 4 * ((py >> 1) & 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) areg[rs][cl][c] = lds_base + p0 * 128 + ((2 * c + h + rot) & 7) * 16;
+        }
+    }
+    uint32_t amini[2];                                                    // LDS byte address in mini stage 0: [row0 / row1]; column c: + ((c & 3) 5 + (c >> 2)) 32
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32 + h * 16;
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
                                                           nchunk * WINO_U_FLOATS * 4, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
                                                           n_img * HWi * P.in_stride * 4, 0x00020000);
     const int u_off = ((a * 6 * 2 + h) * 64 + i32) * 16;                               // + (p*2*64 + kb*32)*16 bytes, + chunk*48 KB
-    int roff[3];                                                                       // this lane's three patch slots
+    // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
+    // (grid row, row inside the image), canvas column -> (grid column, column) -- and parks its pixel index (-1: outside every image:
+    // the loads then use a buffer offset that reads 0.0) in LDS; the lanes look their pieces up there: two divisions per thread
+    // instead of two per lane and piece.
+    int* pix_tab = reinterpret_cast<int*>(lds + 2 * WINO_SB_FLOATS + 2 * 3072);       // 324 ints behind the mini stages
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int slot = (a * 3 + r) * 64 + lane;
-        const int hh = slot >= WINO_R_SLOTS ? 1 : 0, rem = slot - hh * WINO_R_SLOTS, py = rem / 20, q = rem - py * 20;
-        const int px = 2 * (q >= 10 ? q - 10 : q) + (q >= 10 ? 1 : 0);
-        const int gy = y0 - 1 + py, vx = x0 - 1 + px, n = vx >= 0 ? vx / Wv : 0, gx = vx - n * Wv;
-        const bool ok = slot < 2 * WINO_R_SLOTS && q != 9 && q != 19 && gy >= 0 && gy < H && vx >= 0 && n < n_img && gx < W;
-        roff[r] = ok ? ((n * HWi + gy * W + gx) * P.in_stride + 4 * hh) * 4 : 0x7FFFFF00;
+    for (int t = tid; t < 325; t += 256) {
+        const int py = t / 18, px = t - py * 18, vy = y0 - 1 + py, vx = x0 - 1 + px;
+        int m, n;
+        const int gy = cell(vy < 0 ? 0 : vy, Hv, rHv, m), gx = cell(vx < 0 ? 0 : vx, Wv, rWv, n), img = m * gcols + n;
+        const bool ok = (t < 324) & (vy >= 0) & (gy < H) & (vx >= 0) & (gx < W) & (n < gcols) & (img < n_img);
+        pix_tab[t] = ok ? img * HWi + gy * W + gx : -1;              // entry 324 = -1: the "no pixel" slots of the fills point here
     }
+    __syncthreads();
+    auto byte_offset = [&](int pix, int part4) { return pix >= 0 ? (pix * P.in_stride + part4) * 4 : 0x7FFFFF00; };
+    // The first two chunks come from two MINI stages (8 channels each, 324 pixels x 32 B, 3 LDS-DMA instructions per wave each), so the
+    // matrix cores start after 20 KB have landed instead of a 48 KB super-chunk; super-chunk 0 lands behind the first chunk's MFMAs.
+    // Mini layout: 16-byte slot 2 (py 21 + (px & 3) 5 + (px >> 2)) + h: the 16 lanes of a ds_read_b128 group hit every bank group twice.
+    WINO_STAMP(8);                                     // (the block record has arrived, the pixel table stands)
+    int dmini[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dmini[r] = pix_tab[mini_pidx[r]];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dmini[r] = byte_offset(dmini[r], 4 * (lane & 1));
+    // LDS-DMA of a stage: 48 instructions of 8 pixel slots x 8 parts (the last 3 fetch nothing), wave a issues 12 a .. 12 a + 11.  Lane
+    // (l3 = lane >> 3, q = lane & 7) of instruction I fills sub-slot q of pixel slot 8 I + l3 with part (q - rot) & 7 of its pixel.
+    int doff[12];
+    auto main_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) doff[i] = pix_tab[slot_e[i] & 0xFFFF];                  // 12 independent LDS reads, one round trip
+#pragma unroll
+        for (int i = 0; i < 12; ++i) doff[i] = byte_offset(doff[i], 4 * (((lane & 7) - (int)(slot_e[i] >> 16)) & 7));
+    };
     typedef __attribute__((address_space(3))) void lds_void;
-    auto patch_piece = [&](float* stage, int ch, int r) {    // 1 KB of the patch of chunk ch, straight into LDS
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 3 + r) * 256), 16, roff[r], ch * 32, 0, 0);
+    auto mini_piece = [&](int which, int r) {                // 1 KB of the 8-channel patch of chunk `which` (0 / 1) into its mini stage
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(lds + 2 * WINO_SB_FLOATS + which * 3072 + (a * 3 + r) * 256), 16, dmini[r], which * 32, 0, 0);
+    };
+    auto patch_piece = [&](float* stage, int sc, int i) {    // 1 KB (8 pixels x 32 channels) of super-chunk sc, straight into LDS
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 12 + i) * 256), 16, doff[i], sc * 128, 0, 0);
     };
 
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
@@ -185,10 +275,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) vA[i] = vB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane - i);
 #endif
-    auto read_piece = [&](const float* stage, int i) {                   // 12 pieces: one ds_read_b128 each
-        const int row = i / 6, c = i % 6;
-        x[i] = *reinterpret_cast<const f32x4*>(stage + (row ? a_r1 : a_r0) + ((c & 1) * 10 + (c >> 1)) * 4);
-    };
+    // 12 pieces: one ds_read_b128 each, stage par, chunk c of its super-chunk.  Issued as asm: hipcc orders every LDS read it can
+    // see behind ALL pending LDS-DMA (vmcnt(0): it cannot tell the two stages apart), which would drain the pieces flying into the
+    // other stage; so the reads are hidden from it and their completion is counted by hand (WINO_WAIT_LGKM0 before the transform).
+#define WINO_READ(par, c, i)                                                                                                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(areg[(i) / 6][((i) % 6) >> 2][c]), "i"((par) * WINO_SB_FLOATS * 4 + ((i) % 6) * 256))
+#define WINO_READ_MINI(which, i)                                                                                                     \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(amini[(i) / 6]), "i"((which) * 12288 + ((((i) % 6) & 3) * 5 + (((i) % 6) >> 2)) * 32))
     auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
         u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
     };
@@ -244,55 +337,91 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         }
     };
 
-    // One chunk = 48 MFMAs (k-step j / 12 = channel of the lane's four, accumulator j % 12 = (p, kb)) with the next chunk's work
-    // slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four waves of the
-    // workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the in-order
-    // instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and the LDS-DMA of
-    // the patch of chunk ch+2 into the stage chunk ch was read from.  Two stages; one barrier per chunk.
+    // One chunk = 8 input channels = 48 MFMAs (k-step j / 12 = channel of the lane's four, accumulator j % 12 = (p, kb)) with the next
+    // chunk's work slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four waves
+    // of the workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the in-order
+    // instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and a quarter of the
+    // LDS-DMA of a later SUPER-CHUNK (4 chunks, two stages).  Chunk c of super-chunk s reads stage s & 1 (c = 3: the first chunk of
+    // s + 1 from the other stage).  Super-chunk s + 1 is fetched into the stage s - 1 left behind, 4 instructions per wave during
+    // each of the chunks (s-1, 3), (s, 0), (s, 1) -- every piece has a whole chunk to land before the barrier that publishes it.
 #define WINO_MFMA(V, U, j)                                                                                                   \
     acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((j) % 12) >> 1][(j) / 12], U[(j) % 12][(j) / 12], acc[(j) % 12], 0, 0, 0)
-    float* st0 = lds;
-    float* st1 = lds + WINO_STAGE_FLOATS;
-    const int last = nchunk - 1;
+    const int last = nchunk - 1, last_s = last >> 2;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) patch_piece(st0, 0, r);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) patch_piece(st1, last < 1 ? last : 1, r);
+    for (int r = 0; r < 3; ++r) mini_piece(0, r);
 #pragma unroll
     for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
-    __syncthreads();
-    WINO_STAMP(1);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) read_piece(st0, i);
+    for (int r = 0; r < 3; ++r) mini_piece(last < 1 ? 0 : 1, r);
+    WINO_STAMP(9);
+    main_offsets();                                    // (behind the first loads: their latency hides it)
+    WINO_STAMP(10);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) patch_piece(lds, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) patch_piece(lds + WINO_SB_FLOATS, last_s < 1 ? last_s : 1, i);
+    WINO_STAMP(11);
+    __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM16);        // the mini stages and the filters of chunk 0 have landed; the 16 pieces of the stages fly on
+    __builtin_amdgcn_s_barrier();
+    WINO_STAMP(1);
+    WINO_READ_MINI(0, 0); WINO_READ_MINI(0, 1); WINO_READ_MINI(0, 2); WINO_READ_MINI(0, 3); WINO_READ_MINI(0, 4); WINO_READ_MINI(0, 5);
+    WINO_READ_MINI(0, 6); WINO_READ_MINI(0, 7); WINO_READ_MINI(0, 8); WINO_READ_MINI(0, 9); WINO_READ_MINI(0, 10); WINO_READ_MINI(0, 11);
+    __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef POD_WINO_DEBUG_X
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(P.out + (tid * 12 + i) * 4) = x[i];
+    }
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 10; ++i) transform_piece(vA, i);
-    __syncthreads();                                   // every wave has read chunk 0's patch: its stage may be overwritten
+    // the transform's packed instructions are asm: hipcc neither pads the VALU-write -> MFMA-operand hazard behind them nor keeps the
+    // first MFMA from being scheduled up among them (it reads a stale operand then: measured) -- fence and pad by hand
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
     WINO_STAMP(2);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto chunk = [&](auto first, int ch, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12], const float* rd, float* wr) {
-        const int c1 = ch + 1 < nchunk ? ch + 1 : last, c2 = ch + 2 < nchunk ? ch + 2 : last;
-#pragma unroll
-        for (int j = 0; j < 48; ++j) {
-            if (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vC[j >> 1][0], uC[j][0], zero16, 0, 0, 0);
+    auto chunk = [&](auto first, auto c_t, auto par_t, int sc, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12]) {
+        constexpr int c = decltype(c_t)::value, par = decltype(par_t)::value;
+        constexpr int rc = (c + 1) & 3, rpar = c == 3 ? par ^ 1 : par;            // what the reads fetch: the NEXT chunk's patch
+        constexpr int ph = c == 3 ? 0 : c + 1, dpar = c == 3 ? par : par ^ 1;     // fill phase (c == 2: none) and the stage being filled
+        const int ch = 4 * sc + c, c1 = ch + 1 < nchunk ? ch + 1 : last;
+        const int fs0 = c == 3 ? sc + 2 : sc + 1, fs = fs0 < last_s ? fs0 : last_s;
+        float* wr = lds + dpar * WINO_SB_FLOATS;
+        wino_static_for([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vC[j >> 1][0], uC[j][0], zero16, 0, 0, 0);
             else WINO_MFMA(vC, uC, j);
-            constexpr int D0 = (POD_WINO_VAR & 1) ? 0 : 24, R0 = (POD_WINO_VAR & 1) ? 3 : 0, F0 = (POD_WINO_VAR & 1) ? 15 : 12;
-            if (j >= R0 && j < R0 + 12) { if (!(POD_WINO_ELIM & 1)) read_piece(rd, j - R0); }
-            else if (j >= F0 && j < F0 + 12) { if (!(POD_WINO_ELIM & 2)) filter_piece(c1, uN, j - F0); }
-            else if (j >= D0 && j < D0 + 3) { if (!(POD_WINO_ELIM & 4)) patch_piece(wr, c2, j - D0); }
-            else if (j >= 28 && j < 38) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 28); }
+            if constexpr (j < 12) {
+                if constexpr (decltype(first)::value) WINO_READ_MINI(1, j);                  // chunk 1's patch: the second mini stage
+                else if (!(POD_WINO_ELIM & 1)) WINO_READ(rpar, rc, j);
+            }
+            else if constexpr (j < 24) { if (!(POD_WINO_ELIM & 2)) filter_piece(c1, uN, j - 12); }
+            else if constexpr (j < 28) { if (c != 2 && !(POD_WINO_ELIM & 4)) patch_piece(wr, fs, 4 * ph + j - 24); }
+            else if constexpr (j == 28) __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);         // the 12 reads (issued 16+ MFMAs ago)
+            else if constexpr (j >= 29 && j < 39) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 29); }
             __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, 48>{});
+        if (!(POD_WINO_ELIM & 16)) {
+            // the filters of the next chunk and every patch piece issued before this chunk have landed; this chunk's 4 pieces may fly on
+            __builtin_amdgcn_s_waitcnt(c != 2 && !(POD_WINO_VAR & 2) ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
+            __builtin_amdgcn_s_barrier();
         }
-        if (!(POD_WINO_ELIM & 16)) __syncthreads();    // (vmcnt(0) + lgkmcnt(0): the DMA has landed, nothing pending at the header)
     };
-    chunk(std::true_type{}, 0, vA, uA, vB, uB, st1, st0);
-    int ch = 1;
-    for (; ch + 1 < nchunk; ch += 2) {
-        chunk(std::false_type{}, ch, vB, uB, vA, uA, st0, st1);
-        chunk(std::false_type{}, ch + 1, vA, uA, vB, uB, st1, st0);
+    using std::integral_constant;
+    chunk(std::true_type{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, 0, vA, uA, vB, uB);
+    for (int base = 0;; base += 8) {
+#define WINO_CHUNK(t)                                                                                                              \
+    if (base + (t) >= nchunk) break;                                                                                               \
+    if ((t) & 1) chunk(std::false_type{}, integral_constant<int, (t) & 3>{}, integral_constant<int, ((t) >> 2) & 1>{}, (base + (t)) >> 2, vB, uB, vA, uA); \
+    else chunk(std::false_type{}, integral_constant<int, (t) & 3>{}, integral_constant<int, ((t) >> 2) & 1>{}, (base + (t)) >> 2, vA, uA, vB, uB);
+        WINO_CHUNK(1) WINO_CHUNK(2) WINO_CHUNK(3) WINO_CHUNK(4) WINO_CHUNK(5) WINO_CHUNK(6) WINO_CHUNK(7) WINO_CHUNK(8)
+#undef WINO_CHUNK
     }
-    if (ch < nchunk) chunk(std::false_type{}, ch, vB, uB, vA, uA, st0, st1);
 #undef WINO_MFMA
-    __syncthreads();                                   // every wave is done reading the stages: they become the output staging
+    __syncthreads();                                   // every wave is done reading the stages, no DMA in flight: they become the output staging
     WINO_STAMP(3);
 
     // ---- output transform Y = At2 M At4^T, At2 = [[1,1,1,0],[0,1,-1,-1]], At4 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].
@@ -327,12 +456,15 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int ZA = 32 * 4 * LD;                // floats per position row a
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
-        const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4, gy = y0 + oy;
+        const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
+        int m;
+        const int gy = cell(y0 + oy, Hv, rHv, m);
         int64_t px0[4];                                   // output pixel (of plane 0) per column, -1: not a pixel of any image
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int vx = x0 + ox + e, n = vx / Wv, gx = vx - n * Wv;
-            px0[e] = (n < n_img && gx < W && gy < H) ? (out_px + (int64_t)n * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
+            int n;
+            const int gx = cell(x0 + ox + e, Wv, rWv, n), img = m * gcols + n;
+            px0[e] = (n < gcols && img < n_img && gx < W && gy < H) ? (out_px + (int64_t)img * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
         }
         const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (HWi & 3) == 0;
         const int tile = (oy >> 1) * 4 + (tid & 3);
@@ -365,13 +497,19 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         const int k4 = (tid & 15) * 4, kg = ks * 64 + k4;
         f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
         if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + kg);
-        const int ox = tid >> 4, vx = x0 + ox, n = vx / Wv, gx = vx - n * Wv;        // this thread's column of the block
-        const bool col_ok = n < n_img && gx < W;
-        const int64_t col_px = out_px + (int64_t)n * HWi + gx;
+        const int ox = tid >> 4;                                                      // this thread's column of the block
+        int n;
+        const int gx = cell(x0 + ox, Wv, rWv, n);
+        const bool col_ok = n < gcols && gx < W;
+        int m, gy = cell(y0, Hv, rHv, m) - 1;                                        // canvas row y0 + oy: grid row m, image row gy (H: the separator)
 #pragma unroll 4
         for (int oy = 0; oy < 16; ++oy) {
-            const int gy = y0 + oy;
-            if (!col_ok || gy >= H) continue;
+            if (++gy == Hv) {
+                gy = 0;
+                ++m;
+            }
+            const int img = m * gcols + n;
+            if (!col_ok || gy >= H || img >= n_img) continue;
             const float* r = lds + (((oy >> 1) * 4 + (ox >> 2)) * 4 + (ox & 3)) * 64 + k4;      // Z[a][tile][ox & 3][k4] at + a * ZA
             const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? ZA : 0));
             const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 2 * ZA : ZA));
@@ -380,7 +518,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            const int64_t e = (col_px + (int64_t)gy * W) * P.out_stride + kg;
+            const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
@@ -401,7 +539,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_wino_trace[blockIdx.x * 8 + 6] = ((long long)xcc << 32) | hw;
+        g_wino_trace[blockIdx.x * 16 + 6] = ((long long)xcc << 32) | hw;
     }
 #endif
 }
@@ -412,7 +550,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 extern "C" int pod_wino_trace_dump(long long* host, int32_t n_workgroups) {   // diagnostics build only (not in include/pod_mi355x.h)
     if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
     if (n_workgroups > 8192) n_workgroups = 8192;
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pod::g_wino_trace), (size_t)n_workgroups * 8 * sizeof(long long)) != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pod::g_wino_trace), (size_t)n_workgroups * 16 * sizeof(long long)) != hipSuccess) return POD_E_LAUNCH;
     return POD_OK;
 }
 #endif

@@ -20,15 +20,42 @@ def level_pixel_offsets(levels: Sequence[Tuple[int, int]], copies: int) -> List[
 _TABLES = {}
 
 
+def canvas_layout(h: int, w: int, n: int) -> Tuple[int, int, List[Tuple[int, int]]]:
+    """Grid (rows, cols) of a canvas holding n images of h x w -- image i at grid cell (i // cols, i % cols), top-left canvas pixel
+    (row * (h + 1), col * (w + 1)): ONE zero row / column between neighbours, the convolution's padding for both -- that needs the
+    fewest 16x16 blocks, and the (block_row, block_col) list of the blocks that hold at least one image pixel."""
+    best = None
+    for rows in range(1, n + 1):
+        cols = -(-n // rows)
+        if (rows - 1) * cols >= n:                              # an empty grid row
+            continue
+        by, bx = (rows * (h + 1) - 1 + 15) // 16, (cols * (w + 1) - 1 + 15) // 16
+        blocks = []
+        for r in range(by):
+            m0, m1 = (16 * r) // (h + 1), min((16 * r + 15) // (h + 1), rows - 1)
+            if m0 == m1 and 16 * r - m0 * (h + 1) >= h:        # the block row lies on a separator row only
+                continue
+            for c in range(bx):
+                n0, n1 = (16 * c) // (w + 1), min((16 * c + 15) // (w + 1), cols - 1)
+                if n0 == n1 and 16 * c - n0 * (w + 1) >= w:
+                    continue
+                if m0 * cols + n0 < n:                           # the first cell the block touches holds an image (cells fill row-major)
+                    blocks.append((r, c))
+                elif any(m * cols + k < n for m in range(m0, m1 + 1) for k in range(n0, n1 + 1)):
+                    blocks.append((r, c))
+        if best is None or len(blocks) < len(best[2]):
+            best = (rows, cols, blocks)
+    return best
+
+
 def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copies: Optional[int] = None, in_first: int = 0,
                 out_copies: Optional[int] = None) -> torch.Tensor:
-    """int32 (n_blocks, 4) records of pod_wino_conv3x3: {first pixel of image 0 in the input buffer, in the output buffer,
-    H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS: the `copies` images of a level
-    stand side by side, image n at canvas columns n*Wv .. n*Wv+W-1 with Wv = W + 1 rounded up to a multiple of 4 (the spare columns are
-    the zero padding between neighbours), so a partial block at the right edge is paid once per level, not once per image -- where that
-    saves blocks; otherwise every image is its own canvas.  The input
-    buffer holds `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read; the output
-    buffer holds `out_copies` per level and images 0 .. copies - 1 are written."""
+    """int32 (n_blocks, 4) records of pod_wino_conv3x3 (include/pod_mi355x.h): {first pixel of image 0 in the input buffer, in the
+    output buffer, grid_cols << 24 | H << 12 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a
+    CANVAS on which the `copies` images of a level stand in a grid, one zero row / column apart (`canvas_layout`): partial blocks
+    at the right and bottom edges are paid once per level, not once per image (a 6 x 11 map costs 1/7 of a block instead of one).
+    The input buffer holds `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read;
+    the output buffer holds `out_copies` per level and images 0 .. copies - 1 are written."""
     in_copies = copies if in_copies is None else in_copies
     out_copies = copies if out_copies is None else out_copies
     assert in_first + copies <= in_copies and copies <= out_copies
@@ -38,21 +65,18 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         ioffs, ooffs = level_pixel_offsets(levels, in_copies), level_pixel_offsets(levels, out_copies)
         rows = []
         for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
-            assert h < 65536 and w < 65536
-            wv = (w + 4) // 4 * 4
-            # side by side only where that needs fewer blocks (a width that is a multiple of 16 is better off one image per canvas)
-            group = 127 if ((copies - 1) * wv + w + 15) // 16 < copies * ((w + 15) // 16) else 1
-            group = max(1, min(group, (2 ** 31 - 1) // (h * w * 512 * 4), 65535 // wv))   # 32-bit byte offsets (C <= 512), 12-bit block columns
+            assert 0 < h < 4096 and 0 < w < 4096
+            group = max(1, min(127, (2 ** 31 - 1) // (h * w * 512 * 4)))   # 32-bit byte offsets inside a canvas (C <= 512); the image count sits in 7 bits
             done = 0
-            while done < copies:                            # canvases of at most 127 images (the count sits in the top byte of an int32)
+            while done < copies:
                 n = min(group, copies - done)
-                by, bx = (h + 15) // 16, ((n - 1) * wv + w + 15) // 16
-                assert by < 4096 and bx < 4096
-                y = torch.arange(by, dtype=torch.int64).view(-1, 1)
-                x = torch.arange(bx, dtype=torch.int64).view(1, -1)
-                rec = torch.stack(torch.broadcast_tensors(torch.tensor(ioff + (in_first + done) * h * w), torch.tensor(ooff + done * h * w),
-                                                          torch.tensor((h << 16) | w), (n << 24) | (y << 12) | x), dim=-1)
-                rows.append(rec.reshape(-1, 4))
+                grows, gcols, blocks = canvas_layout(h, w, n)
+                while max(b[0] for b in blocks) >= 4096 or max(b[1] for b in blocks) >= 4096 or gcols > 255:   # 12-bit block indices
+                    n = max(1, n // 2)
+                    grows, gcols, blocks = canvas_layout(h, w, n)
+                rec = torch.tensor([[ioff + (in_first + done) * h * w, ooff + done * h * w, (gcols << 24) | (h << 12) | w, (n << 24) | (r << 12) | c]
+                                    for r, c in blocks], dtype=torch.int64)
+                rows.append(rec)
                 done += n
         assert max(ioffs[-1], ooffs[-1]) < 2 ** 31
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()

@@ -27,7 +27,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 n_wg = tab.shape[0] * 4
 lib = ctypes.CDLL(hip.library_path())
-host = np.zeros((min(n_wg, 8192), 8), dtype=np.int64)
+host = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
 lib.pod_wino_trace_dump.argtypes = [ctypes.c_void_p, ctypes.c_int32]
 assert lib.pod_wino_trace_dump(host.ctypes.data, host.shape[0]) == 0
 t = host[:, :6]
@@ -38,6 +38,11 @@ print("%d workgroups traced of %d; shader cycles per phase (median, p10, p90):" 
 for i, nm in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print("  %-20s %8.0f %8.0f %8.0f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+if host[live, 8].any():
+    e = host[live]
+    for nm, i0, i1 in (("  record arrived", 0, 8), ("  mini + filter loads issued", 8, 9), ("  stage offsets", 9, 10), ("  16 stage pieces issued", 10, 11), ("  wait + barrier", 11, 1)):
+        d = e[:, i1] - e[:, i0]
+        print("  %-28s %8.0f %8.0f %8.0f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 tot = t[:, 5] - t[:, 0]
 print("  %-20s %8.0f %8.0f %8.0f" % ("workgroup total", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
 span = t[:, 5].max() - t[:, 0].min()
