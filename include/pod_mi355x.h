@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 3
+#define POD_ABI_VERSION 4
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -269,7 +269,8 @@ typedef struct PodDetections {     /* pod_finalize's outputs */
 /* ---- conv-net side: fused ReLU + dropout -------------------------------------------------------
  * Replaces: the `nn.ReLU(), nn.Dropout(p)` pair after every 3x3 conv of the head subnets (PR:403-424) in
  * MC-dropout mode (PR:103-108), in place, one pass.  x: dev fp32, 16-byte aligned, n elements.
- * Element e uses Philox counter (offset + e/4): pass a different `offset` (or seed) per call. */
+ * Element e uses 16 bits of the Philox4x32-10 call with counter (offset + e/8): keep iff field >= p * 2^16; pass a different
+ * `offset` (or seed) per call. */
 int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
 
 /* ---- conv-net side: bias + residual + ReLU + dropout in one pass ------------------------------------
@@ -304,16 +305,17 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
  *
  * Activations are channels-last: in[pixel][C], out[pixel][K]; all images of the launch live in the two buffers.  `blocks`
  * (device, 16-byte aligned) holds n_blocks int32x4 records {first pixel of image 0 in `in`, first pixel of image 0 in `out`,
- * H << 16 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS of n_images (1..127)
- * consecutive H x W images standing side by side: image n occupies canvas columns n*Wv .. n*Wv + W - 1, Wv = W + 1 rounded up
- * to a multiple of 4, the spare columns are zero padding; block (r, c) covers canvas rows 16r.. and columns 16c.. (n_images = 1: the plain
- * ceil(H/16) x ceil(W/16) tiling of one image).
+ * grid_cols << 24 | H << 12 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a CANVAS of n_images
+ * (1..127) consecutive H x W images (H, W < 4096) standing in a grid of grid_cols (1..255) columns: image i occupies canvas rows
+ * (i / grid_cols) * (H + 1) .. + H - 1 and columns (i % grid_cols) * (W + 1) .. + W - 1 -- one zero row / column between neighbours,
+ * the padding of both; block (r, c) covers canvas rows 16r.. and columns 16c.. and may lie across image borders (n_images = 1: the
+ * plain ceil(H/16) x ceil(W/16) tiling of one image).  Blocks that touch no image need not be listed.
  * C % 8 == 0, K in {64, 128, 256, 512}.  U = pod_wino_filter_transform(weight): 24 * round_up(K, 64) * C floats; weight is
  * (K, C, 3, 3), output channels past K are zero (so a K = 63 predictor runs as K = 64; bias then has round_up(K, 64) entries).
  * k_planes == 0: out is channels-last.  k_planes > 0 (the predictor convs cls_score / bbox_pred / cls_var / bbox_cov,
  * PR:430-484): out is NCHW, image = k_planes planes of H*W starting at float `k_planes * first pixel`: the (N, A*K, H, W)
- * tensors pod_mc_merge_score streams; p must be 0.  Dropout: keep iff Philox word >= p * 2^32, counter = offset + (flat
- * index of the output float4), the mask pod_bias_act draws on the same tensor. */
+ * tensors pod_mc_merge_score streams; p must be 0.  Dropout: 16 Philox4x32-10 bits per element, keep iff field >= p * 2^16, counter
+ * = offset + (flat index of the output element >> 3): the mask pod_bias_act draws on the same tensor. */
 int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,

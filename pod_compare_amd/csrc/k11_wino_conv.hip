@@ -69,7 +69,6 @@ __device__ long long g_wino_trace[8192 * 16];
 #ifndef POD_WINO_VAR
 #define POD_WINO_VAR 0
 #endif
-
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14): lgkmcnt(0) with vmcnt(4) / vmcnt(0)
 constexpr int WINO_WAIT_VM4 = 0x0074, WINO_WAIT_VM0 = 0x0070, WINO_WAIT_VM16 = 0x4070, WINO_WAIT_LGKM0 = 0xC07F;
 
@@ -163,6 +162,19 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         const int pp = (((tid >> 6) * 3 + r) * 64 + (tid & 63)) >> 1, py = pp / 21, pi = pp - py * 21, px = 4 * (pi % 5) + pi / 5;
         mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
     }
+    // the filter operands of chunk 0 do not depend on the block record either: straight from L2 into registers, asked for now
+    const int nchunk = P.C >> 3;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int a = __builtin_amdgcn_readfirstlane(wave);
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
+                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
+    const int u_off = ((a * 6 * 2 + h) * 64 + i32) * 16;                               // + (p*2*64 + kb*32)*16 bytes, + chunk*48 KB
+    f32x4 uA[12];
+    auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
+        u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
@@ -176,7 +188,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         idx = n;
         return v - n * step;
     };
-    const int nchunk = P.C >> 3;
 
     // ---- operands.  Tiles are 2 rows x 4 columns of outputs (F(2,3) down the rows: 4 patch rows; F(4,3) along the columns: 6
     // patch columns), 24 Winograd positions per tile and (c, k) pair where the direct convolution has 72 multiply-adds.  A
@@ -191,8 +202,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     //     the four waves together read each slab byte exactly once;
     //   * the raw 18x18-pixel patch goes global -> LDS by LDS-DMA (buffer_load ... lds), 16-byte slots [h][row][col parity][col/2];
     //     out-of-range buffer offsets return 0.0 -- that IS the zero padding of the convolution; pad slots load nothing.
-    const int i32 = lane & 31, h = lane >> 5;
-    const int a = __builtin_amdgcn_readfirstlane(wave);
     const int row0 = a == 0 ? 0 : a == 2 ? 2 : 1, row1 = a == 2 ? 1 : a == 3 ? 3 : 2;
     const float sgn = a == 1 ? 1.0f : -1.0f;
     // Patch in LDS, one stage per SUPER-CHUNK of 32 input channels = the 128-byte line a pixel owns in the channels-last source:
@@ -220,11 +229,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     uint32_t amini[2];                                                    // LDS byte address in mini stage 0: [row0 / row1]; column c: + ((c & 3) 5 + (c >> 2)) 32
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32 + h * 16;
-    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
-                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
                                                           n_img * HWi * P.in_stride * 4, 0x00020000);
-    const int u_off = ((a * 6 * 2 + h) * 64 + i32) * 16;                               // + (p*2*64 + kb*32)*16 bytes, + chunk*48 KB
     // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
     // (grid row, row inside the image), canvas column -> (grid column, column) -- and parks its pixel index (-1: outside every image:
     // the loads then use a buffer offset that reads 0.0) in LDS; the lanes look their pieces up there: two divisions per thread
@@ -239,7 +245,11 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         pix_tab[t] = ok ? img * HWi + gy * W + gx : -1;              // entry 324 = -1: the "no pixel" slots of the fills point here
     }
     __syncthreads();
-    auto byte_offset = [&](int pix, int part4) { return pix >= 0 ? (pix * P.in_stride + part4) * 4 : 0x7FFFFF00; };
+    auto byte_offset = [&](int pix, int part4) {
+        int o = pix >= 0 ? (pix * P.in_stride + part4) * 4 : ((POD_WINO_VAR & 4) ? part4 * 4 : 0x7FFFFF00);
+        if (POD_WINO_VAR & 8) o &= 0x3FFFF;          // (experiment: every piece from the same 256 KB)
+        return o;
+    };
     // The first two chunks come from two MINI stages (8 channels each, 324 pixels x 32 B, 3 LDS-DMA instructions per wave each), so the
     // matrix cores start after 20 KB have landed instead of a 48 KB super-chunk; super-chunk 0 lands behind the first chunk's MFMAs.
     // Mini layout: 16-byte slot 2 (py 21 + (px & 3) 5 + (px >> 2)) + h: the 16 lanes of a ds_read_b128 group hit every bank group twice.
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
 
-    f32x4 x[12], uA[12], uB[12], vA[6], vB[6], t[6], w6[4];              // x[row][c], u[p][kb], v[p]: 4 channels each
+    f32x4 x[12], uB[12], vA[6], vB[6], t[6], w6[4];                      // x[row][c], u[p][kb] (uA: above), v[p]: 4 channels each
 #if POD_WINO_ELIM
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = uA[i] = uB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
@@ -282,9 +292,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(areg[(i) / 6][((i) % 6) >> 2][c]), "i"((par) * WINO_SB_FLOATS * 4 + ((i) % 6) * 256))
 #define WINO_READ_MINI(which, i)                                                                                                     \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(amini[(i) / 6]), "i"((which) * 12288 + ((((i) % 6) & 3) * 5 + (((i) % 6) >> 2)) * 32))
-    auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
-        u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
-    };
     // packed fp32 arithmetic on the halves of a 4-channel value: r = q * k + p
     auto pk_fma = [](f32x2 k2, f32x2 q, f32x2 p) {
         f32x2 r;
@@ -345,12 +352,10 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // s + 1 from the other stage).  Super-chunk s + 1 is fetched into the stage s - 1 left behind, 4 instructions per wave during
     // each of the chunks (s-1, 3), (s, 0), (s, 1) -- every piece has a whole chunk to land before the barrier that publishes it.
 #define WINO_MFMA(V, U, j)                                                                                                   \
-    acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[((j) % 12) >> 1][(j) / 12], U[(j) % 12][(j) / 12], acc[(j) % 12], 0, 0, 0)
+    acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[(j) % 12][(j) / 12], V[((j) % 12) >> 1][(j) / 12], acc[(j) % 12], 0, 0, 0)
     const int last = nchunk - 1, last_s = last >> 2;
 #pragma unroll
     for (int r = 0; r < 3; ++r) mini_piece(0, r);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
 #pragma unroll
     for (int r = 0; r < 3; ++r) mini_piece(last < 1 ? 0 : 1, r);
     WINO_STAMP(9);
@@ -392,21 +397,21 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         float* wr = lds + dpar * WINO_SB_FLOATS;
         wino_static_for([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
-            if constexpr (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vC[j >> 1][0], uC[j][0], zero16, 0, 0, 0);
+            if constexpr (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uC[j][0], vC[j >> 1][0], zero16, 0, 0, 0);
             else WINO_MFMA(vC, uC, j);
             if constexpr (j < 12) {
                 if constexpr (decltype(first)::value) WINO_READ_MINI(1, j);                  // chunk 1's patch: the second mini stage
                 else if (!(POD_WINO_ELIM & 1)) WINO_READ(rpar, rc, j);
             }
             else if constexpr (j < 24) { if (!(POD_WINO_ELIM & 2)) filter_piece(c1, uN, j - 12); }
-            else if constexpr (j < 28) { if (c != 2 && !(POD_WINO_ELIM & 4)) patch_piece(wr, fs, 4 * ph + j - 24); }
-            else if constexpr (j == 28) __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);         // the 12 reads (issued 16+ MFMAs ago)
-            else if constexpr (j >= 29 && j < 39) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 29); }
+            else if constexpr (j == 24) __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);         // the 12 reads (issued 12+ MFMAs ago)
+            else if constexpr (j >= 25 && j < 35) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 25); }
+            else if constexpr (j >= 36 && j <= 45 && (j - 36) % 3 == 0) { if (c != 2 && !(POD_WINO_ELIM & 4)) patch_piece(wr, fs, 4 * ph + (j - 36) / 3); }
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, 48>{});
         if (!(POD_WINO_ELIM & 16)) {
             // the filters of the next chunk and every patch piece issued before this chunk have landed; this chunk's 4 pieces may fly on
-            __builtin_amdgcn_s_waitcnt(c != 2 && !(POD_WINO_VAR & 2) ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
+            __builtin_amdgcn_s_waitcnt((POD_WINO_VAR & 16) ? WINO_WAIT_VM16 : c != 2 && !(POD_WINO_VAR & 2) ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
             __builtin_amdgcn_s_barrier();
         }
     };
@@ -425,35 +430,39 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     WINO_STAMP(3);
 
     // ---- output transform Y = At2 M At4^T, At2 = [[1,1,1,0],[0,1,-1,-1]], At4 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].
-    // Lane: block row (tile) = (reg&3) + 8 (reg>>2) + 4 (lane>>5), column (channel) = lane & 31.  Every wave applies At4 to its
-    // row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS (128 KB); the store pass
-    // combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],  Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
+    // Every wave applies At4 to its row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS
+    // (130 KB); the store pass combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],
+    // Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
 #if POD_WINO_ELIM & 128
 #pragma unroll
     for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
     return;
 #endif
-    const int LD = P.k_planes > 0 ? 65 : 64;   // one (tile, column) line of the staging: 16-byte reads along k (64) or scalar reads, bank-spread (65)
+    // The MFMAs run with the FILTER as the row operand: a lane's accumulator register reg of block (p, kb) is channel
+    // 32 kb + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of tile lane & 31 -- four consecutive channels per register quad, so the
+    // transform runs on packed pairs and a 16-byte store parks 4 channels.  Staging: Z[a][tile][column e][64 channels], a tile's 4 x 64
+    // floats + 4 pad (1040 B: the 8 tiles of a store's lane group hit 8 different 16-byte bank groups), 4 x 32 x 1040 B = 133 120 B.
+    constexpr int TS = 260;                    // floats per (a, tile)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float m0 = acc[0 * 2 + kb][reg], m1 = acc[1 * 2 + kb][reg], m2 = acc[2 * 2 + kb][reg], m3 = acc[3 * 2 + kb][reg],
-                        m4 = acc[4 * 2 + kb][reg], m5 = acc[5 * 2 + kb][reg];
-            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-            const int tile = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            float* o = lds + ((a * 32 + tile) * 4) * LD + kb * 32 + i32;
-            o[0] = (m0 + s1) + s2;
-            o[LD] = fmaf(2.0f, d2, d1);
-            o[2 * LD] = fmaf(4.0f, s2, s1);
-            o[3 * LD] = fmaf(8.0f, d2, d1) + m5;
+        for (int g = 0; g < 4; ++g) {
+            f32x4 m[6];
+#pragma unroll
+            for (int p6 = 0; p6 < 6; ++p6) m[p6] = f32x4{acc[p6 * 2 + kb][4 * g], acc[p6 * 2 + kb][4 * g + 1], acc[p6 * 2 + kb][4 * g + 2], acc[p6 * 2 + kb][4 * g + 3]};
+            const f32x4 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+            float* o = lds + (a * 32 + i32) * TS + kb * 32 + 8 * g + 4 * h;
+            *reinterpret_cast<f32x4*>(o) = (m[0] + s1) + s2;
+            *reinterpret_cast<f32x4*>(o + 64) = __builtin_elementwise_fma(f32x4{2.f, 2.f, 2.f, 2.f}, d2, d1);
+            *reinterpret_cast<f32x4*>(o + 128) = __builtin_elementwise_fma(f32x4{4.f, 4.f, 4.f, 4.f}, s2, s1);
+            *reinterpret_cast<f32x4*>(o + 192) = __builtin_elementwise_fma(f32x4{8.f, 8.f, 8.f, 8.f}, d2, d1) + m[5];
         }
     __syncthreads();
     WINO_STAMP(4);
 #if POD_WINO_ELIM & 32
     return;
 #endif
-    const int ZA = 32 * 4 * LD;                // floats per position row a
+    constexpr int ZA = 32 * TS;                // floats per position row a
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float* r = lds + (tile * 4 + e) * 65 + k;                // Z[a][tile][e][k] at + a * ZA
+                const float* r = lds + tile * TS + e * 64 + k;                 // Z[a][tile][e][k] at + a * ZA
                 y[e] = (oy & 1) == 0 ? (r[0] + r[ZA]) + r[2 * ZA] : (r[ZA] - r[2 * ZA]) - r[3 * ZA];
             }
             f32x4 v = f32x4{y[0], y[1], y[2], y[3]} + bias;
@@ -494,41 +503,52 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             }
         }
     } else {
-        const int k4 = (tid & 15) * 4, kg = ks * 64 + k4;
-        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + kg);
-        const int ox = tid >> 4;                                                      // this thread's column of the block
+        // thread -> 8 consecutive channels (one Philox call: 16 mask bits per element) of one pixel column, rows of one parity
+        const int k8 = (tid & 7) * 8, kg = ks * 64 + k8, ox = (tid >> 3) & 15, odd = tid >> 7;
+        f32x4 bias0 = f32x4{0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+        if (P.bias) {
+            bias0 = *reinterpret_cast<const f32x4*>(P.bias + kg);
+            bias1 = *reinterpret_cast<const f32x4*>(P.bias + kg + 4);
+        }
         int n;
         const int gx = cell(x0 + ox, Wv, rWv, n);
         const bool col_ok = n < gcols && gx < W;
-        int m, gy = cell(y0, Hv, rHv, m) - 1;                                        // canvas row y0 + oy: grid row m, image row gy (H: the separator)
-#pragma unroll 4
-        for (int oy = 0; oy < 16; ++oy) {
-            if (++gy == Hv) {
-                gy = 0;
+        int m, gy = cell(y0 + odd, Hv, rHv, m) - 2;                                   // canvas row y0 + 2 it + odd: grid row m, image row gy (H: the separator)
+        const float* rbase = lds + (ox >> 2) * TS + (ox & 3) * 64 + k8 + (odd ? ZA : 0);      // Z[a][tile][ox & 3][k8] of row a = odd
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            gy += 2;
+            if (gy >= Hv) {
+                gy -= Hv;
                 ++m;
             }
             const int img = m * gcols + n;
             if (!col_ok || gy >= H || img >= n_img) continue;
-            const float* r = lds + (((oy >> 1) * 4 + (ox >> 2)) * 4 + (ox & 3)) * 64 + k4;      // Z[a][tile][ox & 3][k4] at + a * ZA
-            const f32x4 ra = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? ZA : 0));
-            const f32x4 rb = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 2 * ZA : ZA));
-            const f32x4 rc = *reinterpret_cast<const f32x4*>(r + ((oy & 1) ? 3 * ZA : 2 * ZA));
-            f32x4 v = ((oy & 1) ? (ra - rb) - rc : (ra + rb) + rc) + bias;
+            const float* r = rbase + it * 4 * TS;                                     // tile (it, ox >> 2)
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r), a1 = *reinterpret_cast<const f32x4*>(r + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(r + ZA), b1 = *reinterpret_cast<const f32x4*>(r + ZA + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(r + 2 * ZA), c1 = *reinterpret_cast<const f32x4*>(r + 2 * ZA + 4);
+            f32x4 v0 = (odd ? (a0 - b0) - c0 : (a0 + b0) + c0) + bias0, v1 = (odd ? (a1 - b1) - c1 : (a1 + b1) + c1) + bias1;
             if (P.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
-            const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;
+            const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
-                const uint64_t ctr = P.offset + (uint64_t)(e >> 2);
+                const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
                                                (uint32_t)(P.seed >> 32));
-                v.x = r4.x >= P.thresh ? v.x * P.scale : 0.f;
-                v.y = r4.y >= P.thresh ? v.y * P.scale : 0.f;
-                v.z = r4.z >= P.thresh ? v.z * P.scale : 0.f;
-                v.w = r4.w >= P.thresh ? v.w * P.scale : 0.f;
+                v0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
+                v0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
+                v0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
+                v0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
+                v1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
+                v1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
+                v1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
+                v1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
             }
-            *reinterpret_cast<f32x4*>(P.out + e) = v;
+            *reinterpret_cast<f32x4*>(P.out + e) = v0;
+            *reinterpret_cast<f32x4*>(P.out + e + 4) = v1;
         }
     }
 #ifdef POD_TRACE
@@ -586,7 +606,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
-    P.thresh = (uint32_t)((double)p * 4294967296.0);
+    P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
     const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups

@@ -3,7 +3,7 @@
 // pod_relu_dropout: y = dropout(relu(x), p) in place -- the `nn.ReLU(), nn.Dropout(p)` pair that follows every
 // 3x3 conv of the probabilistic RetinaNet head's subnets (probabilistic_retinanet.py:403-424), evaluated N times
 // per image in MC-dropout mode (PR:103-108).  torch runs it as two kernels (clamp: read+write, fused_dropout:
-// read+write+mask); this is one pass, 16 B per lane, one Philox4x32-10 call per 4 elements (keep iff
+// read+write+mask); this is one pass, 16 B per lane, 16 Philox bits per element (pod_device.h: dropout_words; keep iff
 // uniform >= p, scaled by 1/(1-p), torch.nn.functional.dropout's definition).  HBM-bound: 8 bytes per element.
 #include "pod_device.h"
 
@@ -15,14 +15,13 @@ __global__ void __launch_bounds__(256) k_relu_dropout(float* __restrict__ x, int
                                                       float scale, uint64_t seed, uint64_t offset) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const uint64_t ctr = offset + (uint64_t)i;
-        const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT}, (uint32_t)seed,
-                                      (uint32_t)(seed >> 32));
+        uint32_t w0, w1;
+        dropout_words(offset, (uint64_t)i, 0u, STREAM_DROPOUT, seed, w0, w1);
         float4 v = *reinterpret_cast<const float4*>(x + i * 4);
-        v.x = (r.x >= thresh) ? fmaxf(v.x, 0.0f) * scale : 0.0f;
-        v.y = (r.y >= thresh) ? fmaxf(v.y, 0.0f) * scale : 0.0f;
-        v.z = (r.z >= thresh) ? fmaxf(v.z, 0.0f) * scale : 0.0f;
-        v.w = (r.w >= thresh) ? fmaxf(v.w, 0.0f) * scale : 0.0f;
+        v.x = ((w0 & 0xFFFFu) >= thresh) ? fmaxf(v.x, 0.0f) * scale : 0.0f;
+        v.y = ((w0 >> 16) >= thresh) ? fmaxf(v.y, 0.0f) * scale : 0.0f;
+        v.z = ((w1 & 0xFFFFu) >= thresh) ? fmaxf(v.z, 0.0f) * scale : 0.0f;
+        v.w = ((w1 >> 16) >= thresh) ? fmaxf(v.w, 0.0f) * scale : 0.0f;
         *reinterpret_cast<float4*>(x + i * 4) = v;
     }
     // tail (n % 4 elements)
@@ -31,7 +30,7 @@ __global__ void __launch_bounds__(256) k_relu_dropout(float* __restrict__ x, int
         const uint64_t ctr = offset + (uint64_t)n4 + threadIdx.x;
         const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, STREAM_DROPOUT}, (uint32_t)seed,
                                       (uint32_t)(seed >> 32));
-        x[e] = (r.x >= thresh) ? fmaxf(x[e], 0.0f) * scale : 0.0f;
+        x[e] = ((r.x & 0xFFFFu) >= thresh) ? fmaxf(x[e], 0.0f) * scale : 0.0f;
     }
 }
 
@@ -63,11 +62,8 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n4; i += stride) {
-        u32x4 r = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (P.thresh) {
-            const uint64_t ctr = P.offset + (uint64_t)i;
-            r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT}, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
-        }
+        uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu;
+        if (P.thresh) dropout_words(P.offset, (uint64_t)i, 0u, STREAM_DROPOUT, P.seed, w0, w1);
         float4 v = *reinterpret_cast<const float4*>(P.x + i * 4);
         float4 res = float4{0.f, 0.f, 0.f, 0.f};
         if (P.residual) res = *reinterpret_cast<const float4*>(P.residual + i * 4);
@@ -94,10 +90,10 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
                 if (P.res_bias) rb[j] = P.res_bias[c];
             }
         }
-        v.x = bias_act_one(v.x, b[0], res.x + rb[0], P.relu, r.x >= P.thresh, P.scale);
-        v.y = bias_act_one(v.y, b[1], res.y + rb[1], P.relu, r.y >= P.thresh, P.scale);
-        v.z = bias_act_one(v.z, b[2], res.z + rb[2], P.relu, r.z >= P.thresh, P.scale);
-        v.w = bias_act_one(v.w, b[3], res.w + rb[3], P.relu, r.w >= P.thresh, P.scale);
+        v.x = bias_act_one(v.x, b[0], res.x + rb[0], P.relu, (w0 & 0xFFFFu) >= P.thresh, P.scale);
+        v.y = bias_act_one(v.y, b[1], res.y + rb[1], P.relu, (w0 >> 16) >= P.thresh, P.scale);
+        v.z = bias_act_one(v.z, b[2], res.z + rb[2], P.relu, (w1 & 0xFFFFu) >= P.thresh, P.scale);
+        v.w = bias_act_one(v.w, b[3], res.w + rb[3], P.relu, (w1 >> 16) >= P.thresh, P.scale);
         *reinterpret_cast<float4*>(P.x + i * 4) = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (P.n & 3)) {   // tail (n % 4 elements)
@@ -107,7 +103,7 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
             const uint64_t ctr = P.offset + (uint64_t)P.n4 + threadIdx.x;
             const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, STREAM_DROPOUT}, (uint32_t)P.seed,
                                           (uint32_t)(P.seed >> 32));
-            keep = r.x >= P.thresh;
+            keep = (r.x & 0xFFFFu) >= P.thresh;
         }
         const int c = (int)((e / P.HW) % P.C);
         const float res = (P.residual ? P.residual[e] : 0.0f) + (P.res_bias ? P.res_bias[c] : 0.0f);
@@ -125,14 +121,13 @@ __global__ void __launch_bounds__(256) k_expand_dropout(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
         for (int c = 0; c < copies; ++c) {
-            const uint64_t ctr = offset + (uint64_t)c * (uint64_t)n4 + (uint64_t)i;
-            const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT}, (uint32_t)seed,
-                                          (uint32_t)(seed >> 32));
+            uint32_t w0, w1;
+            dropout_words(offset, (uint64_t)c * (uint64_t)n4 + (uint64_t)i, 2u, STREAM_DROPOUT, seed, w0, w1);
             float4 o;
-            o.x = (r.x >= thresh) ? v.x * scale : 0.0f;
-            o.y = (r.y >= thresh) ? v.y * scale : 0.0f;
-            o.z = (r.z >= thresh) ? v.z * scale : 0.0f;
-            o.w = (r.w >= thresh) ? v.w * scale : 0.0f;
+            o.x = ((w0 & 0xFFFFu) >= thresh) ? v.x * scale : 0.0f;
+            o.y = ((w0 >> 16) >= thresh) ? v.y * scale : 0.0f;
+            o.z = ((w1 & 0xFFFFu) >= thresh) ? v.z * scale : 0.0f;
+            o.w = ((w1 >> 16) >= thresh) ? v.w * scale : 0.0f;
             *reinterpret_cast<float4*>(dst + ((int64_t)c * n4 + i) * 4) = o;
         }
     }
@@ -141,7 +136,7 @@ __global__ void __launch_bounds__(256) k_expand_dropout(const float* __restrict_
 // pod_bias_act_to_nchw: the same tail as pod_bias_act for a channels-last conv output, written as NCHW planes -- the
 // layout change rides on the element-wise pass that exists anyway (a separate transposing copy of the 300 MB p3 trunk
 // output costs 0.3 ms in torch).  Workgroup = one 64 (cells) x 64 (channels) tile through LDS: 16-byte loads along C,
-// 16-byte stores along H*W.  Dropout counters are those of pod_bias_act on the NCHW result (counter = offset + NCHW
+// 16-byte stores along H*W.  Dropout fields are those of pod_bias_act on the NCHW result (float4 group = NCHW
 // float4 index), so the output equals "transpose, then pod_bias_act" bit for bit.
 __global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ bias,
                                                           int32_t C, int64_t HW, int32_t relu, uint32_t thresh, float scale, uint64_t seed,
@@ -176,16 +171,13 @@ __global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restric
         const int c = (tid >> 4) + 16 * it, h4 = (tid & 15) * 4;
         if (c0 + c >= C || hw0 + h4 >= HW) continue;
         const int64_t e = (n * C + c0 + c) * HW + hw0 + h4;   // NCHW element index, a multiple of 4
-        u32x4 r = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (thresh) {
-            const uint64_t ctr = offset + (uint64_t)(e >> 2);
-            r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT}, (uint32_t)seed, (uint32_t)(seed >> 32));
-        }
+        uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu;
+        if (thresh) dropout_words(offset, (uint64_t)(e >> 2), 0u, STREAM_DROPOUT, seed, w0, w1);
         float4 v = float4{tile[h4 + 0][c], tile[h4 + 1][c], tile[h4 + 2][c], tile[h4 + 3][c]};
-        v.x = bias_act_one(v.x, 0.0f, 0.0f, relu, r.x >= thresh, scale);
-        v.y = bias_act_one(v.y, 0.0f, 0.0f, relu, r.y >= thresh, scale);
-        v.z = bias_act_one(v.z, 0.0f, 0.0f, relu, r.z >= thresh, scale);
-        v.w = bias_act_one(v.w, 0.0f, 0.0f, relu, r.w >= thresh, scale);
+        v.x = bias_act_one(v.x, 0.0f, 0.0f, relu, (w0 & 0xFFFFu) >= thresh, scale);
+        v.y = bias_act_one(v.y, 0.0f, 0.0f, relu, (w0 >> 16) >= thresh, scale);
+        v.z = bias_act_one(v.z, 0.0f, 0.0f, relu, (w1 & 0xFFFFu) >= thresh, scale);
+        v.w = bias_act_one(v.w, 0.0f, 0.0f, relu, (w1 >> 16) >= thresh, scale);
         *reinterpret_cast<float4*>(dst + e) = v;
     }
 }
@@ -202,7 +194,7 @@ extern "C" int pod_bias_act_to_nchw(const float* src, float* dst, const float* b
     const int64_t tiles_hw = (HW + 63) / 64, tiles_c = (C + 63) / 64;
     const int64_t blocks = N * tiles_hw * tiles_c;
     if (blocks > 0x7FFFFFFFLL || tiles_hw > 0x7FFFFFFFLL) return POD_E_INVALID;
-    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t thresh = POD_DROPOUT_THRESH16(p);
     hipLaunchKernelGGL(pod::k_bias_act_to_nchw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, bias, C, HW, relu, thresh,
                        1.0f / (1.0f - p), seed, offset, (int32_t)tiles_hw, (int32_t)tiles_c);
     POD_CHECK_LAUNCH();
@@ -215,7 +207,7 @@ extern "C" int pod_expand_dropout(const float* src, float* dst, int64_t n, int32
     if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return POD_E_INVALID;
     if (n == 0) return POD_OK;
     const int64_t n4 = n / 4;
-    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t thresh = POD_DROPOUT_THRESH16(p);
     const float scale = 1.0f / (1.0f - p);
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -235,7 +227,7 @@ extern "C" int pod_bias_act(float* x, const float* bias, const float* residual, 
     pod::BiasActParams P;
     P.x = x; P.bias = bias; P.residual = residual; P.res_bias = res_bias;
     P.n4 = n / 4; P.n = n; P.HW = HW; P.C = C; P.relu = relu;
-    P.thresh = (uint32_t)((double)p * 4294967296.0);   // keep iff u32 >= p * 2^32
+    P.thresh = POD_DROPOUT_THRESH16(p);   // keep iff 16-bit field >= p * 2^16
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
     int64_t blocks = (P.n4 + 255) / 256;
@@ -253,7 +245,7 @@ extern "C" int pod_relu_dropout(float* x, int64_t n, float p, uint64_t seed, uin
     if (!x || n < 0 || !(p >= 0.0f && p < 1.0f) || (reinterpret_cast<uintptr_t>(x) & 15u) != 0) return POD_E_INVALID;
     if (n == 0) return POD_OK;
     const int64_t n4 = n / 4;
-    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);   // keep iff u32 >= p * 2^32
+    const uint32_t thresh = POD_DROPOUT_THRESH16(p);   // keep iff 16-bit field >= p * 2^16
     const float scale = 1.0f / (1.0f - p);
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride: 16 workgroups per CU

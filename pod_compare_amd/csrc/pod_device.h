@@ -57,6 +57,18 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
+// Dropout masks of the model-side kernels (k8_model_ops.hip, k11_wino_conv.hip): 16 random bits per element, 8 elements per
+// Philox4x32-10 call.  Float4 group g (elements 4g .. 4g+3 of the flat tensor a kernel writes) owns words 2 (g & 1) and
+// 2 (g & 1) + 1 of the call with counter base + (g >> 1); element j of the group keeps its value iff field j -- low / high half
+// of the two words -- is >= thresh16 = (uint32_t)(p * 2^16) (0: no dropout), and is scaled by 1 / (1 - p).
+__device__ __forceinline__ void dropout_words(uint64_t base, uint64_t g, uint32_t c2, uint32_t stream, uint64_t seed, uint32_t& w0, uint32_t& w1) {
+    const uint64_t ctr = base + (g >> 1);
+    const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), c2, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    w0 = (g & 1) ? r.z : r.x;
+    w1 = (g & 1) ? r.w : r.y;
+}
+#define POD_DROPOUT_THRESH16(p) ((uint32_t)((double)(p) * 65536.0))
+
 // Native-RNG normals: Box-Muller on two 16-bit uniforms (one 32-bit Philox word per pair of normals,
 // 8 normals per Philox4x32-10 call).  u1 = (a + 0.5) / 2^16 >= 2^-17 bounds the radius, so
 //     |z| <= sqrt(-2 ln 2^-17) = 4.855 < POD_EPS_MAX,

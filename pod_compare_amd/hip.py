@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 3
+POD_ABI_VERSION = 4
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64

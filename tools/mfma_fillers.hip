@@ -30,7 +30,7 @@ struct Cfg {
     int pos;     // 0: filler right after the MFMA, 1: two fillers behind every second MFMA
 };
 
-template <int NR, int RW, int CONF, int NF, int ND, int NV, int VK, int BAR, int WAVES, int POS, int DPAT = 0>
+template <int NR, int RW, int CONF, int NF, int ND, int NV, int VK, int BAR, int WAVES, int POS, int DPAT = 0, int NW = 0>
 __global__ void __launch_bounds__(256, 1) k_fill(const float* __restrict__ gsrc, float* __restrict__ sink, long long* __restrict__ cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256, 1) k_fill(const float* __restrict__ gsrc,
                         }
                 }
             }
+            if (j >= 40 && j - 40 < NW) *reinterpret_cast<f32x4*>(lds + 6144 + wave * 1024 + (j - 40) * 256 + lane * 4) = uC[j - 40];   // stage a loaded piece by hand
             __builtin_amdgcn_sched_barrier(0);
         }
         if (BAR) __syncthreads();
@@ -282,6 +283,11 @@ int main() {
     RUND(0, 16, 0, 0, 3, 0, 0, 1, 4, 0, 5);
     RUND(12, 16, 1, 12, 3, 40, 0, 1, 4, 0, 4);
     RUND(12, 16, 1, 12, 3, 40, 0, 1, 4, 0, 5);
+    run("4 ds_write_b128 per chunk beside bare MFMAs", k_fill<0, 16, 0, 0, 0, 0, 0, 1, 4, 0, 0, 4>, 256, 48);
+    run("4 extra loads + 4 ds_write_b128 beside bare MFMAs", k_fill<0, 16, 0, 4, 0, 0, 0, 1, 4, 0, 0, 4>, 256, 48);
+    run("K11 mix, patch by 4 loads + 4 ds_write_b128 instead of DMA", k_fill<12, 16, 1, 16, 0, 40, 0, 1, 4, 0, 0, 4>, 256, 48);
+    run("K11 mix, patch by 4 DMA pieces (hot)", k_fill<12, 16, 1, 12, 4, 40, 0, 1, 4, 0, 2, 0>, 256, 48);
+    run("K11 mix, patch by 4 DMA pieces (cold, full lines)", k_fill<12, 16, 1, 12, 4, 40, 0, 1, 4, 0, 5, 0>, 256, 48);
     // VALU
     RUN(0, 16, 0, 0, 0, 40, 0, 0, 4, 0);
     RUN(0, 16, 0, 0, 0, 40, 1, 0, 4, 0);
