@@ -70,9 +70,9 @@ def _oracle_inputs(ho, runs):
 @pytest.mark.parametrize("draw_id", [0, 12345])
 def test_product_kernels_equal_oracle_on_their_own_draws(name, draw_id):
     g = Golden(os.path.join(GOLDEN, name + ".npz"))
-    if draw_id != 0 and name.startswith("full_"):
-        pytest.skip("one draw id is enough at full size")
     ho = g.head_outputs()
+    if draw_id != 0 and sum(int(t.shape[1] * t.shape[2] * t.shape[3]) for t in ho.delta) // 4 > 100000:
+        pytest.skip("one draw id is enough at full size (R = 193 374 anchors)")
     hd = ho.to("cuda")
     s = g.spec
     hp = make_path(ho, g.meta["topk"])

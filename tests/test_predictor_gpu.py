@@ -167,6 +167,82 @@ def test_loaded_checkpoint_gives_prior_scores_and_matches_the_cpu_model(tmp_path
     assert res.pred_boxes_covariance.shape == (0, 4, 4)
 
 
+class Fp64Conv:
+    """Stand-in for wino.WinoConv with the same call signature and NO arithmetic in common with it: decodes the block table into
+    its images (so the table's meaning is checked on the way), evaluates each with F.conv2d in fp64 on the CPU, rounds to fp32 and
+    applies bias + ReLU + dropout with pod_bias_act on the same channels-last buffer -- the same Philox fields as the fused store."""
+
+    def __init__(self, conv):
+        self.w, self.b = conv.weight.detach().double().cpu(), conv.bias.detach().float()
+        self.K, self.C = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+        self.Kpad = (self.K + 63) // 64 * 64
+
+    def __call__(self, src, dst, table, relu=False, dropout_p=0.0, seed=0, offset=0, planes=False):
+        import torch.nn.functional as F
+        from pod_compare_amd import hip
+        rec = table.cpu().long()
+        canvases = {(int(r[0]), int(r[1]), int(r[2]), int(r[3]) >> 24) for r in rec}
+        x_all = src.cpu().double()
+        if not planes:
+            dst.zero_()
+        for xin, yout, z, n in sorted(canvases):
+            H, W = (z >> 12) & 0xFFF, z & 0xFFF
+            for i in range(n):
+                x = x_all[xin + i * H * W:xin + (i + 1) * H * W].view(1, H, W, self.C).permute(0, 3, 1, 2)
+                y = F.conv2d(x, self.w, None, padding=1)[0].float()                         # (K, H, W)
+                o = yout + i * H * W
+                if planes:
+                    dst.view(-1)[o * self.K:(o + H * W) * self.K].view(self.K, H, W).copy_(y + self.b.cpu().view(-1, 1, 1))
+                else:
+                    dst[o:o + H * W, :self.K].copy_(y.permute(1, 2, 0).reshape(H * W, self.K))
+        if not planes:
+            bias = torch.zeros(self.Kpad, device=dst.device)
+            bias[:self.K].copy_(self.b)
+            hip.check(hip.load().pod_bias_act(dst.data_ptr(), bias.data_ptr(), None, None, dst.numel(), self.Kpad, 1, 1 if relu else 0,
+                                              float(dropout_p), seed, offset, hip.current_stream()), "pod_bias_act")
+        return dst
+
+
+def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(tmp_path):
+    """Detection level, model -> hot path: a calibrated checkpoint with the head sharpened so that detections exist, N = 10 MC
+    dropout runs, the same dropout masks and the same hot-path draws; once with every head convolution on pod_wino_conv3x3 and
+    once with every head convolution evaluated in fp64 (Fp64Conv).  Same detections: classes and order identical, scores,
+    boxes and covariances within the parity tolerance -- fp32 Winograd in the head moves no detection."""
+    src, frame = _calibrated_checkpoint(tmp_path, 33)
+    cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml", random_seed=0,
+                              data_dir=str(tmp_path), is_testing=True)
+    pred = pinf.build_predictor(cfg)
+    head = pred.model.head
+    with torch.no_grad():
+        for conv in list(head.cls_subnet) + list(head.bbox_subnet):
+            conv.weight.mul_(3.0)                                   # std-0.01 filters would shrink the activations to nothing
+        spread = float(torch.cat([t.reshape(-1) for t in pred.model(frame.cuda()).cls]).std())
+        head.cls_score.weight.mul_(1.5 / spread)                    # logits ~ N(-5, 1.5): a few per cent of the (anchor, class) pairs
+        head.cls_score.bias.fill_(-5.0)                             # pass the 0.05 threshold instead of all sitting at the prior 0.01
+        head.bbox_pred.weight.mul_(3.0)
+    feats = [f.clone() for f in pred.model.fpn(pred.model.bottom_up(pred.model.preprocess_image(frame.cuda())))]
+    pred.model.fpn.forward = lambda _: [f.clone() for f in feats]   # one set of features for both heads (MIOpen's backbone kernels
+    inp = [{"image": frame.cuda(), "height": 96, "width": 160, "image_id": 7}]      # accumulate with atomics: not bit-reproducible)
+    head._drop_calls = 0
+    got = pred(inp)
+    real = head._wino
+    try:
+        head._wino = lambda conv: Fp64Conv(conv)
+        head._drop_calls = 0
+        want = pred(inp)
+    finally:
+        head._wino = real
+    assert len(want) >= 5, "the sharpened head must produce detections for this test to mean anything"
+    assert len(got) == len(want)
+    assert torch.equal(got.pred_classes.cpu(), want.pred_classes.cpu())
+    assert_close(got.scores.cpu(), want.scores.cpu(), "scores")
+    bscale = want.pred_boxes.tensor.cpu().abs().amax(dim=1, keepdim=True).clamp(min=1.0)                # per detection: a corner near 0 of a
+    assert_close(got.pred_boxes.tensor.cpu() / bscale, want.pred_boxes.tensor.cpu() / bscale, "boxes")   # 300-pixel box moves with ITS box
+    scale = want.pred_boxes_covariance.cpu().abs().amax(dim=(1, 2), keepdim=True).clamp(min=1.0)       # per detection: an off-diagonal
+    assert_close(got.pred_boxes_covariance.cpu() / scale, want.pred_boxes_covariance.cpu() / scale, "cov")   # entry is small against ITS matrix
+    assert_close(got.pred_cls_probs.cpu(), want.pred_cls_probs.cpu(), "probs")
+
+
 def test_eval_mode_trunk_sharing_on_the_gpu():
     """SURVEY f-4 on the GPU: without dropout the mean and variance branches of a subnet see the same trunk activation, so
     the head evaluates each trunk once (PR:518-523 runs it twice); the outputs equal two separate evaluations."""

@@ -1,6 +1,7 @@
 """pod_wino_conv3x3 (csrc/k11_wino_conv.hip): the head's 3x3 convolutions (probabilistic_retinanet.py:403-484) as fp32 Winograd
-on the matrix cores, against torch's conv2d on the same tensors.  Tolerance 2e-5 of the output's scale (fp32 Winograd, F(2,3) down the
-rows x F(4,3) along the columns, differs from a direct fp32 convolution by ~4e-6 of the scale at C = 256)."""
+on the matrix cores.  Referees: a CPU fp64 direct convolution with a per-element bound in units of 2^-24 (|w| * |x| + |b|)
+(`test_error_against_an_fp64_direct_convolution`), and torch's conv2d on the same tensors with 2e-5 of the output's scale (fp32
+Winograd, F(2,3) down the rows x F(4,3) along the columns, differs from a direct fp32 convolution by ~2e-6 of the scale at C = 256)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -61,6 +62,39 @@ def test_predictor_planes_of_a_subset_of_the_runs(K):
         want = F.conv2d(x[first:first + count], w, b, padding=1)
         assert float((got[:count] - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
         assert bool((got[count:] == 7.0).all())
+
+
+BENCH_LEVELS = [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)]      # the five FPN levels of the 768 x 1344 benchmark frame
+C_BOUND = 32.0
+
+
+@pytest.mark.parametrize("K,planes", [(256, False), (63, True), (36, True)], ids=["trunk-256", "cls_score-63", "bbox_pred-36"])
+def test_error_against_an_fp64_direct_convolution(K, planes):
+    """The referee that is not MIOpen: F.conv2d in fp64 on the CPU, on the benchmark launch's shapes (C = 256, five levels) with
+    post-ReLU activations.  Per ELEMENT  |err| <= c 2^-24 (|w| * |x| + |b|)  -- the unit every forward error bound of an fp32
+    evaluation is written in (a length-n fp32 dot product guarantees c <= n = 2304).  Measured c (tools/wino_fp64_check.py, MI355X):
+    pod_wino_conv3x3 11.6 / 10.8 / 13.6 (trunk / cls_score / bbox_pred), MIOpen's fp32 conv2d 2.5 - 2.8, mkldnn's fp32 conv2d on the
+    CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class."""
+    C, copies, u = 256, 1, 2.0 ** -24
+    g = torch.Generator().manual_seed(K)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, generator=g)
+    xs = [torch.randn(copies, C, h, wd, generator=g).relu() for h, wd in BENCH_LEVELS]
+    conv = WinoConv(w.cuda(), b.cuda())
+    src = flat([x.cuda() for x in xs])
+    offs = level_pixel_offsets(BENCH_LEVELS, copies)
+    dst = torch.full((offs[-1] * K,) if planes else (src.shape[0], K), float("nan"), device="cuda")
+    conv(src, dst, block_table(BENCH_LEVELS, copies, "cuda"), planes=planes)
+    c_max = 0.0
+    for i, (x, (h, wd)) in enumerate(zip(xs, BENCH_LEVELS)):
+        want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        bound = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), padding=1)
+        got = (dst[offs[i] * K:offs[i + 1] * K].view(copies, K, h, wd) if planes
+               else dst[offs[i]:offs[i + 1]].view(copies, h, wd, K).permute(0, 3, 1, 2)).cpu().double()
+        assert torch.isfinite(got).all()
+        c_max = max(c_max, float(((got - want).abs() / (u * bound)).max()))
+    print("c = %.2f" % c_max)
+    assert c_max <= C_BOUND
 
 
 def test_dropout_mask_is_the_one_pod_bias_act_draws():
