@@ -271,6 +271,17 @@ def main():
     stage = (lambda t: t.cpu()) if backend != "nccl" else (lambda t: t)
     spec = CONFIGS[args.config]
     N = spec["runs"]
+    rank_devices = [local_rank]
+    if world > 1:
+        # one process per GPU: every rank must sit on a device of its own (PCI bus id, not just the ordinal: two ranks that both see
+        # "cuda:0" through different HIP_VISIBLE_DEVICES are fine, two ranks on the same physical device are not)
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else local_rank
+        mine = stage(torch.tensor([local_rank, int(bus)], device=dev, dtype=torch.int64))
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_devices = [int(t[0]) for t in every]
+        if not share and len({(int(t[0]), int(t[1])) for t in every}) != world:
+            raise SystemExit("bench.py --gpus %d: ranks share a device %s; launch one rank per GPU" % (world, [tuple(int(v) for v in t) for t in every]))
 
     if args.ensemble_per_gpu:
         if args.config != "cfg5" or world < spec["members"]:
@@ -357,6 +368,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         dets = [step(i) for i in range(args.steps)]
+        host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / args.steps      # host time to enqueue one image (model launches + pod_run_image)
         for st in streams[1:]:
             streams[0].wait_stream(st)          # the flush below reads every stream's detections
         flush_ms = 0.0
@@ -381,12 +393,13 @@ def main():
         dt = time.perf_counter() - t0
     per_rank = [args.steps / t_images]
     if world > 1:
-        t = stage(torch.tensor([dt, flush_ms, t_images], device=dev, dtype=torch.float64))
+        t = stage(torch.tensor([dt, flush_ms, t_images, host_enqueue_ms], device=dev, dtype=torch.float64))
         tl = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(tl, t)
         dt = max(float(x[0]) for x in tl)
         flush_ms = max(float(x[1]) for x in tl)
         per_rank = [args.steps / float(x[2]) for x in tl]
+        host_enqueue_ms = max(float(x[3]) for x in tl)
     n_det_mean = float(torch.stack([d.n_det for d in dets]).float().mean().item())
 
     out = {
@@ -403,10 +416,10 @@ def main():
                                                 "the head does not compute those 3 of its 4N subnet evaluations",
                    "members_on_this_gpu": len(members),
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
-                   "rccl_ranks": world, "collective_backend": backend if world > 1 else None,
+                   "rccl_ranks": world, "collective_backend": backend if world > 1 else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
                    "rng": "in-kernel Philox4x32-10, fresh key per image"},
-        "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if world > 1 else None,
+        "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if world > 1 else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "mean_detections": n_det_mean,
     }
     if rank == 0 and not args.no_diagnostics:
@@ -462,12 +475,15 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
     dense_delta = torch.empty(R * 4, dtype=torch.float32, device=dev) if N > 1 else None
     dense_reg = torch.empty(R * D, dtype=torch.float32, device=dev) if N > 1 and D > 0 else None
 
-    def time_k1(mean_delta, mean_reg_var):
+    def time_k1(mean_delta, mean_reg_var, with_score=False):
         def k1_call(j):
             hotpath.hip.check(lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(mean_delta),
                                                      P(mean_reg_var), P(hp.cand_keys), P(hp.cand_count),
                                                      P(hp.maybe_bits) if prune else None, st),
                               "pod_mc_merge_score")
+            if with_score:     # merge AND score, the job SURVEY 8 a3 + a4 defines: K1b samples the anchors K1 flagged
+                hotpath.hip.check(lib.pod_score_maybe(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits),
+                                                      P(hp.cand_keys), P(hp.cand_count), P(hp.probs_dense), st), "pod_score_maybe")
 
         for j in range(3):
             lib.pod_reset_counters(P(hp.counters), 8, st)
@@ -486,8 +502,8 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
             lib.pod_reset_counters(P(hp.counters), 8, st)
             evs[bidx][0].record()
             for j in range(K1B):
-                if not prune:
-                    lib.pod_reset_counters(P(hp.counters), 8, st)   # dense-scoring mode appends candidates: keep the lists bounded
+                if not prune or with_score:
+                    lib.pod_reset_counters(P(hp.counters), 8, st)   # scoring appends candidates: keep the lists bounded
                 k1_call(bidx * K1B + j)
             evs[bidx][1].record()
         torch.cuda.synchronize()
@@ -501,6 +517,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
     k1_avg_ms, k1_min_ms = time_k1(hp.mean_delta, hp.mean_reg_var)
     k1_bytes = k1_algorithmic_bytes(R, K, D, N, spec["cls_var"], params.merge_quirk, dense_box=hp.dense_box_merge)
     kd_avg_ms, kd_min_ms = time_k1(dense_delta, dense_reg)
+    ks_avg_ms, ks_min_ms = time_k1(hp.mean_delta, hp.mean_reg_var, with_score=True) if prune else (k1_avg_ms, k1_min_ms)
     kd_bytes = k1_algorithmic_bytes(R, K, D, N, spec["cls_var"], params.merge_quirk, dense_box=True)
     # HBM traffic of K1 comes from separate rocprofv3 --pmc passes (a counter run cannot share a process with this timing
     # run); the committed summary of the latest pass is read back when it was taken on this very workload.
@@ -520,7 +537,11 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                        "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                        "algorithmic_bytes": k1_bytes, "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
                        "channels_streamed": "2K class channels (box_delta / box_reg_var are merged at the candidates by K2b)"
-                                            if not hp.dense_box_merge else "2K+4+D"}
+                                            if not hp.dense_box_merge else "2K+4+D",
+                       "merge_and_score": {"what": "the same algorithmic bytes over K1 + K1b back to back (SURVEY 8 a3 + a4: merge AND score"
+                                                   + ("; + one pod_reset_counters launch per pair)" if prune else ")"),
+                                           "avg_us": 1e3 * ks_avg_ms, "min_us": 1e3 * ks_min_ms,
+                                           "achieved": k1_bytes / (ks_avg_ms * 1e-3) / 1e9, "frac": k1_bytes / (ks_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     # the same kernel asked for the reference-shaped dense merge of every channel (PI:211-270), for comparison
     out["roofline_dense_merge"] = {"kernel": "pod_mc_merge_score, mean_delta / mean_reg_var requested", "bound": "hbm",
                                    "achieved": kd_bytes / (kd_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -535,7 +556,11 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
         out["roofline_k1"] = out["roofline"]
         out["roofline_k1"]["scope"] = "dominant kernel of the post-processing chain K1..K7 (SURVEY 8d's merge + score)"
         out["roofline"] = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
-        out["roofline"]["scope"] = "dominant kernel of the step by time (the head's convolutions); K1's roofline: roofline_k1"
+        out["roofline"]["scope"] = "dominant kernel of the step by time (the head's convolutions); SURVEY 8(d)'s kernel (K1): roofline.k1"
+        k1r = out["roofline_k1"]
+        out["roofline"]["k1"] = {k: k1r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                                                      "avg_launch_us", "merge_and_score")}
+        out["k1_hbm_frac"], out["k1_merge_and_score_hbm_frac"] = k1r["frac"], k1r["merge_and_score"]["frac"]
         out["roofline_head_conv"] = out["roofline"]
 
     # ---- the whole conv net of a step against the fp32 MFMA peak ---------------------------------------------

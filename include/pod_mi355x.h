@@ -211,7 +211,10 @@ int pod_nms_cluster(const PodConfig* cfg, const int32_t* n_total, int32_t n_capa
  * box_mode: 0 = bayesian_inference, 1 = covariance_intersection;
  * cls_mode: 0 = max_score (centre's score/class/probs), 1 = bayesian_inference (mean of member probs).
  * Degenerate cluster (no member, Q12): falls back to the centre's box/covariance.
- * out_* : dev, max_detections rows. */
+ * out_* : dev, max_detections rows.
+ * CAPACITIES: boxes / cov / scores / classes / probs must hold cfg->n_levels * cfg->topk rows and keep cfg->max_detections
+ * entries, whatever *n_total / *n_keep say: the first rows are loaded in the same round trip as the counts (rows past the
+ * counts are read, never used). */
 int pod_bayes_fuse(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
                    const float* boxes, const float* cov, const float* scores, const int32_t* classes,
                    const float* probs, int32_t box_mode, int32_t cls_mode,
@@ -222,7 +225,9 @@ int pod_bayes_fuse(const PodConfig* cfg, const int32_t* n_total, const int32_t* 
  * Replaces: general_anchor_statistics_postprocessing IU:91-154 (cluster mean, residual outer
  * products / max(m-1,1), + mean member covariance when the net provides one, mean prob vector,
  * singleton rule IU:127-133, score/class re-derived from the merged prob vector IU:146-152).
- * cov may be NULL (no network covariance). */
+ * cov may be NULL (no network covariance).
+ * CAPACITIES as for pod_bayes_fuse: candidate arrays of cfg->n_levels * cfg->topk rows, keep of cfg->max_detections entries
+ * (speculative loads run ahead of the counts). */
 int pod_anchor_stats_merge(const PodConfig* cfg, const int32_t* n_total, const int32_t* keep, const int32_t* n_keep,
                            const float* boxes, const float* cov, const int32_t* classes, const float* probs,
                            float* out_boxes, float* out_cov, float* out_scores, int32_t* out_classes, float* out_probs,

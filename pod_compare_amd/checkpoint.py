@@ -127,7 +127,12 @@ def read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
     else:
         try:        # detectron2 checkpoints hold tensors, numbers and strings only: the restricted unpickler is enough
             data = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:      # older files pickle numpy scalars / argparse namespaces next to the weights
+        except pickle.UnpicklingError as e:
+            # older files pickle numpy scalars / argparse namespaces next to the weights.  Full unpickling executes code from the
+            # file: only for files the operator vouches for (POD_TRUSTED_CHECKPOINTS=1), never as a silent fallback.
+            if os.environ.get("POD_TRUSTED_CHECKPOINTS") != "1":
+                raise CheckpointError("{}: not readable by the restricted unpickler ({}); if the file is trusted, set "
+                                      "POD_TRUSTED_CHECKPOINTS=1 to allow full unpickling".format(path, str(e).splitlines()[0])) from e
             data = torch.load(path, map_location="cpu", weights_only=False)
         sd = data["model"] if isinstance(data, dict) and "model" in data and isinstance(data["model"], dict) else data
     out = {}
@@ -210,6 +215,16 @@ def load_model_weights(model, save_dir: Optional[str], weights: str, strict: boo
     if not path:
         return ""
     missing, unexpected = load_detectron2_state_dict(model, read_checkpoint_file(path), strict=strict)
+    n_own = len(model.state_dict())
+    for part in ("bottom_up.", "head."):
+        own_part = [k for k in model.state_dict() if k.startswith(part)]
+        if own_part and all(k in missing for k in own_part):
+            # a renamed head / backbone would otherwise leave that whole part at its random init behind a mere warning
+            if part == "bottom_up." or len(missing) == n_own:
+                raise CheckpointError("checkpoint {}: no {} tensor of the model was found in the file (names: {} ...)".format(
+                    path, part.rstrip("."), sorted(unexpected)[:4]))
+            warnings.warn("checkpoint {} holds NO tensor of the model's {} (a backbone-only file?): that part keeps its random init".format(
+                path, part.rstrip(".")))
     if missing or unexpected:
         warnings.warn("checkpoint {}: {} model tensors not in the file (e.g. {}), {} file tensors unused (e.g. {})".format(
             path, len(missing), missing[:3], len(unexpected), unexpected[:3]))

@@ -596,13 +596,16 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
           reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
         return POD_E_INVALID;
     if (n_blocks == 0) return POD_OK;
-    static std::once_flag once;
-    static hipError_t attr = hipSuccess;
-    std::call_once(once, [] {
-        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   pod::WINO_LDS_BYTES);
+    // the 130 KB dynamic-LDS opt-in is a PER-DEVICE function attribute: once per device ordinal this process launches on
+    static std::once_flag once[64];
+    static hipError_t attr[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
+    std::call_once(once[dev], [dev] {
+        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        pod::WINO_LDS_BYTES);
     });
-    if (attr != hipSuccess) return POD_E_LAUNCH;
+    if (attr[dev] != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;

@@ -66,8 +66,10 @@ def _predict(box_cls, box_delta, box_cls_var, box_reg_var, anchors, mode, image_
     dev = box_cls[0].device
     shapes = tuple(tuple(t.shape[2:]) for t in box_cls)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    # the workspace keeps a copy of the anchors: a call with other anchor tensors (same shapes) must not decode against the first ones
+    akey = tuple((a.data_ptr(), a._version, tuple(a.shape)) for a in anchors)
     key = (shapes, A, K, n_runs, bool(box_cls_var), D, str(dev), stream, topk_candidates, score_thresh, nms_thresh, max_detections,
-           cls_var_num_samples, affinity_thresh, merge_quirk)
+           cls_var_num_samples, affinity_thresh, merge_quirk, akey)
     hp = _PATHS.get(key)
     if hp is None:      # one workspace per (geometry, stream), as the predictor keeps them
         p = hotpath.PathParams(num_classes=K, num_anchors=A, topk_candidates=topk_candidates, score_thresh=score_thresh,
@@ -141,6 +143,18 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
                  lambda: "blocks: contiguous CUDA int32 (n, 4)")
     torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == Kpad), lambda: "bias: round_up(K, 64) fp32 values")
     torch._check(planes or out_elements == src.shape[0] * Kpad, lambda: "channels-last output: out_elements == pixels * round_up(K, 64)")
+    torch._check(0.0 <= dropout_p < 1.0 and not (planes and dropout_p), lambda: "dropout_p in [0, 1), 0 with planes=True")
+    if blocks.shape[0]:
+        # the kernel reads and writes at offsets taken from the table: every canvas must lie inside the two buffers
+        b = blocks.to(torch.int64)
+        z, w = b[:, 2], b[:, 3]
+        gcols, H, W, n = (z >> 24) & 0xFF, (z >> 12) & 0xFFF, z & 0xFFF, (w >> 24) & 0xFF
+        last_in, last_out = b[:, 0] + n * H * W, b[:, 1] + n * H * W
+        per_px = int(K) if planes else Kpad
+        ok = ((b[:, 0] >= 0) & (b[:, 1] >= 0) & (H > 0) & (W > 0) & (n > 0) & (n <= 127) & (gcols > 0) & (last_in <= src.shape[0])
+              & (last_out * per_px <= int(out_elements)) & (((w >> 12) & 0xFFF) * 16 < ((n + gcols - 1) // gcols) * (H + 1))
+              & ((w & 0xFFF) * 16 < gcols * (W + 1)))
+        torch._check(bool(ok.all()), lambda: "blocks: a record lies outside src / the output (record {})".format(int((~ok).nonzero()[0])))
     out = torch.zeros(int(out_elements), dtype=torch.float32, device=src.device) if planes else \
         torch.empty((src.shape[0], Kpad), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):

@@ -47,19 +47,23 @@ class _RestartingEps:
         return self.src(shape)
 
 
-def _worker(rank, world, port, num_images, tmp):
+def _worker(rank, world, port, num_images, tmp, backend="gloo", own_gpu=False):
     from pod_compare_amd import apply_net, config
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev_index = rank if own_gpu else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     g = Golden(os.path.join(GOLDEN, FIXTURE + ".npz"))
     cfg = config.setup_config(CFG + "/BDD-Detection/retinanet/retinanet_R_50_FPN_1x_reg_cls_var.yaml", CFG + "/Inference/ensembles_pre_nms.yaml")
-    cfg.MODEL.DEVICE = "cuda:0"
+    cfg.MODEL.DEVICE = "cuda:%d" % dev_index
     M = g.spec["runs"]
     ho = g.head_outputs().to("cuda") if rank < M else None
     runner = apply_net.EnsemblePerGpu(cfg, rank, world, frame_hw=tuple(g.meta["out"]), net_hw=tuple(g.meta["image"]),
                                       model=_Member(ho, rank) if rank < M else None)
-    assert runner.pipe.host_staged and (runner.model is None) == (rank >= M)
+    assert runner.pipe.host_staged == (backend != "nccl") and (runner.model is None) == (rank >= M)
     runner.predictor.eps_fn = _RestartingEps(g)
     dummy = torch.zeros((3,) + tuple(g.meta["out"]), dtype=torch.uint8, device="cuda")
     results = {}
@@ -78,11 +82,11 @@ def _worker(rank, world, port, num_images, tmp):
     dist.destroy_process_group()
 
 
-def test_one_member_per_rank_pipeline_reproduces_the_reference_on_every_merge_rank(tmp_path):
+def run_pipeline(tmp_path, backend="gloo", own_gpu=False):
     g = Golden(os.path.join(GOLDEN, FIXTURE + ".npz"))
     world, num_images = g.spec["runs"] + 1, 8
     port = 34500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, num_images, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, num_images, str(tmp_path), backend, own_gpu), nprocs=world, join=True)
     ref_b, ref_c, ref_s, ref_k = g.t("pred_boxes"), g.t("pred_boxes_covariance"), g.t("scores"), g.t("pred_classes")
     seen = []
     for r in range(world):
@@ -95,3 +99,7 @@ def test_one_member_per_rank_pipeline_reproduces_the_reference_on_every_merge_ra
             assert bool(((c - ref_c).abs() <= 1e-4 * ref_c.abs().clamp(min=1.0)).all())
             assert float((s - ref_s).abs().max()) <= 2e-6
     assert sorted(seen) == list(range(num_images))
+
+
+def test_one_member_per_rank_pipeline_reproduces_the_reference_on_every_merge_rank(tmp_path):
+    run_pipeline(tmp_path)
