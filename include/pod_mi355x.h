@@ -294,6 +294,11 @@ int pod_bias_act(float* x, const float* bias, const float* residual, const float
  * src != dst; dropout counters are those of pod_bias_act on the NCHW result. */
 int pod_bias_act_to_nchw(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
                          float p, uint64_t seed, uint64_t offset, pod_stream_t stream);
+/* The reverse layout change, for an NCHW conv (MIOpen) whose consumer is pod_wino_conv3x3: dst[(n*HW + hw)*C + c] =
+ * act(src[(n*C + c)*HW + hw] + bias[c]), the bias + ReLU pass of detectron2's bottleneck conv1 (the reference model's
+ * backbone, probabilistic_retinanet.py:20-60 via build_retinanet_resnet_fpn_backbone) writing channels-last.  C % 4 == 0. */
+int pod_bias_act_to_nhwc(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
+                         pod_stream_t stream);
 
 /* ---- conv-net side: broadcast + dropout -------------------------------------------------------------
  * Replaces: feeding the SAME first-conv activation to every MC run's `nn.Dropout(p)` (PR:104-106 replicates the feature

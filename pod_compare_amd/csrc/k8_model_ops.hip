@@ -182,7 +182,70 @@ __global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restric
     }
 }
 
+// pod_bias_act_to_nhwc: the reverse trip, for a conv whose CONSUMER is pod_wino_conv3x3 (channels-last input): the bias + ReLU pass
+// that follows an NCHW (MIOpen) conv anyway writes [pixel][C] instead of planes.  64 (cells) x 64 (channels) tiles through LDS:
+// 16-byte loads along H*W (scalar when H*W % 4 != 0), 16-byte stores along C.
+__global__ void __launch_bounds__(256) k_bias_act_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ bias,
+                                                          int32_t C, int64_t HW, int32_t relu, int32_t tiles_hw, int32_t tiles_c) {
+    __shared__ float tile[64][65];   // [channel][cell], padded
+    const int tid = threadIdx.x;
+    int64_t t = blockIdx.x;
+    const int tc = (int)(t % tiles_c);
+    t /= tiles_c;
+    const int th = (int)(t % tiles_hw);
+    const int64_t n = t / tiles_hw;
+    const int64_t hw0 = (int64_t)th * 64;
+    const int c0 = tc * 64;
+    const bool vec = (HW & 3) == 0;
+    // load: thread -> (channel row = tid / 16 + 16 * it, 4 cells at (tid % 16) * 4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (tid >> 4) + 16 * it, h4 = (tid & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + c < C) {
+            const float* p = src + (n * C + c0 + c) * HW + hw0 + h4;
+            if (vec && hw0 + h4 < HW) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (hw0 + h4 + j < HW) v[j] = p[j];
+            }
+            const float b = bias ? bias[c0 + c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] += b;
+                if (relu) v[j] = fmaxf(v[j], 0.0f);
+            }
+        }
+        tile[c][h4 + 0] = v[0]; tile[c][h4 + 1] = v[1]; tile[c][h4 + 2] = v[2]; tile[c][h4 + 3] = v[3];
+    }
+    __syncthreads();
+    // store: thread -> (cell row = tid / 16 + 16 * it, 4 channels at (tid % 16) * 4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4;
+        if (hw0 + r >= HW || c0 + c4 >= C) continue;
+        *reinterpret_cast<float4*>(dst + ((n * HW + hw0 + r) * C + c0 + c4)) = float4{tile[c4 + 0][r], tile[c4 + 1][r], tile[c4 + 2][r], tile[c4 + 3][r]};
+    }
+}
+
 }  // namespace pod
+
+extern "C" int pod_bias_act_to_nhwc(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
+                                    pod_stream_t stream) {
+    if (!src || !dst || src == dst || N < 0 || C < 4 || (C & 3) != 0 || HW < 1) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return POD_E_INVALID;
+    if (N == 0) return POD_OK;
+    const int64_t tiles_hw = (HW + 63) / 64, tiles_c = (C + 63) / 64;
+    const int64_t blocks = N * tiles_hw * tiles_c;
+    if (blocks > 0x7FFFFFFFLL || tiles_hw > 0x7FFFFFFFLL) return POD_E_INVALID;
+    hipLaunchKernelGGL(pod::k_bias_act_to_nhwc, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, bias, C, HW, relu,
+                       (int32_t)tiles_hw, (int32_t)tiles_c);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
 
 extern "C" int pod_bias_act_to_nchw(const float* src, float* dst, const float* bias, int64_t N, int32_t C, int64_t HW, int32_t relu,
                                     float p, uint64_t seed, uint64_t offset, pod_stream_t stream) {

@@ -27,7 +27,7 @@ POD_MAX_DETECTIONS = 128
 EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates", "pod_gather_decode",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
-           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
+           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
            "pod_dump_cls_normals", "pod_dump_box_normals", "pod_wino_filter_transform", "pod_wino_conv3x3")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
@@ -107,6 +107,7 @@ def load() -> ctypes.CDLL:
     lib.pod_match_groundtruth.argtypes = [P, P, P, P, c_int32, P, P, P, c_int32, c_int32, c_float, c_float, P, P, P, P, P, P]
     lib.pod_relu_dropout.argtypes = [P, c_int64, c_float, c_uint64, c_uint64, P]
     lib.pod_bias_act_to_nchw.argtypes = [P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
+    lib.pod_bias_act_to_nhwc.argtypes = [P, P, P, c_int64, c_int32, c_int64, c_int32, P]
     lib.pod_expand_dropout.argtypes = [P, P, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_wino_filter_transform.argtypes = [P, P, c_int32, c_int32, P]
     lib.pod_wino_conv3x3.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P]

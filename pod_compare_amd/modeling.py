@@ -150,7 +150,44 @@ def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
 
 
 WINO_HEAD = True              # GPU only: the head subnets' 3x3 convs on pod_wino_conv3x3 (all levels, all runs per launch)
+WINO_BACKBONE = __import__("os").environ.get("POD_WINO_BACKBONE", "1") != "0"   # GPU only: the bottlenecks' and the FPN's 3x3 / stride-1 convs on pod_wino_conv3x3 too (batch 1: few
+                              # workgroups per launch, but a third of MIOpen's CU-time per FLOP -- the other streams' images fill the idle CUs)
 NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run channels-last (p3 of a 768x1344 input: 16128)
+
+
+def wino_of(conv: nn.Conv2d):
+    """The conv's Winograd-transformed filter (pod_wino_filter_transform), refreshed when the parameters change."""
+    from .wino import WinoConv
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+    cached = getattr(conv, "_pod_wino", None)
+    if cached is None or cached[0] != key:
+        cached = (key, WinoConv(conv.weight, conv.bias))
+        torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
+        conv._pod_wino = cached
+    return cached[1]
+
+
+def wino_eligible(conv: Optional[nn.Conv2d], x: torch.Tensor) -> bool:
+    """pod_wino_conv3x3 can stand in for `conv` on x: 3x3 / stride 1 / pad 1, fp32 on the GPU, one image, channel counts it tiles."""
+    return (WINO_BACKBONE and FUSE_CONV_TAIL and conv is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and conv.groups == 1
+            and tuple(conv.dilation) == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels in (64, 128, 256, 512)
+            and x.shape[2] < 4096 and x.shape[3] < 4096)
+
+
+def wino_conv_nchw(conv: nn.Conv2d, x: torch.Tensor, relu: bool, pre_bias: Optional[torch.Tensor] = None, pre_relu: bool = False) -> torch.Tensor:
+    """act(conv(pre_act(x + pre_bias))) for an NCHW x (1, C, H, W): the element-wise tail of the PRODUCER of x (bias + ReLU of the conv
+    before) rides on the pass that lays x out channels-last (pod_bias_act_to_nhwc), the 3x3 conv runs on pod_wino_conv3x3 with its own
+    bias + ReLU in the store, and the result comes back as NCHW planes."""
+    from . import hip
+    from .wino import block_table
+    _, C, H, W = x.shape
+    a = torch.empty((H * W, C), dtype=x.dtype, device=x.device)
+    hip.check(hip.load().pod_bias_act_to_nhwc(x.contiguous().data_ptr(), a.data_ptr(), hip.ptr(pre_bias), 1, C, H * W, 1 if pre_relu else 0,
+                                              hip.current_stream()), "pod_bias_act_to_nhwc")
+    out = torch.empty((1, conv.out_channels, H, W), dtype=x.dtype, device=x.device)
+    wino_of(conv)(a, out.view(-1), block_table([(H, W)], 1, x.device), relu=relu, planes=True)
+    return out
 
 
 def _conv_bn(cin, cout, k, stride=1, padding=0):
@@ -168,8 +205,13 @@ class Bottleneck(nn.Module):
         self.conv3 = _conv_bn(mid, cout, 1)
 
     def forward(self, x):
-        out = conv_bias_act(self.conv1, x, relu=True)
-        out = conv_bias_act(self.conv2, out, relu=True)
+        c1, c2 = _plain_conv(self.conv1), _plain_conv(self.conv2)
+        if c1 is not None and c1.bias is not None and c2 is not None and c2.bias is not None and wino_eligible(c2, x):
+            y = F.conv2d(x, c1.weight, None, c1.stride, c1.padding)                       # conv1 without its bias (MIOpen, NCHW)
+            out = wino_conv_nchw(c2, y, relu=True, pre_bias=c1.bias, pre_relu=True)       # its bias + ReLU, then conv2 + bias + ReLU
+        else:
+            out = conv_bias_act(self.conv1, x, relu=True)
+            out = conv_bias_act(self.conv2, out, relu=True)
         if self.shortcut is None:
             return conv_bias_act(self.conv3, out, relu=True, residual=x)
         return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x)
@@ -219,7 +261,7 @@ class FPN(nn.Module):
         l5 = self.lateral[2](c5)
         l4 = self.lateral[1](c4) + F.interpolate(l5, size=c4.shape[-2:], mode="nearest")
         l3 = self.lateral[0](c3) + F.interpolate(l4, size=c3.shape[-2:], mode="nearest")
-        p3, p4, p5 = self.output[0](l3), self.output[1](l4), self.output[2](l5)
+        p3, p4, p5 = (wino_conv_nchw(m, l, relu=False) if wino_eligible(m, l) else m(l) for m, l in zip(self.output, (l3, l4, l5)))
         p6 = self.p6(c5)
         p7 = self.p7(F.relu(p6))
         return [p3, p4, p5, p6, p7]
@@ -290,15 +332,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         return x
 
     def _wino(self, conv: nn.Conv2d):
-        """The conv's Winograd-transformed filter (pod_wino_filter_transform), refreshed when the parameters change."""
-        from .wino import WinoConv
-        key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
-        cached = getattr(conv, "_pod_wino", None)
-        if cached is None or cached[0] != key:
-            cached = (key, WinoConv(conv.weight, conv.bias))
-            torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
-            conv._pod_wino = cached
-        return cached[1]
+        return wino_of(conv)
 
     def _trunk_all_levels(self, convs, x0: torch.Tensor, levels, copies: int, dropout: bool):
         """`copies` evaluations of a subnet on ALL levels: one pod_wino_conv3x3 launch per conv layer (fp32 Winograd on the
