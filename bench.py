@@ -502,9 +502,9 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
             lib.pod_reset_counters(P(hp.counters), 8, st)
             evs[bidx][0].record()
             for j in range(K1B):
-                if not prune or with_score:
-                    lib.pod_reset_counters(P(hp.counters), 8, st)   # scoring appends candidates: keep the lists bounded
-                k1_call(bidx * K1B + j)
+                if not prune:
+                    lib.pod_reset_counters(P(hp.counters), 8, st)   # dense-scoring mode appends candidates: keep the lists bounded
+                k1_call(bidx * K1B + j)     # (with_score: K1b appends ~10 x 400 keys per batch into lists sized for every anchor)
             evs[bidx][1].record()
         torch.cuda.synchronize()
         lib.pod_reset_counters(P(hp.counters), int(hp.counters.numel()), st)
@@ -538,8 +538,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                        "algorithmic_bytes": k1_bytes, "avg_launch_us": 1e3 * k1_avg_ms, "min_launch_us": 1e3 * k1_min_ms,
                        "channels_streamed": "2K class channels (box_delta / box_reg_var are merged at the candidates by K2b)"
                                             if not hp.dense_box_merge else "2K+4+D",
-                       "merge_and_score": {"what": "the same algorithmic bytes over K1 + K1b back to back (SURVEY 8 a3 + a4: merge AND score"
-                                                   + ("; + one pod_reset_counters launch per pair)" if prune else ")"),
+                       "merge_and_score": {"what": "the same algorithmic bytes over K1 + K1b back to back (SURVEY 8 a3 + a4: merge AND score)",
                                            "avg_us": 1e3 * ks_avg_ms, "min_us": 1e3 * ks_min_ms,
                                            "achieved": k1_bytes / (ks_avg_ms * 1e-3) / 1e9, "frac": k1_bytes / (ks_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     # the same kernel asked for the reference-shaped dense merge of every channel (PI:211-270), for comparison
