@@ -331,6 +331,15 @@ int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* b
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                      pod_stream_t stream);
 
+/* The same convolution with every fp32 product formed on the BF16 matrix cores (experimental, opt-in; csrc/k12_wino_conv_split.hip):
+ * both operands are split exactly into three bf16 terms and the six significant partial products are accumulated in fp32
+ * (v_mfma_f32_32x32x16_bf16) -- fp32-class accuracy against an fp64 convolution at 6/16 of the fp32 MFMA's matrix-pipe cycles.
+ * Us = pod_wino_filter_transform_split(weight): 3 * 24 * round_up(K, 64) * C bf16 values.  Same arguments otherwise; C % 16 == 0. */
+int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream);
+int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
+                           int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
+                           pod_stream_t stream);
+
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set
  * in one call.  Images are concatenated: image m owns detections [det_off[m], det_off[m+1]) and ground-truth boxes

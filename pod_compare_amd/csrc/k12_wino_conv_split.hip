@@ -1,45 +1,24 @@
-// 3x3 / stride 1 / pad 1 fp32 convolution of the probabilistic RetinaNet head's subnets (probabilistic_retinanet.py:403-427:
-// four conv3x3(256 -> 256) + ReLU + Dropout per subnet, evaluated for every MC run on every FPN level) and predictors
-// (PR:430-484) as ONE launch per conv layer over all levels and all runs: fp32 Winograd on the fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32), bias + ReLU + dropout fused into the store.
-//
-// Why Winograd: a direct fp32 convolution is bounded by the 157 TFLOP/s fp32 MFMA peak (MIOpen's implicit GEMM reaches
-// 0.83 of it on the p3 maps and nothing can reach more than 1.0).  F(2,3) down the rows x F(4,3) along the columns needs
-// 4 x 6 = 24 multiply-adds per 2x4 outputs and (c, k) pair instead of 72, so the same matrix cores deliver up to 3x the
-// direct-convolution rate, in fp32 throughout.  Error vs a direct fp32 convolution: ~4e-6 of the output scale at C = 256
-// (F(2x2,3x3), the first version: 2e-6 and 16 / 36 of the multiply-adds).
-//
-//   Y = At2 [ (G4 g G6^T) . (Bt4 d Bt6^T) ] At4^T     d: 4x6 input patch, g: 3x3 filter, Y: 2x4 outputs, "." summed over c
-//
-// Data layout (channels-last): activations are [pixel][C] fp32; every (level, run) image of a launch lives in the same
-// buffer, a table of 16x16-pixel output blocks (int4 {first pixel of image 0 in `in`, in `out`, H << 16 | W,
-// n_images << 24 | by << 12 | bx}) says where.  Filters are transformed once (pod_wino_filter_transform) into the order the
-// kernel's lanes load them in.  The predictor convolutions (cls_score, bbox_pred, cls_var, bbox_cov: K = 63 / 36 / 90 real
-// channels) write NCHW planes, the layout K1 streams, straight from the staging tile.
-//
-// Workgroup = 256 threads = 4 waves, one per SIMD: 32 tiles (8 x 4 tiles of 2x4 = 16x16 output pixels) x 64 output
-// channels x the 24 Winograd positions.  Wave a owns ROW a of the 4x6 position grid for the 32 tiles and all 64 channels:
-// 6 positions x 2 channel blocks of 32x32 = 12 MFMA blocks = 192 accumulator registers.  A row of Bt4 d is one sum or
-// difference of two patch rows, then the 6-point column transform: 20 four-channel operations per chunk, and every
-// transformed value feeds two MFMAs.  Per chunk of 8 input channels (48 MFMAs per wave) the raw 18x18-pixel input patch is
-// staged in LDS by LDS-DMA (no transformed copy exists anywhere; two 12 KB stages) and the filter operands go from L2
-// straight into registers (each wave needs only its row's positions: the four waves read each slab byte once).
-// With one wave per SIMD every non-MFMA instruction costs issue time on top of the MFMA time (fp32 MFMA and the other pipes
-// do not overlap within a wave: measured), so the design minimises them: 27 memory instructions and 40 packed VALU per 48
-// MFMAs.  The output transform applies At4 to each wave's row in registers, parks the result in LDS (128 KB) and combines the
-// four rows (At2) in the store pass.
-//
-// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1.5 MB
-// for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
+// The head's 3x3 convolutions (probabilistic_retinanet.py:403-484) once more -- same Winograd F(2,3) x F(4,3) formulation, same data
+// path (patch as full 128-byte lines by LDS-DMA, filters from L2, the same prologue and epilogue) and the same results to fp32
+// rounding as pod_wino_conv3x3 (k11_wino_conv.hip) -- with every fp32 product formed on the BF16 matrix cores: both operands are
+// split exactly into three bf16 terms (x = x0 + x1 + x2, 8 significand bits each) and the six partial products that matter are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Against an fp64 reference this is as accurate as the fp32 MFMA
+// (profiles/r03_experiments.md: error constant 2.5 vs 3.1 on a K = 2304 dot product) at 6/16 of its matrix-pipe cycles: the fp32
+// MFMA of gfx950 runs at the vector rate, 1/16 of the bf16 rate.
 #include "pod_wino.h"
 
 namespace pod {
 
-// Filter transform U = G4 g G6t (4 x 6 positions: F(2,3) down the rows, F(4,3) along the columns),
-//   G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],  G6 = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]],
-// written in the order the main kernel's lanes load it:
-// U[ks][chunk][q = 6 a + p][h][j][s] = U_q[c = 8 chunk + 4 h + s][k = 64 ks + j] (16 bytes per lane and position); channels >= K are zero.
-__global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w, float* __restrict__ U, int32_t K, int32_t C, int32_t Kpad) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vu32x4 __attribute__((ext_vector_type(4)));
+constexpr int WINO_US_BYTES = 24 * 2 * 3 * 64 * 16;      // pre-split filter terms of a 16-channel chunk: [24 positions][kb][term][h][j][8 bf16]  144 KB
+constexpr int WINO_WAIT_VM18 = 0x4072;                    // lgkmcnt(0) vmcnt(18)
+
+// Filter transform U = G4 g G6t as in k_wino_filter, every value split into three bf16 terms (round to nearest: u = u0 + u1 + u2),
+// written in the order the kernel's lanes load them:
+// Us[ks][chunk16][q = 6 a + p][kb][term][h][j][e] = term(U_q[c = 16 chunk16 + 8 h + e][k = 64 ks + 32 kb + j]); channels >= K are zero.
+__global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Us, int32_t K, int32_t C, int32_t Kpad) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)Kpad * C) return;
     const int k = (int)(t / C), c = (int)(t % C);
@@ -54,9 +33,8 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
         t0[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
         t0[3][j] = g[2][j];
     }
-    const int nchunk = C / 8, ks = k >> 6, j64 = k & 63, ch = c >> 3, cc = c & 7;
-    const int h = cc >> 2, sc = cc & 3;
-    float* dst = U + ((int64_t)ks * nchunk + ch) * WINO_U_FLOATS + (h * 64 + j64) * 4 + sc;
+    const int nchunk = C / 16, ks = k >> 6, kb = (k >> 5) & 1, j32 = k & 31, ch = c >> 4, hh = (c >> 3) & 1, e = c & 7;
+    uint16_t* dst = Us + (((int64_t)ks * nchunk + ch) * (int64_t)WINO_US_BYTES) / 2 + (hh * 32 + j32) * 8 + e;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float x0 = t0[a][0], x1 = t0[a][1], x2 = t0[a][2];
@@ -68,11 +46,26 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
         u[4] = (1.0f / 24.0f) * x0 - (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
         u[5] = x2;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) dst[(a * 6 + p) * 512] = u[p];
+        for (int p = 0; p < 6; ++p) {
+            auto rne = [](float f) {                                             // fp32 -> bf16 bits in the top half, round to nearest even
+                uint32_t w = __float_as_uint(f);
+                w += 0x7FFFu + ((w >> 16) & 1u);
+                return w & 0xFFFF0000u;
+            };
+            const uint32_t b0 = rne(u[p]);
+            const float r1 = u[p] - __uint_as_float(b0);
+            const uint32_t b1 = rne(r1);
+            const float r2 = r1 - __uint_as_float(b1);
+            const uint32_t b2 = rne(r2);
+            uint16_t* d = dst + (((a * 6 + p) * 2 + kb) * 3) * 512;            // 512 bf16 = 64 lanes x 8 per (position, kb, term)
+            d[0] = (uint16_t)(b0 >> 16);
+            d[512] = (uint16_t)(b1 >> 16);
+            d[1024] = (uint16_t)(b2 >> 16);
+        }
     }
 }
 
-__global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
+__global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xcd = blockIdx.x & 7;
@@ -94,19 +87,22 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         const int pp = (((tid >> 6) * 3 + r) * 64 + (tid & 63)) >> 1, py = pp / 21, pi = pp - py * 21, px = 4 * (pi % 5) + pi / 5;
         mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
     }
-    // the filter operands of chunk 0 do not depend on the block record either: straight from L2 into registers, asked for now
-    const int nchunk = P.C >> 3;
+    // the filter operands of the first position of chunk 0 do not depend on the block record either: asked for now
+    const int nchunk = P.C >> 4;                                          // chunks of 16 input channels (one bf16 MFMA k-step)
     const int i32 = lane & 31, h = lane >> 5;
     const int a = __builtin_amdgcn_readfirstlane(wave);
-    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.U + ((int64_t)ks * nchunk) * WINO_U_FLOATS), 0,
-                                                          nchunk * WINO_U_FLOATS * 4, 0x00020000);
-    const int u_off = ((a * 6 * 2 + h) * 64 + i32) * 16;                               // + (p*2*64 + kb*32)*16 bytes, + chunk*48 KB
-    f32x4 uA[12];
-    auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
-        u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(P.U) + ((int64_t)ks * nchunk) * WINO_US_BYTES), 0,
+                                                          nchunk * WINO_US_BYTES, 0x00020000);
+    const int u_off = (a * 6 * 6 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*3 + split) KB, + chunk * 144 KB
+    vu32x4 uP[3][6];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
+                                                                          // 12 MFMAs last 384 cycles, an L2 round trip under load longer)
+    auto filter_piece = [&](int q16, int p, vu32x4(&u)[6], int i) {       // i = kb*3 + split: one buffer_load_dwordx4 (8 bf16) each
+        u[i] = __builtin_bit_cast(vu32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, q16 * WINO_US_BYTES + (p * 6 + i) * 1024, 0));
     };
 #pragma unroll
-    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
+    for (int i = 0; i < 6; ++i) filter_piece(0, 0, uP[0], i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) filter_piece(0, 1, uP[1], i);
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
@@ -146,7 +142,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // one part) then hit 16 different 16-byte bank groups -- conflict-free for every (row, column, chunk).
     const int ty = i32 >> 2, tx = i32 & 3;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
-    uint32_t areg[2][2][4];                                               // LDS byte address in stage 0: [row0 / row1][columns 0-3 / 4-5][chunk of the super-chunk]
+    uint32_t areg[2][2][2][2];                                            // LDS byte address in stage 0: [row0 / row1][columns 0-3 / 4-5][16-channel half of the super-chunk][4-channel half of the lane's 8]
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
         const int py = 2 * ty + (rs ? row1 : row0);
@@ -155,12 +151,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         for (int cl = 0; cl < 2; ++cl) {
             const int rot = ((tx + cl) & 3) + 4 * ((py >> 1) & 1);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) areg[rs][cl][c] = lds_base + p0 * 128 + ((2 * c + h + rot) & 7) * 16;
+            for (int c16 = 0; c16 < 2; ++c16)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) areg[rs][cl][c16][hf] = lds_base + p0 * 128 + ((4 * c16 + 2 * h + hf + rot) & 7) * 16;
         }
     }
-    uint32_t amini[2];                                                    // LDS byte address in mini stage 0: [row0 / row1]; column c: + ((c & 3) 5 + (c >> 2)) 32
+    uint32_t amini[2];                                                    // LDS byte address in mini stage h (the lane's 8 channels of chunk 0): [row0 / row1]; + 16: second half
 #pragma unroll
-    for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32 + h * 16;
+    for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + h * 12288 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32;
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
                                                           n_img * HWi * P.in_stride * 4, 0x00020000);
     // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
@@ -208,156 +206,182 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 12 + i) * 256), 16, doff[i], sc * 128, 0, 0);
     };
 
-    f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
+    // Between the 32-cycle bf16 MFMAs an LDS-DMA piece costs its ~100 issue cycles in full (behind the 64-cycle fp32 MFMAs most of it
+    // hides), so the K loop fills the stages through registers: every chunk loads 6 pieces (one buffer_load_dwordx4 per position) and
+    // parks the 6 it loaded a chunk earlier (ds_write_b128: free).  Stage s + 1 is written during the two chunks of super-chunk s.
+    f32x4 stg[6];
+#define WINO_STG_SLOT(p, m) ((p) == 4 && (m) == 11 ? 0 : (p) == 5 && (m) == 6 ? 1 : (p) == 5 && (m) >= 8 ? (m) - 6 : -1)
+    const uint32_t stg_addr = lds_base + a * 12288 + lane * 16;          // + stage * 48 KB + piece * 1 KB
+    auto stage_load = [&](int k, int sc, int i) {
+        stg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, doff[i], sc * 128, 0));
+    };
+    auto stage_write = [&](int par, int k, int i) {
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(stg_addr + par * (WINO_SB_FLOATS * 4) + i * 1024)) = stg[k];
+    };
 
-    f32x4 x[12], uB[12], vA[6], vB[6], t[6], w6[4];                      // x[row][c], u[p][kb] (uA: above), v[p]: 4 channels each
+    f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first product multiplies into a zero C
+    f32x4 x[12];                                                         // raw patch, one 4-channel half at a time: x[row][c]
+    vu32x4 Vb[6][3];                                                      // the transformed patch as bf16 operands: [position][split], 8 channels (regs 0-1: channels 0-3, 2-3: 4-7)
 #if POD_WINO_ELIM
 #pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = uA[i] = uB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
+    for (int i = 0; i < 18; ++i) Vb[i / 3][i % 3] = vu32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + lane};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) vA[i] = vB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane - i);
+    for (int i = 0; i < 12; ++i) x[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
 #endif
-    // 12 pieces: one ds_read_b128 each, stage par, chunk c of its super-chunk.  Issued as asm: hipcc orders every LDS read it can
-    // see behind ALL pending LDS-DMA (vmcnt(0): it cannot tell the two stages apart), which would drain the pieces flying into the
-    // other stage; so the reads are hidden from it and their completion is counted by hand (WINO_WAIT_LGKM0 before the transform).
-#define WINO_READ(par, c, i)                                                                                                        \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(areg[(i) / 6][((i) % 6) >> 2][c]), "i"((par) * WINO_SB_FLOATS * 4 + ((i) % 6) * 256))
-#define WINO_READ_MINI(which, i)                                                                                                     \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(amini[(i) / 6]), "i"((which) * 12288 + ((((i) % 6) & 3) * 5 + (((i) % 6) >> 2)) * 32))
-    // packed fp32 arithmetic on the halves of a 4-channel value: r = q * k + p
-    auto pk_fma = [](f32x2 k2, f32x2 q, f32x2 p) {
-        f32x2 r;
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(k2), "v"(q), "v"(p));
-        return r;
-    };
-    auto pk_add = [](f32x2 p, f32x2 q) {
-        f32x2 r;
-        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
-        return r;
-    };
-    auto pk_sub = [](f32x2 p, f32x2 q) {
-        f32x2 r;
-        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));
-        return r;
-    };
-    auto fma4 = [&](float k, f32x4 q, f32x4 p) {   // q * k + p
-        const f32x2 k2 = f32x2{k, k};
-        const f32x2 l = pk_fma(k2, f32x2{q.x, q.y}, f32x2{p.x, p.y}), hq = pk_fma(k2, f32x2{q.z, q.w}, f32x2{p.z, p.w});
-        return f32x4{l.x, l.y, hq.x, hq.y};
-    };
-    auto add4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_add(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_add(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
-    auto sub4 = [&](f32x4 p, f32x4 q) { const f32x2 l = pk_sub(f32x2{p.x, p.y}, f32x2{q.x, q.y}), hq = pk_sub(f32x2{p.z, p.w}, f32x2{q.z, q.w}); return f32x4{l.x, l.y, hq.x, hq.y}; };
-    // row a of V = Bt4 d Bt6^T for the lane's tile, 10 pieces of two 4-channel operations:
-    //   t_c = x0_c + s x1_c (6);  V0 = 4 t0 - 5 t2 + t4;  V5 = 4 t1 - 5 t3 + t5;  e = t4 - 4 t2, o = t3 - 4 t1: V1 = e + o, V2 = e - o;
-    //   f = t4 - t2, g = 2 (t3 - t1): V3 = f + g, V4 = f - g
-    auto transform_piece = [&](f32x4(&v)[6], int i) {
-        if (i < 3) {
+    // (reads as asm with hand-counted completion: see k11_wino_conv.hip)
+#define WINO_READ(par, c16, hf, i)                                                                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(areg[(i) / 6][((i) % 6) >> 2][c16][hf]), "i"((par) * WINO_SB_FLOATS * 4 + ((i) % 6) * 256))
+#define WINO_READ_MINI(hf, i)                                                                                                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(amini[(i) / 6]), "i"((hf) * 16 + ((((i) % 6) & 3) * 5 + (((i) % 6) >> 2)) * 32))
+#define WINO_READ12(M, ...)                                                                                                          \
+    M(__VA_ARGS__, 0); M(__VA_ARGS__, 1); M(__VA_ARGS__, 2); M(__VA_ARGS__, 3); M(__VA_ARGS__, 4); M(__VA_ARGS__, 5);                \
+    M(__VA_ARGS__, 6); M(__VA_ARGS__, 7); M(__VA_ARGS__, 8); M(__VA_ARGS__, 9); M(__VA_ARGS__, 10); M(__VA_ARGS__, 11)
+    // Row a of V = Bt4 d Bt6^T for the lane's tile and 4 channels -- the SAME operations in the same order as the fp32 kernel's
+    // packed transform (fused multiply-adds where it has them), but as scalar instructions: beside bf16 MFMAs a packed fp32
+    // instruction costs ~40 cycles (tools/mfma_bf16_split.hip), an ordinary one nothing --, then every value split into three bf16
+    // terms by round-to-nearest (v = v0 + v1 + v2 to 2^-26 |v|; truncation would make the dropped partial products one-signed: a bias
+    // the Winograd cancellation amplifies -- measured) and packed pairwise into half hf of Vb.
+    auto make_v = [&](int hf) __attribute__((always_inline)) {
+        if (POD_WINO_ELIM & 8) return;
+        f32x4 t[6], v[6];
 #pragma unroll
-            for (int c = 2 * i; c < 2 * i + 2; ++c) t[c] = fma4(sgn, x[6 + c], x[c]);
-        } else if (i == 3) {
-            w6[0] = fma4(-5.0f, t[2], t[4]);          // t4 - 5 t2
-            w6[1] = fma4(-5.0f, t[3], t[5]);          // t5 - 5 t3
-        } else if (i == 4) {
-            v[0] = fma4(4.0f, t[0], w6[0]);
-            v[5] = fma4(4.0f, t[1], w6[1]);
-        } else if (i == 5) {
-            w6[0] = fma4(-4.0f, t[2], t[4]);          // e
-            w6[1] = fma4(-4.0f, t[1], t[3]);          // o
-        } else if (i == 6) {
-            v[1] = add4(w6[0], w6[1]);
-            v[2] = sub4(w6[0], w6[1]);
-        } else if (i == 7) {
-            w6[2] = sub4(t[4], t[2]);                 // f
-            w6[3] = sub4(t[3], t[1]);                 // g / 2
-        } else if (i == 8) {
-            v[3] = fma4(2.0f, w6[3], w6[2]);
-        } else if (i == 9) {
-            v[4] = fma4(-2.0f, w6[3], w6[2]);
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sgn, x[6 + c][e], x[c][e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w0 = __builtin_fmaf(-5.0f, t[2][e], t[4][e]), w1 = __builtin_fmaf(-5.0f, t[3][e], t[5][e]);
+            v[0][e] = __builtin_fmaf(4.0f, t[0][e], w0);
+            v[5][e] = __builtin_fmaf(4.0f, t[1][e], w1);
+            const float ev = __builtin_fmaf(-4.0f, t[2][e], t[4][e]), od = __builtin_fmaf(-4.0f, t[1][e], t[3][e]);
+            v[1][e] = ev + od;
+            v[2][e] = ev - od;
+            const float f = t[4][e] - t[2][e], g = t[3][e] - t[1][e];
+            v[3][e] = __builtin_fmaf(2.0f, g, f);
+            v[4][e] = __builtin_fmaf(-2.0f, g, f);
+        }
+        // the three terms of the 12 channel pairs, STAGE by stage (12 independent instructions per stage: a pair's own chain is
+        // cvt -> shift / mask -> subtract -> cvt -> ..., nine dependent steps; depth-first they wait for each other's latency)
+        f32x2 vv[12], r1[12], r2[12];
+        uint32_t w0[12], w1[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) vv[i] = f32x2{v[i >> 1][2 * (i & 1)], v[i >> 1][2 * (i & 1) + 1]};           // pair i = (position i / 2, channels 2 (i & 1) ..)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w0[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv[i], bf16x2));   // v_cvt_pk_bf16_f32: nearest even, packed
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r1[i] = f32x2{__builtin_bit_cast(float, w0[i] << 16), __builtin_bit_cast(float, w0[i] & 0xFFFF0000u)};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r1[i] = vv[i] - r1[i];                                                        // exact
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w1[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1[i], bf16x2));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r2[i] = f32x2{__builtin_bit_cast(float, w1[i] << 16), __builtin_bit_cast(float, w1[i] & 0xFFFF0000u)};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r2[i] = r1[i] - r2[i];                                                        // exact
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            Vb[i >> 1][0][2 * hf + (i & 1)] = w0[i];
+            Vb[i >> 1][1][2 * hf + (i & 1)] = w1[i];
+            Vb[i >> 1][2][2 * hf + (i & 1)] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2[i], bf16x2));
         }
     };
 
-    // One chunk = 8 input channels = 48 MFMAs (k-step j / 12 = channel of the lane's four, accumulator j % 12 = (p, kb)) with the next
-    // chunk's work slotted behind them, at most one memory instruction per MFMA (the order is pinned in the source: the four waves
-    // of the workgroup run in lock step, memory instructions issued in a burst queue behind each other and stall the in-order
-    // instruction streams): patch reads of chunk ch+1 (LDS), filter loads of chunk ch+1 (L2), its transform, and a quarter of the
-    // LDS-DMA of a later SUPER-CHUNK (4 chunks, two stages).  Chunk c of super-chunk s reads stage s & 1 (c = 3: the first chunk of
-    // s + 1 from the other stage).  Super-chunk s + 1 is fetched into the stage s - 1 left behind, 4 instructions per wave during
-    // each of the chunks (s-1, 3), (s, 0), (s, 1) -- every piece has a whole chunk to land before the barrier that publishes it.
-#define WINO_MFMA(V, U, j)                                                                                                   \
-    acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[(j) % 12][(j) / 12], V[((j) % 12) >> 1][(j) / 12], acc[(j) % 12], 0, 0, 0)
-    const int last = nchunk - 1, last_s = last >> 2;
+    // One chunk = 16 input channels = one k-step of v_mfma_f32_32x32x16_bf16.  Every fp32 product x * u is formed from the three bf16
+    // terms of each operand: the 6 partial products that matter (x1u1, x0u2, x2u0, x0u1, x1u0, x0u0: small ones first), fp32 accumulate --
+    // against fp64 as accurate as the fp32 MFMA (profiles/r03_experiments.md), at 6/16 of its matrix-pipe cycles.  72 MFMAs per
+    // chunk: positions p = 0..5 of the wave's row, two channel blocks, 6 products; the filter terms of position p + 1 (6 x 16 B per lane,
+    // pre-split, from L2) are loaded behind the first six MFMAs of position p.  The patch of the NEXT chunk is read from LDS behind the
+    // last three positions (first half) and transformed + split between the chunks (the second half behind the first's arithmetic).
+    // Super-chunk s + 1 (32 channels) is fetched by LDS-DMA into the stage s - 1 left behind during the SECOND chunk of s - 1, after a
+    // mid-chunk barrier (every wave has read that stage), and published by the barrier that ends the first chunk of s.
+    const int last = nchunk - 1, last_s = last >> 1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) mini_piece(0, r);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) mini_piece(last < 1 ? 0 : 1, r);
+    for (int r = 0; r < 3; ++r) mini_piece(1, r);
     WINO_STAMP(9);
     main_offsets();                                    // (behind the first loads: their latency hides it)
     WINO_STAMP(10);
 #pragma unroll
     for (int i = 0; i < 12; ++i) patch_piece(lds, 0, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) patch_piece(lds + WINO_SB_FLOATS, last_s < 1 ? last_s : 1, i);
+    for (int i = 0; i < 6; ++i) stage_load(i, last_s < 1 ? last_s : 1, i);      // (chunk 0 parks them in stage 1)
     WINO_STAMP(11);
-    __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM16);        // the mini stages and the filters of chunk 0 have landed; the 16 pieces of the stages fly on
+    __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM18);        // the mini stages and the first filter terms have landed; stage 0's 12 pieces and 6 of stage 1's fly on
     __builtin_amdgcn_s_barrier();
     WINO_STAMP(1);
-    WINO_READ_MINI(0, 0); WINO_READ_MINI(0, 1); WINO_READ_MINI(0, 2); WINO_READ_MINI(0, 3); WINO_READ_MINI(0, 4); WINO_READ_MINI(0, 5);
-    WINO_READ_MINI(0, 6); WINO_READ_MINI(0, 7); WINO_READ_MINI(0, 8); WINO_READ_MINI(0, 9); WINO_READ_MINI(0, 10); WINO_READ_MINI(0, 11);
+    WINO_READ12(WINO_READ_MINI, 0);
     __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef POD_WINO_DEBUG_X
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(P.out + (tid * 12 + i) * 4) = x[i];
-    }
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < 10; ++i) transform_piece(vA, i);
-    // the transform's packed instructions are asm: hipcc neither pads the VALU-write -> MFMA-operand hazard behind them nor keeps the
-    // first MFMA from being scheduled up among them (it reads a stale operand then: measured) -- fence and pad by hand
+    make_v(0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 1");
+    WINO_READ12(WINO_READ_MINI, 1);
+    __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+    __builtin_amdgcn_sched_barrier(0);
+    make_v(1);
+    __builtin_amdgcn_sched_barrier(0);
     WINO_STAMP(2);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto chunk = [&](auto first, auto c_t, auto par_t, int sc, f32x4(&vC)[6], f32x4(&uC)[12], f32x4(&vN)[6], f32x4(&uN)[12]) {
-        constexpr int c = decltype(c_t)::value, par = decltype(par_t)::value;
-        constexpr int rc = (c + 1) & 3, rpar = c == 3 ? par ^ 1 : par;            // what the reads fetch: the NEXT chunk's patch
-        constexpr int ph = c == 3 ? 0 : c + 1, dpar = c == 3 ? par : par ^ 1;     // fill phase (c == 2: none) and the stage being filled
-        const int ch = 4 * sc + c, c1 = ch + 1 < nchunk ? ch + 1 : last;
-        const int fs0 = c == 3 ? sc + 2 : sc + 1, fs = fs0 < last_s ? fs0 : last_s;
-        float* wr = lds + dpar * WINO_SB_FLOATS;
+    // chunk q = (super-chunk q >> 1, half c16 = q & 1), stage parity par = (q >> 1) & 1
+    auto chunk = [&](auto first, auto c16_t, auto par_t, int q) {
+        constexpr int c16 = decltype(c16_t)::value, par = decltype(par_t)::value;
+        constexpr bool fill = decltype(first)::value || c16 == 1;                  // the next chunk reads a stage this chunk's barrier publishes: no read-ahead
+        constexpr int n16 = c16 ^ 1, npar = c16 == 1 ? par ^ 1 : par;             // the NEXT chunk's half and stage
+        const int qn = q + 1 <= last ? q + 1 : last;
+        // this chunk parks pieces 6 c16 .. 6 c16 + 5 of super-chunk s + 1 (loaded a chunk ago) in the other stage and loads the next six:
+        // 6 .. 11 of s + 1 (c16 = 0) or 0 .. 5 of s + 2 (c16 = 1)
+        const int ls0 = (q >> 1) + 1 + c16, ls = ls0 < last_s ? ls0 : last_s;
         wino_static_for([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
-            if constexpr (decltype(first)::value && j < 12) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uC[j][0], vC[j >> 1][0], zero16, 0, 0, 0);
-            else WINO_MFMA(vC, uC, j);
-            if constexpr (j < 12) {
-                if constexpr (decltype(first)::value) WINO_READ_MINI(1, j);                  // chunk 1's patch: the second mini stage
-                else if (!(POD_WINO_ELIM & 1)) WINO_READ(rpar, rc, j);
+            constexpr int j = decltype(J)::value, p = j / 12, m = j % 12, kb = m & 1, prod = m >> 1;
+            constexpr int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;      // filter term of the product
+            constexpr int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;   // patch term
+            if constexpr (decltype(first)::value && prod == 0)
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), zero16, 0, 0, 0);
+            else
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
+            if constexpr (m < 6) { if (!(POD_WINO_ELIM & 2)) filter_piece(p >= 4 ? qn : q, (p + 2) % 6, uP[(p + 2) % 3], m); }
+            else if constexpr (m == 7) { if (!(POD_WINO_ELIM & 4)) stage_write(par ^ 1, p, 6 * c16 + p); }
+            else if constexpr (WINO_STG_SLOT(p, m) >= 0) {       // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
+                if (!(POD_WINO_ELIM & 4)) stage_load(WINO_STG_SLOT(p, m), ls, 6 * (c16 ^ 1) + WINO_STG_SLOT(p, m));      // order, and every filter term ahead is needed soon
+            } else if constexpr (!decltype(first)::value && !fill && p >= 1 && p <= 4 && m >= 8 && m <= 10) {   // the next chunk's first half (its stage is published)
+                if (!(POD_WINO_ELIM & 1)) WINO_READ(npar, n16, 0, (p - 1) * 3 + m - 8);
             }
-            else if constexpr (j < 24) { if (!(POD_WINO_ELIM & 2)) filter_piece(c1, uN, j - 12); }
-            else if constexpr (j == 24) __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);         // the 12 reads (issued 12+ MFMAs ago)
-            else if constexpr (j >= 25 && j < 35) { if (!(POD_WINO_ELIM & 8)) transform_piece(vN, j - 25); }
-            else if constexpr (j >= 36 && j <= 45 && (j - 36) % 3 == 0) { if (c != 2 && !(POD_WINO_ELIM & 4)) patch_piece(wr, fs, 4 * ph + (j - 36) / 3); }
             __builtin_amdgcn_sched_barrier(0);
-        }, std::make_integer_sequence<int, 48>{});
-        if (!(POD_WINO_ELIM & 16)) {
-            // the filters of the next chunk and every patch piece issued before this chunk have landed; this chunk's 4 pieces may fly on
-            __builtin_amdgcn_s_waitcnt((POD_WINO_VAR & 16) ? WINO_WAIT_VM16 : c != 2 && !(POD_WINO_VAR & 2) ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
-            __builtin_amdgcn_s_barrier();
-        }
+        }, std::make_integer_sequence<int, 72>{});
+        // No vmcnt wait: the stage the next reads touch was filled two chunks ago, and loads return in order -- the filter terms this
+        // chunk's MFMAs consumed were issued AFTER those pieces, so the pieces have landed; the barrier publishes them.  The filter terms
+        // of the next chunk's first positions may fly on through the arithmetic below (hipcc waits for them where they are used).
+        __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+        __builtin_amdgcn_s_barrier();
+        if (q >= last) return;
+        if constexpr ((decltype(first)::value || fill) && !(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 0);     // (not read ahead: the stage was published only now)
+        __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+        __builtin_amdgcn_sched_barrier(0);
+        make_v(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 1);
+        __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+        __builtin_amdgcn_sched_barrier(0);
+        make_v(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // (no second barrier: the stage these reads touched is next written two chunks on, behind two chunk-end barriers)
     };
     using std::integral_constant;
-    chunk(std::true_type{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, 0, vA, uA, vB, uB);
-    for (int base = 0;; base += 8) {
+    chunk(std::true_type{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, 0);
+    for (int base = 0;; base += 4) {
 #define WINO_CHUNK(t)                                                                                                              \
     if (base + (t) >= nchunk) break;                                                                                               \
-    if ((t) & 1) chunk(std::false_type{}, integral_constant<int, (t) & 3>{}, integral_constant<int, ((t) >> 2) & 1>{}, (base + (t)) >> 2, vB, uB, vA, uA); \
-    else chunk(std::false_type{}, integral_constant<int, (t) & 3>{}, integral_constant<int, ((t) >> 2) & 1>{}, (base + (t)) >> 2, vA, uA, vB, uB);
-        WINO_CHUNK(1) WINO_CHUNK(2) WINO_CHUNK(3) WINO_CHUNK(4) WINO_CHUNK(5) WINO_CHUNK(6) WINO_CHUNK(7) WINO_CHUNK(8)
+    chunk(std::false_type{}, integral_constant<int, (t) & 1>{}, integral_constant<int, ((t) >> 1) & 1>{}, base + (t));
+        WINO_CHUNK(1) WINO_CHUNK(2) WINO_CHUNK(3) WINO_CHUNK(4)
 #undef WINO_CHUNK
     }
-#undef WINO_MFMA
     __syncthreads();                                   // every wave is done reading the stages, no DMA in flight: they become the output staging
     WINO_STAMP(3);
 
@@ -500,7 +524,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 }  // namespace pod
 
 #ifdef POD_TRACE
-extern "C" int pod_wino_trace_dump(long long* host, int32_t n_workgroups) {   // diagnostics build only (not in include/pod_mi355x.h)
+extern "C" int pod_wino_trace_dump_split(long long* host, int32_t n_workgroups) {   // diagnostics build only
     if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
     if (n_workgroups > 8192) n_workgroups = 8192;
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pod::g_wino_trace), (size_t)n_workgroups * 16 * sizeof(long long)) != hipSuccess) return POD_E_LAUNCH;
@@ -508,47 +532,47 @@ extern "C" int pod_wino_trace_dump(long long* host, int32_t n_workgroups) {   //
 }
 #endif
 
-extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream) {
-    if (!weight || !U || K < 1 || C < 8 || (C & 7) != 0) return POD_E_INVALID;
+extern "C" int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream) {
+    if (!weight || !Us || K < 1 || C < 16 || (C & 15) != 0) return POD_E_INVALID;
     const int32_t Kpad = (K + 63) / 64 * 64;
     const int64_t n = (int64_t)Kpad * C;
-    hipLaunchKernelGGL(pod::k_wino_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, U, K, C, Kpad);
+    hipLaunchKernelGGL(pod::k_wino_filter_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       reinterpret_cast<uint16_t*>(Us), K, C, Kpad);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
 
-extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                                int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                                pod_stream_t stream) {
-    if (!in || !out || in == out || !U || !blocks || n_blocks < 0 || C < 8 || (C & 7) != 0 || K < 64 || (K & 63) != 0 ||
+extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
+                                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
+                                      pod_stream_t stream) {
+    if (!in || !out || in == out || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0 ||
         !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
         return POD_E_INVALID;
     const int32_t KS = K / 64;
     if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
-    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) |
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Us) |
           reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
         return POD_E_INVALID;
     if (n_blocks == 0) return POD_OK;
-    // the 130 KB dynamic-LDS opt-in is a PER-DEVICE function attribute: once per device ordinal this process launches on
     static std::once_flag once[64];
     static hipError_t attr[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
     std::call_once(once[dev], [dev] {
-        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3_split), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         pod::WINO_LDS_BYTES);
     });
     if (attr[dev] != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
-    P.in = in; P.out = out; P.U = U; P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
+    P.in = in; P.out = out; P.U = reinterpret_cast<const float*>(Us); P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
+    const int per8 = 8 / KS;
     const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

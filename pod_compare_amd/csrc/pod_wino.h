@@ -1,0 +1,85 @@
+// Shared by the two Winograd convolution kernels (k11_wino_conv.hip: fp32 MFMA; k12_wino_conv_split.hip: the same convolution with
+// every fp32 product formed from 3-way bf16 splits on the bf16 matrix cores): parameters, LDS geometry, the slot table of the stage
+// fills, wait immediates, diagnostics hooks.
+#pragma once
+#include <mutex>
+#include <type_traits>
+#include <utility>
+
+#include "pod_device.h"
+
+namespace pod {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k8_model_ops.hip: same mask as pod_bias_act
+
+constexpr int WINO_U_FLOATS = 24 * 2 * 64 * 4;          // filter slab of a chunk: [24 positions][h][j][4 channels]  48 KB
+constexpr int WINO_SB_FLOATS = 384 * 32;                 // raw patch stage of a SUPER-CHUNK (32 input channels): [pixel slot 360 (+24: 48 whole DMA instructions)][8 parts of 16 B], 48 KB
+constexpr int WINO_LDS_BYTES = 4 * 32 * 4 * 65 * 4;      // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
+
+// -DPOD_TRACE (diagnostics build, tools/wino_trace.py): s_memtime stamps of every workgroup's phases
+#ifdef POD_TRACE
+static __device__ long long g_wino_trace[8192 * 16];
+#define WINO_STAMP(k)                                                                                          \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define WINO_STAMP_WALL(k)                                                                                     \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 16 + (k)] = wall_clock64();       \
+    } while (0)
+#else
+#define WINO_STAMP(k)
+#define WINO_STAMP_WALL(k)
+#endif
+
+// -DPOD_WINO_ELIM=<bits> (tagged experiment builds only, tools/wino_elim.sh): parts of the kernel compiled out to price them --
+// results are then wrong, only the time is of interest.  1 patch reads, 2 filter loads, 4 patch DMA, 8 input transform,
+// 16 chunk barrier, 32 store pass, 64 dropout mask, 128 accumulator dump + store pass.
+#ifndef POD_WINO_ELIM
+#define POD_WINO_ELIM 0
+#endif
+#ifndef POD_WINO_VAR
+#define POD_WINO_VAR 0
+#endif
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14): lgkmcnt(0) with vmcnt(4) / vmcnt(0)
+constexpr int WINO_WAIT_VM4 = 0x0074, WINO_WAIT_VM0 = 0x0070, WINO_WAIT_VM16 = 0x4070, WINO_WAIT_LGKM0 = 0xC07F;
+
+struct WinoParams {
+    const float* in;
+    float* out;
+    const float* U;
+    const float* bias;
+    const int4* blocks;
+    int32_t n_blocks, C, K, KS, in_stride, out_stride, relu, k_planes;   // k_planes > 0: NCHW planes of k_planes real channels
+    uint32_t thresh;
+    float scale;
+    uint64_t seed, offset;
+};
+
+
+// What lane l3 = pixel slot, q = sub-slot of an LDS-DMA instruction fetches (see the layout in the kernel): per pixel slot 0..383
+// (py 18 + px) | rot << 16 (pixel 324: the slot holds no pixel), computed at compile time.
+struct WinoSlotTable {
+    uint32_t v[384];
+    constexpr WinoSlotTable() : v() {
+        for (int p = 0; p < 384; ++p) {
+            const int cls = p & 1, k = p >> 1, rr = k / 18, px = k - rr * 18;
+            const int py = cls ? (rr < 4 ? rr + 4 : rr + 8) : (rr < 4 ? rr : rr < 8 ? rr + 4 : rr + 8);
+            const bool ok = cls ? rr < 8 : rr < 10;
+            v[p] = ok ? (uint32_t)((py * 18 + px) | ((((px >> 2) & 3) + 4 * ((py >> 1) & 1)) << 16)) : 324u;
+        }
+    }
+};
+static __device__ const WinoSlotTable g_wino_slots{};
+
+template <typename F, int... Js>
+__device__ __forceinline__ void wino_static_for(F&& f, std::integer_sequence<int, Js...>) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+
+
+}  // namespace pod

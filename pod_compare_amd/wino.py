@@ -1,6 +1,7 @@
 """Host side of pod_wino_conv3x3 (csrc/k11_wino_conv.hip): the head subnets' 3x3 convolutions (probabilistic_retinanet.py:403-427)
 over all FPN levels and all MC runs in one launch.  Channels-last activations, every (level, run) image in one
 [pixel][C] buffer; `block_table` lists the 16x16-pixel output blocks of all images.  GPU only: there is no CPU path."""
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -85,20 +86,31 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
     return t
 
 
+# POD_WINO_SPLIT=1: pod_wino_conv3x3_split (csrc/k12_wino_conv_split.hip) where the channel count allows it (C % 16 == 0): the same
+# convolution with every fp32 product formed from exact 3-way bf16 splits on the bf16 matrix cores (fp32-class accuracy, see its header)
+SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "0") == "1"
+
+
 class WinoConv:
     """One conv3x3(C -> K, stride 1, pad 1) with its filter transformed once.  K is padded to a multiple of 64 with zero
     filters (outputs written for the padded channels are zero + nothing: bias is padded with zeros too)."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], split: Optional[bool] = None):
         assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
         self.K, self.C = int(weight.shape[0]), int(weight.shape[1])
         self.Kpad = (self.K + 63) // 64 * 64
         if self.C % 8 or self.Kpad not in (64, 128, 256, 512):
             raise ValueError("pod_wino_conv3x3: C %% 8 == 0 and K <= 512 in steps of 64 required, got C=%d K=%d" % (self.C, self.K))
         lib = hip.load()
-        self.U = torch.empty(24 * self.Kpad * self.C, dtype=torch.float32, device=weight.device)
-        hip.check(lib.pod_wino_filter_transform(weight.detach().contiguous().data_ptr(), self.U.data_ptr(), self.K, self.C, hip.current_stream()),
-                  "pod_wino_filter_transform")
+        self.split = (SPLIT_BF16 if split is None else bool(split)) and self.C % 16 == 0
+        if self.split:      # three bf16 terms per transformed filter value, in the split kernel's load order
+            self.U = torch.empty(3 * 24 * self.Kpad * self.C, dtype=torch.int16, device=weight.device)
+            hip.check(lib.pod_wino_filter_transform_split(weight.detach().contiguous().data_ptr(), self.U.data_ptr(), self.K, self.C,
+                                                          hip.current_stream()), "pod_wino_filter_transform_split")
+        else:
+            self.U = torch.empty(24 * self.Kpad * self.C, dtype=torch.float32, device=weight.device)
+            hip.check(lib.pod_wino_filter_transform(weight.detach().contiguous().data_ptr(), self.U.data_ptr(), self.K, self.C, hip.current_stream()),
+                      "pod_wino_filter_transform")
         self.bias = None
         if bias is not None:
             self.bias = torch.zeros(self.Kpad, dtype=torch.float32, device=weight.device)
@@ -111,7 +123,8 @@ class WinoConv:
         NCHW images with K (real) planes each, level-major like the table's output side."""
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and src.dtype == dst.dtype == torch.float32
         assert planes or dst.shape[-1] == self.Kpad
-        hip.check(hip.load().pod_wino_conv3x3(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
-                                              table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
-                                              seed, offset, hip.current_stream()), "pod_wino_conv3x3")
+        fn = hip.load().pod_wino_conv3x3_split if self.split else hip.load().pod_wino_conv3x3
+        hip.check(fn(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
+                     table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
+                     seed, offset, hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
         return dst

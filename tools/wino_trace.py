@@ -28,8 +28,9 @@ torch.cuda.synchronize()
 n_wg = tab.shape[0] * 4
 lib = ctypes.CDLL(hip.library_path())
 host = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
-lib.pod_wino_trace_dump.argtypes = [ctypes.c_void_p, ctypes.c_int32]
-assert lib.pod_wino_trace_dump(host.ctypes.data, host.shape[0]) == 0
+dump = lib.pod_wino_trace_dump_split if conv.split else lib.pod_wino_trace_dump
+dump.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+assert dump(host.ctypes.data, host.shape[0]) == 0
 t = host[:, :6]
 live = t[:, 5] > 0
 t = t[live]
@@ -43,6 +44,12 @@ if host[live, 8].any():
     for nm, i0, i1 in (("  record arrived", 0, 8), ("  mini + filter loads issued", 8, 9), ("  stage offsets", 9, 10), ("  16 stage pieces issued", 10, 11), ("  wait + barrier", 11, 1)):
         d = e[:, i1] - e[:, i0]
         print("  %-28s %8.0f %8.0f %8.0f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+if host[live, 13].any():       # constant-rate 100 MHz stamps at both ends of a workgroup: the shader clock the kernel really ran at
+    e = host[live]
+    wall_ns = (e[:, 13] - e[:, 12]) * 10.0
+    cyc = e[:, 5] - e[:, 0]
+    print("  workgroup wall time %.1f us median; shader clock = cycles / wall = %.3f GHz" % (np.median(wall_ns) / 1e3, np.median(cyc / wall_ns)))
+    print("  launch span by the 100 MHz clock: %.3f ms" % ((e[:, 13].max() - e[:, 12].min()) * 1e-5))
 tot = t[:, 5] - t[:, 0]
 print("  %-20s %8.0f %8.0f %8.0f" % ("workgroup total", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
 span = t[:, 5].max() - t[:, 0].min()
