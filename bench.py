@@ -55,6 +55,7 @@ CONFIGS = {
 FRAME_HW = (720, 1280)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak (no xf32 / tf32 on gfx950)
+BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (16 x the fp32 rate)
 
 
 def k1_algorithmic_bytes(R, K, D, N, has_cls_var, quirk, dense_box=True):
@@ -84,6 +85,9 @@ def parse_args():
                     help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="head / backbone 3x3 convolutions on pod_wino_conv3x3_split (fp32 products from 3-way bf16 splits on the bf16 "
+                         "matrix cores) instead of the fp32-MFMA kernel; without the flag that kernel is measured as a second leg (`split_bf16`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the K1 / conv / NLL / worst-case legs after the timed region")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
@@ -185,10 +189,10 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
     table = wino.block_table(levels, copies, dev)
     src = torch.randn(table.pod_pixels, conv.C, device=dev)
     dst = torch.empty(table.pod_pixels, conv.Kpad, device=dev)
-    for _ in range(2):
+    for _ in range(8):          # (the chip needs a few launches of this kernel to settle its clock)
         conv(src, dst, table, relu=True, dropout_p=head.dropout_rate, seed=1, offset=0)
     torch.cuda.synchronize()
-    B, nb = 4, 6
+    B, nb = 8, 6
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nb)]
     torch.cuda._sleep(3_000_000)
     for a, b in evs:
@@ -200,7 +204,8 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
     ms = sorted(a.elapsed_time(b) / B for a, b in evs)
     avg = sum(ms) / len(ms)
     tiles = copies * sum(((h + 1) // 2) * ((w + 3) // 4) for h, w in levels)        # 2 x 4 output tiles, 24 Winograd positions each
-    mfma_flop = 2.0 * 24 * tiles * conv.C * conv.K
+    mfma_flop = 2.0 * 24 * tiles * conv.C * conv.K * (6 if conv.split else 1)      # split kernel: 6 bf16 partial products per fp32 product
+    peak = BF16_MFMA_PEAK_TF if conv.split else FP32_MFMA_PEAK_TF
     direct_flop = 2.0 * 9 * table.pod_pixels * conv.C * conv.K
     traffic = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wino_traffic.json")), reverse=True):
@@ -208,9 +213,11 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
         if t.get("levels") == [list(x) for x in levels] and t.get("copies") == copies:
             traffic = t.get("traffic_bytes")
             break
-    return {"kernel": "pod_wino_conv3x3 (k_wino_conv3x3): conv3x3 256->256 + bias + ReLU + dropout, %d runs x %d levels in one launch" % (copies, len(levels)),
-            "bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TF, "achieved": mfma_flop / avg / 1e9,
-            "frac": mfma_flop / avg / 1e9 / FP32_MFMA_PEAK_TF, "direct_equivalent_tflops": direct_flop / avg / 1e9,
+    return {"kernel": "%s: conv3x3 256->256 + bias + ReLU + dropout, %d runs x %d levels in one launch" % (
+                "pod_wino_conv3x3_split (k_wino_conv3x3_split, bf16 matrix cores: 6 partial products per fp32 product)" if conv.split
+                else "pod_wino_conv3x3 (k_wino_conv3x3, fp32 matrix cores)", copies, len(levels)),
+            "bound": "mfma", "unit": "TFLOP/s", "peak": peak, "achieved": mfma_flop / avg / 1e9,
+            "frac": mfma_flop / avg / 1e9 / peak, "direct_equivalent_tflops": direct_flop / avg / 1e9,
             "algorithmic_flop": mfma_flop, "direct_flop": direct_flop, "avg_launch_us": 1e3 * avg, "min_launch_us": 1e3 * ms[0],
             "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 32, "traffic": traffic,
             "share_of_step": "12 launches of this kernel are ~93 % of a step's GPU time (conv_roofline.by_kind)"}
@@ -271,6 +278,8 @@ def main():
     stage = (lambda t: t.cpu()) if backend != "nccl" else (lambda t: t)
     spec = CONFIGS[args.config]
     N = spec["runs"]
+    from pod_compare_amd import wino
+    wino.SPLIT_BF16 = bool(args.split_bf16)
     rank_devices = [local_rank]
     if world > 1:
         # one process per GPU: every rank must sit on a device of its own (PCI bus id, not just the ordinal: two ranks that both see
@@ -401,12 +410,30 @@ def main():
         per_rank = [args.steps / float(x[2]) for x in tl]
         host_enqueue_ms = max(float(x[3]) for x in tl)
     n_det_mean = float(torch.stack([d.n_det for d in dets]).float().mean().item())
+    second = None
+    if world == 1 and not args.no_diagnostics and not args.no_cnn and len(members) == 1 and modeling.WINO_HEAD:
+        # second leg, same steps, the OTHER convolution kernel (never `value`): pod_wino_conv3x3_split when the headline ran on the
+        # fp32-MFMA kernel and vice versa
+        wino.SPLIT_BF16 = not args.split_bf16
+        k2 = max(10, min(args.steps, 60))
+        with torch.no_grad():
+            for i in range(2 * n_streams + 4):       # filter transforms of the other kernel, solver caches
+                step(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(k2):
+                step(i)
+            torch.cuda.synchronize()
+            second = {"kernel": "pod_wino_conv3x3_split" if wino.SPLIT_BF16 else "pod_wino_conv3x3", "steps": k2,
+                      "value": k2 / (time.perf_counter() - t2), "unit": "images/s"}
+        wino.SPLIT_BF16 = bool(args.split_bf16)
 
     out = {
         "metric": "images/sec (BayesOD+MC-dropout, 1280x720)" if args.config == "cfg3" else "images/sec (%s, 1280x720)" % spec["mode"],
         "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
+        "dtype": "f32" if not args.split_bf16 else "f32 (3x3 convolutions: every product from 3-way bf16 splits of both operands, fp32 accumulate)",
+        "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
         "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
                    "classes": params.num_classes, "synthetic_mode": args.synth, "planted_boxes": args.boxes, "conv_net_in_timed_region": not args.no_cnn,
                    "conv_net_output": "computed and timed, then discarded: the hot path consumes planted head tensors (random-init "
@@ -418,10 +445,13 @@ def main():
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
                    "rccl_ranks": world, "collective_backend": backend if world > 1 else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
+                   "conv3x3_kernel": "pod_wino_conv3x3_split (bf16 matrix cores, 3-way splits)" if args.split_bf16 else "pod_wino_conv3x3 (fp32 matrix cores)",
                    "rng": "in-kernel Philox4x32-10, fresh key per image"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if world > 1 else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "mean_detections": n_det_mean,
     }
+    if second is not None:
+        out["split_bf16" if second["kernel"].endswith("_split") else "fp32_mfma"] = second
     if rank == 0 and not args.no_diagnostics:
         diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev, R, N, D, mc)
     if rank == 0:
@@ -561,6 +591,13 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                                       "avg_launch_us", "merge_and_score")}
         out["k1_hbm_frac"], out["k1_merge_and_score_hbm_frac"] = k1r["frac"], k1r["merge_and_score"]["frac"]
         out["roofline_head_conv"] = out["roofline"]
+        other = "split_bf16" if not args.split_bf16 else "fp32_mfma"
+        if other in out:          # the same launch on the other kernel, for the second leg's record
+            from pod_compare_amd import wino as _w
+            _w.SPLIT_BF16 = not args.split_bf16
+            r2 = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
+            _w.SPLIT_BF16 = bool(args.split_bf16)
+            out[other]["head_conv_launch"] = {k: r2[k] for k in ("kernel", "peak", "achieved", "frac", "direct_equivalent_tflops", "avg_launch_us", "min_launch_us")}
 
     # ---- the whole conv net of a step against the fp32 MFMA peak ---------------------------------------------
     if not args.no_cnn and spec.get("members", 1) == 1:

@@ -157,8 +157,9 @@ NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run chan
 
 def wino_of(conv: nn.Conv2d):
     """The conv's Winograd-transformed filter (pod_wino_filter_transform), refreshed when the parameters change."""
+    from . import wino
     from .wino import WinoConv
-    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version), wino.SPLIT_BF16)
     cached = getattr(conv, "_pod_wino", None)
     if cached is None or cached[0] != key:
         cached = (key, WinoConv(conv.weight, conv.bias))

@@ -32,9 +32,12 @@ def make(levels, copies, C, K, seed=0):
     ([(45, 80), (6, 10)], 2, 256, 256),                       # the head's channel counts
     ([(20, 24)], 1, 32, 512),
 ])
-def test_channels_last_output_equals_conv2d(levels, copies, C, K):
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+def test_channels_last_output_equals_conv2d(levels, copies, C, K, split):
+    """split: pod_wino_conv3x3_split (3-way bf16 splits on the bf16 matrix cores; needs C % 16 == 0, else the fp32 kernel serves)."""
     w, b, xs = make(levels, copies, C, K)
-    conv = WinoConv(w, b)
+    conv = WinoConv(w, b, split=split)
+    assert conv.split == (split and C % 16 == 0)
     src = flat(xs)
     dst = torch.full((src.shape[0], K), float("nan"), device="cuda")
     conv(src, dst, block_table(levels, copies, "cuda"), relu=True)
@@ -46,13 +49,14 @@ def test_channels_last_output_equals_conv2d(levels, copies, C, K):
         assert float((got - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
 @pytest.mark.parametrize("K", [63, 36, 90])
-def test_predictor_planes_of_a_subset_of_the_runs(K):
+def test_predictor_planes_of_a_subset_of_the_runs(K, split):
     """cls_score / bbox_pred / bbox_cov shapes: K real channels (padded to 64 / 128 inside), NCHW planes out, reading runs
     first .. first+count-1 of a buffer of 5 runs per level, writing a buffer of 4 runs per level whose last run stays as it was."""
     levels, in_copies, first, count, out_copies = [(23, 40), (12, 20), (6, 10), (3, 5)], 5, 2, 3, 4
     w, b, xs = make(levels, in_copies, 64, K, seed=K)
-    conv = WinoConv(w, b)
+    conv = WinoConv(w, b, split=split)
     src = flat(xs)
     offs = level_pixel_offsets(levels, out_copies)
     out = torch.full((offs[-1] * K,), 7.0, device="cuda")
@@ -68,19 +72,22 @@ BENCH_LEVELS = [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)]      # the fiv
 C_BOUND = 32.0
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
 @pytest.mark.parametrize("K,planes", [(256, False), (63, True), (36, True)], ids=["trunk-256", "cls_score-63", "bbox_pred-36"])
-def test_error_against_an_fp64_direct_convolution(K, planes):
+def test_error_against_an_fp64_direct_convolution(K, planes, split):
     """The referee that is not MIOpen: F.conv2d in fp64 on the CPU, on the benchmark launch's shapes (C = 256, five levels) with
     post-ReLU activations.  Per ELEMENT  |err| <= c 2^-24 (|w| * |x| + |b|)  -- the unit every forward error bound of an fp32
     evaluation is written in (a length-n fp32 dot product guarantees c <= n = 2304).  Measured c (tools/wino_fp64_check.py, MI355X):
     pod_wino_conv3x3 11.6 / 10.8 / 13.6 (trunk / cls_score / bbox_pred), MIOpen's fp32 conv2d 2.5 - 2.8, mkldnn's fp32 conv2d on the
-    CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class."""
+    CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class.
+    pod_wino_conv3x3_split (every product from 3-way bf16 splits, 6 partial products, fp32 accumulate): 10.6 / 9.6 / 8.5 -- the same
+    bound is asserted for both kernels."""
     C, copies, u = 256, 1, 2.0 ** -24
     g = torch.Generator().manual_seed(K)
     w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
     b = torch.randn(K, generator=g)
     xs = [torch.randn(copies, C, h, wd, generator=g).relu() for h, wd in BENCH_LEVELS]
-    conv = WinoConv(w.cuda(), b.cuda())
+    conv = WinoConv(w.cuda(), b.cuda(), split=split)
     src = flat([x.cuda() for x in xs])
     offs = level_pixel_offsets(BENCH_LEVELS, copies)
     dst = torch.full((offs[-1] * K,) if planes else (src.shape[0], K), float("nan"), device="cuda")
@@ -97,14 +104,15 @@ def test_error_against_an_fp64_direct_convolution(K, planes):
     assert c_max <= C_BOUND
 
 
-def test_dropout_mask_is_the_one_pod_bias_act_draws():
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+def test_dropout_mask_is_the_one_pod_bias_act_draws(split):
     """bias + ReLU + dropout in the conv's store == the conv without them followed by pod_bias_act on the same channels-last
     tensor (same Philox counters), bit for bit."""
     levels, copies, C, K = [(20, 28), (5, 7)], 2, 32, 64
     w, b, xs = make(levels, copies, C, K, seed=3)
     src, table = flat(xs), block_table(levels, copies, "cuda")
-    fused = WinoConv(w, b)(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=0.3, seed=1234, offset=5 << 34)
-    plain = WinoConv(w, None)(src, torch.empty(src.shape[0], K, device="cuda"), table)
+    fused = WinoConv(w, b, split=split)(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True, dropout_p=0.3, seed=1234, offset=5 << 34)
+    plain = WinoConv(w, None, split=split)(src, torch.empty(src.shape[0], K, device="cuda"), table)
     hip.check(hip.load().pod_bias_act(plain.data_ptr(), b.data_ptr(), None, None, plain.numel(), K, 1, 1, 0.3, 1234, 5 << 34,
                                       hip.current_stream()), "pod_bias_act")
     assert torch.equal(fused, plain)
