@@ -208,7 +208,7 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
     peak = BF16_MFMA_PEAK_TF if conv.split else FP32_MFMA_PEAK_TF
     direct_flop = 2.0 * 9 * table.pod_pixels * conv.C * conv.K
     traffic = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wino_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_wino_split_traffic.json" if conv.split else "*_wino_traffic.json")), reverse=True):
         t = json.load(open(path))
         if t.get("levels") == [list(x) for x in levels] and t.get("copies") == copies:
             traffic = t.get("traffic_bytes")

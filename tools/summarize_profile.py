@@ -115,13 +115,17 @@ if bench:
                      f(l.get("hot_path_ms_per_image")), f(l.get("hot_path_worst_ms")), f((l.get("roofline_k1") or l.get("roofline") or {}).get("frac")),
                      f((l.get("conv_roofline") or {}).get("frac"))))
     lines.append("")
-# ---- pod_wino_conv3x3 (tools/profile_wino.sh <tag>w)
-wsrc = "gpurun_out/%sw" % tag
-if os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
-    lines += ["## pod_wino_conv3x3, the launch bench.py times (`tools/profile_wino.sh`: 19 runs x 5 FPN levels of the 768x1344 frame, C = K = 256)", "",
-              "`rocprofv3 --kernel-trace --stats -- python tools/wino_only.py 20 19 bench`:", "",
+# ---- pod_wino_conv3x3 (tools/profile_wino.sh <tag>w) and pod_wino_conv3x3_split (POD_WINO_SPLIT=1 tools/profile_wino.sh <tag>ws)
+import re
+for suffix, split in (("w", False), ("ws", True)):
+    wsrc = "gpurun_out/%s%s" % (tag, suffix)
+    if not os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
+        continue
+    name = "pod_wino_conv3x3_split (fp32 products from 3-way bf16 splits, bf16 matrix cores)" if split else "pod_wino_conv3x3 (fp32 matrix cores)"
+    lines += ["## %s, the launch bench.py times (`tools/profile_wino.sh`: 19 runs x 5 FPN levels of the 768x1344 frame, C = K = 256)" % name, "",
+              "`%srocprofv3 --kernel-trace --stats -- python tools/wino_only.py 20 19 bench`:" % ("POD_WINO_SPLIT=1 " if split else ""), "",
               "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
-    rows = list(csv.DictReader(open(os.path.join(wsrc, "wino_stats.csv"))))
+    rows = [r for r in csv.DictReader(open(os.path.join(wsrc, "wino_stats.csv"))) if "k_wino_conv3x3" in r["Name"]]
     for r in rows[:1]:
         lines.append("| %s | %s | %.1f | %.1f | %.1f |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
     ev_txt = open(os.path.join(wsrc, "wino_events.txt")).read().strip()
@@ -133,19 +137,24 @@ if os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
     lines += ["PMC counters per launch (separate `rocprofv3 --pmc` passes):", "", "| counter | mean per launch |", "|---|---|"]
     lines += ["| %s | %.6g |" % (k, v) for k, v in sorted(pm.items())]
     avg_ns = float(rows[0]["AverageNs"])
-    tiles, padded = 19 * (48 * 42 + 24 * 21 + 12 * 11 + 6 * 6 + 3 * 3), 1689 * 32        # 2 x 4 output tiles of the bench launch
+    m = re.search(r"\((\d+) tiles, (\d+) with block padding\)", ev_txt)
+    tiles, padded = (int(m.group(1)), int(m.group(2))) if m else (51243, 51968)                      # 2 x 4 output tiles of the bench launch
     fetch, write = 2 * pm.get("FETCH_SIZE", 0) * 1024, pm.get("WRITE_SIZE", 0) * 1024
     mfma_busy = pm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (pm.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024)
-    lines += ["", "Derived: executed MFMA FLOPs of the real 2x4 tiles 2*24*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the 157.3 TFLOP/s fp32 MFMA peak;" % (
-                  tiles, 2 * 24 * tiles * 65536 / 1e9, 2 * 24 * tiles * 65536 / avg_ns / 1e3, 2 * 24 * tiles * 65536 / avg_ns / 1e3 / 157.3),
+    products, peak, unit = (6, 2500.0, "bf16") if split else (1, 157.3, "fp32")
+    flop = 2 * 24 * tiles * 65536 * products
+    lines += ["", "Derived: executed MFMA FLOPs of the real 2x4 tiles %s2*24*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the %.1f TFLOP/s %s MFMA peak;" % (
+                  "6 partial products x " if split else "", tiles, flop / 1e9, flop / avg_ns / 1e3, flop / avg_ns / 1e3 / peak, peak, unit),
               "matrix pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = %.2f (it also works on the %d padding tiles of partial 16x16 blocks);" % (mfma_busy, padded - tiles),
+              "LDS bank conflicts SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.2f;" % (pm.get("SQ_LDS_BANK_CONFLICT", 0) / max(pm.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
               "direct-convolution rate 2*9*pixels*256*256 / t = %.1f TFLOP/s.  HBM-side traffic (FETCH_SIZE x 2 on gfx950, KB units) %.2f GB read + %.2f GB written" % (
                   2 * 9 * 19 * 21486 * 65536 / avg_ns / 1e3, fetch / 1e9, write / 1e9),
-              "per launch = %.2f TB/s: the activations (0.41 GB) are read once per 64-channel filter slice (4 slices, each pinned to two XCDs so its 1 MB of" % ((fetch + write) / avg_ns / 1e3),
-              "filters stays in that L2) plus the 18x18 / 16x16 halo; far below the HBM roof, the kernel is matrix-pipe bound.", ""]
-    json.dump({"levels": [[96, 168], [48, 84], [24, 42], [12, 21], [6, 11]], "copies": 19, "traffic_bytes": fetch + write, "fetch_bytes_corrected": fetch,
+              "per launch = %.2f TB/s: the activations (0.41 GB) are read once per 64-channel filter slice (4 slices, each pinned to two XCDs so its filters" % ((fetch + write) / avg_ns / 1e3),
+              "stay in that L2) plus the 18x18 / 16x16 halo; far below the HBM roof.", ""]
+    json.dump({"kernel": "pod_wino_conv3x3_split" if split else "pod_wino_conv3x3", "levels": [[96, 168], [48, 84], [24, 42], [12, 21], [6, 11]], "copies": 19,
+               "traffic_bytes": fetch + write, "fetch_bytes_corrected": fetch,
                "write_bytes": write, "avg_launch_ns_rocprof": avg_ns, "mfma_busy_frac": mfma_busy,
                "source": "tools/profile_wino.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/wino_only.py 2 19 bench; FETCH_SIZE x2 (gfx950)"},
-              open(os.path.join(dst, "%s_wino_traffic.json" % tag), "w"))
+              open(os.path.join(dst, "%s_wino%s_traffic.json" % (tag, "_split" if split else "")), "w"))
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:80]))
