@@ -141,7 +141,9 @@ def conv_census(model, img, N, quirk, dev):
         e0.record()
         y = real_wino(self, src, dst, table, **kw)
         e1.record()
-        calls.append(("3x3_head_winograd_hip", 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))   # direct-convolution FLOPs
+        # a head launch covers all FPN levels x runs; a backbone / FPN launch is one NCHW feature map (modeling.wino_conv_nchw)
+        cat = "3x3_head_winograd_hip" if table.pod_levels > 1 else "3x3_backbone_fpn_winograd_hip"
+        calls.append((cat, 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))   # direct-convolution FLOPs
         return y
 
     reps = 3
@@ -166,8 +168,8 @@ def conv_census(model, img, N, quirk, dev):
         d["gflop"] /= reps
         d["ms"] /= reps
         d["tflops"] = d["gflop"] / d["ms"] if d["ms"] > 0 else None
-    w = out.get("3x3_head_winograd_hip")
-    if w:   # F(2,3) x F(4,3): 24 multiplies where the direct form has 72, tiles of partial 16x16 blocks included in the time only
+    for w in (out.get("3x3_head_winograd_hip"), out.get("3x3_backbone_fpn_winograd_hip")):
+      if w:   # F(2,3) x F(4,3): 24 multiplies where the direct form has 72, tiles of partial 16x16 blocks included in the time only
         w["note"] = ("pod_wino_conv3x3; gflop / tflops are DIRECT-convolution FLOPs (the model's arithmetic), the matrix cores "
                      "execute 24/72 of them: mfma_tflops_executed is what to hold against the 157.3 TFLOP/s peak")
         w["mfma_tflops_executed"] = w["tflops"] * 24.0 / 72.0 if w["tflops"] else None
@@ -220,7 +222,7 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
             "frac": mfma_flop / avg / 1e9 / peak, "direct_equivalent_tflops": direct_flop / avg / 1e9,
             "algorithmic_flop": mfma_flop, "direct_flop": direct_flop, "avg_launch_us": 1e3 * avg, "min_launch_us": 1e3 * ms[0],
             "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 32, "traffic": traffic,
-            "share_of_step": "12 launches of this kernel are ~93 % of a step's GPU time (conv_roofline.by_kind)"}
+            "share_of_step": "the head's 12 launches of this kernel are ~90 % of a step's GPU time (conv_roofline.by_kind)"}
 
 
 def run_ensemble_per_gpu(args, spec, world, rank, dev):
@@ -613,6 +615,17 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                 "conv_ms_per_image_one_stream": conv_ms,
                                 "one_stream_frac": gflop / conv_ms / FP32_MFMA_PEAK_TF if conv_ms > 0 else None,
                                 "by_kind": census}
+        bb = census.get("3x3_backbone_fpn_winograd_hip")
+        if bb:      # the bottlenecks' and the FPN's 3x3 / stride-1 convolutions on pod_wino_conv3x3: one NCHW feature map per launch
+            out["roofline_backbone"] = {"kernel": "pod_wino_conv3x3 on the backbone's and the FPN's 3x3 / stride-1 convolutions (%d launches per image, "
+                                                  "one feature map each, batch 1: 24-1008 workgroups)" % bb["calls"],
+                                        "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF,
+                                        "achieved": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0),
+                                        "frac": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0) / (BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF),
+                                        "direct_equivalent_tflops": bb["tflops"], "gflop_direct": bb["gflop"], "ms_per_image": bb["ms"],
+                                        "traffic": None,
+                                        "note": "HIP events around each launch on one stream (launch gaps included); MIOpen's Winograd on the same "
+                                                "convolutions ran at 82 TFLOP/s direct-equivalent in round 2"}
 
     # ---- NLL of the detections against the planted ground truth (the "NLL parity" half of the metric) ---------
     if spec["reg_var"] or N > 1:

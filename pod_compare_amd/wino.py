@@ -82,6 +82,7 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         assert max(ioffs[-1], ooffs[-1]) < 2 ** 31
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()
         t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table
+        t.pod_levels = len(levels)
         _TABLES[key] = t
     return t
 

@@ -296,25 +296,47 @@ def test_coco_image_list_is_mapped_like_detectron2s_test_loader(tmp_path):
 
 
 def test_wino_block_table_canvases():
-    """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {in pixel, out pixel, H<<16|W,
-    n_images<<24 | by<<12 | bx}: images of a level side by side on one canvas where that saves blocks, else one canvas per image."""
-    from pod_compare_amd.wino import block_table, level_pixel_offsets
+    """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {first in pixel, first out pixel,
+    grid_cols<<24 | H<<12 | W, n_images<<24 | by<<12 | bx} (include/pod_mi355x.h): the images of a level stand in a grid on one canvas,
+    one zero row / column apart.  Decoding the records the way the kernel does must give every output pixel of every image exactly once."""
+    from pod_compare_amd.wino import block_table, canvas_layout, level_pixel_offsets
     levels = [(23, 40), (6, 10), (16, 32)]
     assert level_pixel_offsets(levels, 3) == [0, 3 * 920, 3 * 920 + 3 * 60, 3 * 920 + 3 * 60 + 3 * 512]
+
+    def decode(table):
+        """-> list of (in pixel, out pixel) of every image pixel the blocks cover"""
+        pairs = []
+        for pin, pout, geo, blk in table.tolist():
+            gcols, H, W = (geo >> 24) & 0xFF, (geo >> 12) & 0xFFF, geo & 0xFFF
+            n, by, bx = (blk >> 24) & 0x7F, (blk >> 12) & 0xFFF, blk & 0xFFF
+            assert gcols >= 1 and n >= 1
+            hit = 0
+            for cy in range(16 * by, 16 * by + 16):
+                gr, y = divmod(cy, H + 1)
+                for cx in range(16 * bx, 16 * bx + 16):
+                    gc, x = divmod(cx, W + 1)
+                    img = gr * gcols + gc
+                    if y < H and x < W and gc < gcols and img < n:
+                        pairs.append((pin + img * H * W + y * W + x, pout + img * H * W + y * W + x))
+                        hit += 1
+            assert hit > 0, "a block that covers no image pixel is wasted work"
+        return pairs
+
     t = block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3)
-    assert t.dtype == torch.int32
-    rows = t.tolist()
-    # level 0: W = 40 -> Wv = 44 (W + 1 rounded up to 4), canvas of 2 images = 84 columns = 6 block columns (3 + 3 apart): no saving -> per image
-    assert rows[0] == [1 * 920, 0, (23 << 16) | 40, (1 << 24) | 0] and rows[5] == [920, 0, (23 << 16) | 40, (1 << 24) | (1 << 12) | 2]
-    assert rows[6][:2] == [2 * 920, 920]
-    # level 1: W = 10 -> Wv = 12, 2 images = 22 columns = 2 block columns instead of 2 x 1: no saving either
-    l1 = [r for r in rows if r[2] == (6 << 16) | 10]
-    assert [r[:2] for r in l1] == [[5 * 920 + 1 * 60, 3 * 920], [5 * 920 + 2 * 60, 3 * 920 + 60]]
-    # level 2: W = 32 is a multiple of 16: one canvas per image
-    l2 = [r for r in rows if r[2] == (16 << 16) | 32]
-    assert len(l2) == 2 * 2 and all((r[3] >> 24) == 1 for r in l2)
-    assert len({tuple(r) for r in rows}) == len(rows)
+    assert t.dtype == torch.int32 and t.shape[1] == 4
+    pairs = decode(t)
+    ioffs, ooffs = level_pixel_offsets(levels, 5), level_pixel_offsets(levels, 3)
+    want = [(ioffs[l] + (1 + c) * h * w + p, ooffs[l] + c * h * w + p) for l, (h, w) in enumerate(levels) for c in range(2) for p in range(h * w)]
+    assert sorted(pairs) == sorted(want)                     # every pixel once, read from images in_first.. and written to images 0..
+    assert len({tuple(r) for r in t.tolist()}) == t.shape[0]
     assert block_table(levels, 2, "cpu", in_copies=5, in_first=1, out_copies=3) is t      # cached
-    # the benchmark frame: 19 runs side by side save 78 of 1767 blocks
-    big = block_table([(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)], 19, "cpu")
-    assert big.shape[0] == 1689 and int(big[0, 3]) >> 24 == 19
+    assert t.pod_pixels == 2 * (920 + 60 + 512) and t.pod_levels == 3
+    # 19 maps of 6 x 11 share at most 8 blocks (one canvas per image: 19)
+    rows, cols, blocks = canvas_layout(6, 11, 19)
+    assert rows * cols >= 19 and len(blocks) <= 8
+    # the benchmark launch: 19 runs x 5 levels in 1624 blocks (one canvas per image: 1767), each pixel once
+    bench_levels = [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)]
+    big = block_table(bench_levels, 19, "cpu")
+    assert big.shape[0] == 1624
+    got = decode(big)
+    assert len(got) == big.pod_pixels and len({p for _, p in got}) == big.pod_pixels and all(a == b for a, b in got)
