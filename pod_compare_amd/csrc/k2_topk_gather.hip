@@ -15,6 +15,13 @@
 
 namespace pod {
 
+#ifdef POD_TRACE
+__device__ long long g_k2_trace[128 * 16];          // [workgroup][stamp]: wall_clock64 (100 MHz) at the phases of k2_level_topk
+#define K2_STAMP(i) do { if (threadIdx.x == 0) g_k2_trace[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
+
 constexpr int TOPK_THREADS = 1024;
 constexpr int SORT_CAP = POD_MAX_TOPK;   // 2048 keys = 16 KiB LDS
 
@@ -81,6 +88,8 @@ struct TopkLds {
     uint64_t prefix;
     uint32_t wtot[4];
     int32_t remaining, fill, bucket, ticket, pick, pick_rem;
+    uint64_t red_or[TOPK_THREADS / 64], red_and[TOPK_THREADS / 64];
+    uint32_t red_n[TOPK_THREADS / 64];
 };
 
 // Where level l's rows start in the level-concatenated candidate list, and the list's length: the counts of ALL levels are
@@ -119,7 +128,7 @@ __device__ __forceinline__ void write_selection(const K2Params& P, const TopkLds
 // SORT = false stops before the sort: S.keys[0 .. returned size) then holds an unordered SUPERSET of the top `want` (at most
 // SORT_CAP keys, zero-padded), which is all a slice has to hand to the final selection.
 template <bool SORT, class Fetch>
-__device__ int topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
+__device__ __forceinline__ int topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
     const int tid = threadIdx.x;
     int n_sort;
     if (count <= SORT_CAP) {
@@ -237,6 +246,145 @@ __device__ int topk_into_lds(TopkLds& S, Fetch fetch, int count, int want) {
     return n_sort;
 }
 
+// The same selection for count <= CACHE_CAP with every key fetched ONCE: a thread keeps its KPT keys in registers through all
+// radix passes and the compaction (the loop version above re-fetches the list per pass: with 9 000 - 16 000 keys that was 3 - 4
+// round trips to L2 / HBM per workgroup, twice on the critical path of a big level).  The digits start at the highest bit in
+// which two present keys DIFFER (an OR / AND reduction over the workgroup): scores of candidates lie in (threshold, 1], so the
+// top 6 bits of every key agree and a fixed byte grid would spend its first pass on them.  Narrows until at most `cap` keys
+// (>= want) are left; SORT = false leaves them unordered, zero-padded to `cap`, and returns how many there are.
+constexpr int KPT = 16;
+constexpr int CACHE_CAP = KPT * TOPK_THREADS;
+
+// How far the select narrows before the bitonic network takes over: the smallest power of two that holds the `want` keys (a
+// 2048-key sort costs 20 us on one CU, a 1024-key sort 11, an extra radix pass over registers 2.5).
+__device__ __forceinline__ int sort_cap(int want) {
+    int c = 256;
+    while (c < want) c <<= 1;
+    return c;
+}
+
+template <bool SORT, class Fetch>
+__device__ __forceinline__ int topk_cached(TopkLds& S, Fetch fetch, int count, int want, int cap, int tb = 0) {
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    uint64_t kk[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = u * TOPK_THREADS + tid;
+        kk[u] = (i < count) ? fetch(i) : 0ull;
+    }
+    uint64_t vor = 0ull, vand = ~0ull;
+    uint32_t present = 0;
+#pragma unroll
+    for (int u = 0; u < KPT; ++u)
+        if (kk[u] != 0ull) {
+            vor |= kk[u];
+            vand &= kk[u];
+            ++present;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vor |= shfl_xor_u64(vor, o);
+        vand &= shfl_xor_u64(vand, o);
+        present += __shfl_xor(present, o, 64);
+    }
+    if (ln == 0) {
+        S.red_or[wv] = vor;
+        S.red_and[wv] = vand;
+        S.red_n[wv] = present;
+    }
+    if (tid == 0) S.fill = 0;
+    __syncthreads();
+    vor = 0ull, vand = ~0ull, present = 0;
+#pragma unroll
+    for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+        vor |= S.red_or[w];
+        vand &= S.red_and[w];
+        present += S.red_n[w];
+    }
+    K2_STAMP(tb);
+    const uint64_t diff = vor ^ vand;                    // bits in which two present keys differ (keys are distinct)
+    int hi = diff ? 64 - __clzll((long long)diff) : 0;    // every present key agrees on bits >= hi
+    uint64_t prefix = hi < 64 ? (vand >> hi) << hi : 0ull;
+    int remaining = want, bucket = (int)present;         // candidates = (want - remaining) above the bucket + the bucket
+    while ((want - remaining) + bucket > cap && hi > 0) {
+        const int shift = hi > 8 ? hi - 8 : 0;
+        const uint32_t dmask = (1u << (hi - shift)) - 1u;
+        const uint64_t himask = hi < 64 ? (~0ull << hi) : 0ull;
+        if (tid < 256) S.hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            const bool live = kk[u] != 0ull && (kk[u] & himask) == prefix;
+            const uint32_t digit = (uint32_t)(kk[u] >> shift) & dmask;
+            const unsigned long long lm = __ballot(live);
+            if (lm != 0ull) {
+                const int leader = __ffsll((long long)lm) - 1;
+                const uint32_t d0 = __shfl(digit, leader, 64);
+                if (__ballot(live && digit == d0) == lm) {
+                    if (ln == leader) atomicAdd(&S.hist[d0], (uint32_t)__popcll(lm));
+                } else if (live) {
+                    atomicAdd(&S.hist[digit], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t cnt = 0, incl = 0;
+        if (tid < 256) {
+            cnt = S.hist[tid];
+            incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_down(incl, o, 64);
+                if (ln + o < 64) incl += up;
+            }
+            if (ln == 0) S.wtot[wv] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            for (int w = wv + 1; w < 4; ++w) incl += S.wtot[w];
+            const uint32_t excl = incl - cnt, rem = (uint32_t)remaining;
+            const bool chosen = tid == 0 ? excl < rem : (excl < rem && rem <= incl);
+            if (chosen) {
+                S.pick = tid;
+                S.pick_rem = (int)(rem - excl);
+                S.bucket = (int)cnt;
+            }
+        }
+        __syncthreads();
+        remaining = S.pick_rem;
+        bucket = S.bucket;
+        prefix |= (uint64_t)S.pick << shift;
+        hi = shift;
+    }
+    K2_STAMP(tb + 1);
+    const int n_cand = (want - remaining) + bucket;            // exact count of present keys >= prefix
+    int n_sort = 1;
+    while (n_sort < n_cand) n_sort <<= 1;
+    const int n_clear = SORT ? n_sort : cap;
+    for (int i = tid; i < n_clear; i += TOPK_THREADS) S.keys[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const bool sel = kk[u] != 0ull && kk[u] >= prefix;
+        const unsigned long long sm = __ballot(sel);
+        if (sm != 0ull) {
+            const int leader = __ffsll((long long)sm) - 1;
+            int at = 0;
+            if (ln == leader) at = atomicAdd(&S.fill, __popcll(sm));
+            at = __shfl(at, leader, 64);
+            if (sel) S.keys[at + __popcll(sm & ((1ull << ln) - 1ull))] = kk[u];
+        }
+    }
+    __syncthreads();
+    K2_STAMP(tb + 2);
+    if (SORT) {
+        bitonic_sort_desc(S.keys, n_sort, tid, TOPK_THREADS);
+        K2_STAMP(tb + 3);
+        return n_sort;
+    }
+    return n_cand;
+}
+
 // Grid = n_levels x TOPK_SLICES workgroups.  A level with <= SORT_CAP candidates (every level of a typical image) is sorted by
 // its slice-0 workgroup alone.  A bigger level is cut into TOPK_SLICES slices: the global top-k is contained in the union of the
 // slices' top-k, so every workgroup narrows its slice down to <= 2048 candidates containing the slice's top-k (16x shorter scans,
@@ -249,9 +397,11 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
     const int tid = threadIdx.x;
     uint64_t* keys = P.cand_keys + P.anchor_base[l];
     int32_t* ticket = P.cand_count + P.n_levels + l;
+    K2_STAMP(0);
     const int C = P.cand_count[l];           // stays put: the gather kernel (K2b / K23) consumes (re-zeroes) the counts
     int total = 0;
     const int off = P.cat_keys ? level_offset(P, l, total) : 0;      // the other levels' counts: same round trip as C
+    K2_STAMP(1);
     const int k = min(P.topk, C);
     uint64_t* out = P.sel_keys + (int64_t)l * P.topk;
     if (C <= SORT_CAP) {
@@ -260,34 +410,58 @@ __global__ void __launch_bounds__(TOPK_THREADS) k2_level_topk(const K2Params P) 
         write_selection(P, S, l, k, out, off, total);
         return;
     }
+    if (C <= CACHE_CAP) {                 // one workgroup holds the whole level in registers: no slices, no ticket
+        if (b != 0) return;
+        topk_cached<true>(S, [=](int i) { return keys[i]; }, C, k, sort_cap(k));
+        write_selection(P, S, l, k, out, off, total);
+        return;
+    }
     const int slice = ((C + TOPK_SLICES - 1) / TOPK_SLICES + 7) & ~7;      // keys per slice
     const int begin = b * slice;
     const int len = max(0, min(slice, C - begin));
-    // survivors of a slice = an unordered superset of its top-k, at most SORT_CAP keys, written over the head of the slice and
-    // zero-padded to min(len, SORT_CAP); a slice that short is its own survivor list.  Sorting here would only be redone below.
-    if (len > SORT_CAP) {
+    const bool cached = slice <= CACHE_CAP;                                // else the loop version (levels beyond 262 144 candidates)
+    // survivors of a slice = an unordered superset of its top-k, at most `cap` keys, written over the head of the slice and
+    // zero-padded to min(len, cap); a slice that short is its own survivor list.  Sorting here would only be redone below.
+    const int cap = (cached && k <= SORT_CAP / 2) ? SORT_CAP / 2 : SORT_CAP;
+    if (len > cap) {
         const uint64_t* mine = keys + begin;
-        const int n_out = topk_into_lds<false>(S, [=](int i) { return mine[i]; }, len, min(k, len));
-        for (int i = tid; i < SORT_CAP; i += TOPK_THREADS) keys[begin + i] = i < n_out ? S.keys[i] : 0ull;   // only this workgroup touches the slice
+        const int n_out = cached ? topk_cached<false>(S, [=](int i) { return mine[i]; }, len, min(k, len), cap, 2)
+                                 : topk_into_lds<false>(S, [=](int i) { return mine[i]; }, len, min(k, len));
+        for (int i = tid; i < cap; i += TOPK_THREADS) keys[begin + i] = i < n_out ? S.keys[i] : 0ull;   // only this workgroup touches the slice
     }
     __threadfence();
     __syncthreads();
     if (tid == 0) S.ticket = atomicAdd(ticket, 1);
     __syncthreads();
+    K2_STAMP(6);
     if (S.ticket != TOPK_SLICES - 1) return;
     __threadfence();
-    // last workgroup of the level: virtual list j -> entry (j % SORT_CAP) of slice (j / SORT_CAP)'s survivor list; 0 = no key
+    K2_STAMP(7);
+    // last workgroup of the level: virtual list j -> entry (j % cap) of slice (j / cap)'s survivor list; 0 = no key
     auto survivors = [=](int j) -> uint64_t {
-        const int sb = j / SORT_CAP, r = j - sb * SORT_CAP;
+        const int sb = j / cap, r = j - sb * cap;
         const int sbegin = sb * slice;
         const int slen = max(0, min(slice, C - sbegin));
         // device-scope load: this CU's L1 may still hold the line from before the other workgroup compacted its slice
-        return r < min(SORT_CAP, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        return r < min(cap, slen) ? __hip_atomic_load(keys + sbegin + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     };
-    topk_into_lds<true>(S, survivors, TOPK_SLICES * SORT_CAP, k);
+    if (TOPK_SLICES * cap <= CACHE_CAP)
+        topk_cached<true>(S, survivors, TOPK_SLICES * cap, k, sort_cap(k), 8);
+    else
+        topk_into_lds<true>(S, survivors, TOPK_SLICES * cap, k);
     write_selection(P, S, l, k, out, off, total);
     if (tid == 0) *ticket = 0;
+    K2_STAMP(12);
 }
+
+#ifdef POD_TRACE
+}  // namespace pod
+extern "C" int pod_k2_trace_dump(long long* host) {   // diagnostics build only (not in include/pod_mi355x.h): 128 x 16 stamps
+    if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pod::g_k2_trace), sizeof(long long) * 128 * 16) == hipSuccess ? POD_OK : POD_E_LAUNCH;
+}
+namespace pod {
+#endif
 
 __global__ void __launch_bounds__(64) k2b_gather(const K2bParams P) {
     GatheredCandidate g;

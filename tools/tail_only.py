@@ -26,10 +26,15 @@ def timeit(name, fn, iters=30):
 hip.check(lib.pod_mc_merge_score(cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), None, None, P(hp.cand_keys), P(hp.cand_count), P(hp.maybe_bits), st), "k1")
 hip.check(lib.pod_score_maybe(cfg, lv, P(hp.mean_cls), P(hp.mean_cls_var), P(hp.maybe_bits), P(hp.cand_keys), P(hp.cand_count), P(hp.probs_dense), st), "k1b")
 saved_counts = hp.counters.clone()
-def k2():
+saved_keys = hp.cand_keys.clone()          # a big level's slices are compacted in place
+def restore():
     hp.counters.copy_(saved_counts)
+    hp.cand_keys.copy_(saved_keys)
+timeit("restore (2 copies)", restore)
+def k2():
+    restore()
     lib.pod_level_topk(cfg, lv, P(hp.cand_keys), P(hp.cand_count), P(hp.sel_keys), P(hp.sel_count), P(hp.cat_keys), P(hp.cat_level), P(hp.n_total), st)
-timeit("K2 topk (+ 2 us copy)", k2)
+timeit("K2 topk + restore", k2)
 timeit("K2b gather", lambda: lib.pod_gather_candidates(cfg, lv, P(hp.anchors), P(hp.cat_keys), P(hp.cat_level), P(hp.n_total), P(hp.cand_count), P(hp.probs_dense), P(hp.cand_anchor_idx), P(hp.cand_level), P(hp.cand_score), P(hp.cand_class), P(hp.cand_probs), P(hp.cand_delta), P(hp.cand_reg_var), P(hp.cand_anchor), P(hp.cand_run_delta), st))
 timeit("K3 decode_cov", lambda: hp.decode(lv, None))
 timeit("K4 nms", lambda: hp.nms())
