@@ -21,10 +21,15 @@ def make_keys(C, seed, skew):
 
 
 @pytest.mark.parametrize("skew", [False, True])
-@pytest.mark.parametrize("counts", [[1, 0, 5], [63, 64, 65], [700, 1024, 1500], [2048, 2049, 5000], [20000, 2268, 594], [145152, 36288, 9072, 2268, 594]])
-def test_level_topk_equals_sorted_prefix(counts, skew):
+@pytest.mark.parametrize("counts,topk", [([1, 0, 5], 1000), ([63, 64, 65], 1000), ([700, 1024, 1500], 1000), ([2048, 2049, 5000], 1000),
+                                         ([20000, 2268, 594], 1000), ([145152, 36288, 9072, 2268, 594], 1000),
+                                         # the register-cached select's size classes: one workgroup (<= 16 384), 16 cached slices (<= 262 144),
+                                         # the loop version beyond; k > 1024 makes the slices hand over 2048 survivors (final selection: loop version)
+                                         ([16384, 16385, 2050], 1000), ([300000, 40000], 1000), ([145152, 9072, 3000], 2048), ([36288, 16000], 100),
+                                         ([5000, 20000], 1), ([2049, 40000], 1024), ([2049, 40000], 1025)])
+def test_level_topk_equals_sorted_prefix(counts, topk, skew):
     lib, P = hip.load(), hip.ptr
-    L, topk = len(counts), 1000
+    L = len(counts)
     cfg = hip.PodConfig()
     cfg.n_levels, cfg.topk = L, topk
     lv = (hip.PodLevel * L)()
