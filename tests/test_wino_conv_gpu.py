@@ -280,3 +280,30 @@ def test_full_frame_model_forward_winograd_head_equals_miopen_head():
         for g, w in zip(getattr(got, name), getattr(want, name)):
             assert g.shape == w.shape
             assert float((g - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max())), name      # (the backbone is MIOpen in both)
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+@pytest.mark.parametrize("mid,H,W,stride", [(64, 47, 83, 1), (128, 25, 42, 2), (256, 13, 21, 1), (512, 6, 11, 2)])
+def test_bottleneck_with_conv2_on_the_winograd_kernel_equals_the_miopen_bottleneck(mid, H, W, stride, split, monkeypatch):
+    """detectron2's BottleneckBlock (conv1 1x1 [stride], conv2 3x3, conv3 1x1, shortcut; FrozenBN folded) as modeling.Bottleneck runs it
+    since round 3 -- conv1 on MIOpen without bias, its bias + ReLU on the pass that lays the map out channels-last
+    (pod_bias_act_to_nhwc), conv2 + bias + ReLU on pod_wino_conv3x3 with NCHW planes out -- against the same block with every
+    convolution on MIOpen (POD_WINO_BACKBONE=0's path), the res2 .. res5 channel counts, odd map sizes."""
+    from pod_compare_amd import modeling, wino
+    monkeypatch.setattr(wino, "SPLIT_BF16", split)
+    torch.manual_seed(mid)
+    cin = 2 * mid if stride == 2 else 4 * mid
+    blk = modeling.Bottleneck(cin, 4 * mid, mid, stride).cuda().eval()
+    for m in blk.modules():                      # non-trivial frozen statistics, then fold them into the convs
+        if isinstance(m, modeling.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0.0, 0.2); m.running_mean.normal_(0.0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    assert modeling.fold_frozen_bn(blk) == (4 if cin != 4 * mid else 3)
+    x = torch.randn(1, cin, H * stride, W * stride, device="cuda").relu()
+    with torch.no_grad():
+        monkeypatch.setattr(modeling, "WINO_BACKBONE", True)
+        got = blk(x)
+        monkeypatch.setattr(modeling, "WINO_BACKBONE", False)
+        want = blk(x)
+    assert got.shape == want.shape == (1, 4 * mid, H, W)
+    assert float((got - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+    assert not torch.equal(got, want)            # (two different convolution kernels did run)
