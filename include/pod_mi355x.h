@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 5
+#define POD_ABI_VERSION 4
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -325,17 +325,11 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
  * k_planes == 0: out is channels-last.  k_planes > 0 (the predictor convs cls_score / bbox_pred / cls_var / bbox_cov,
  * PR:430-484): out is NCHW, image = k_planes planes of H*W starting at float `k_planes * first pixel`: the (N, A*K, H, W)
  * tensors pod_mc_merge_score streams; p must be 0.  Dropout: 16 Philox4x32-10 bits per element, keep iff field >= p * 2^16, counter
- * = offset + (flat index of the output element >> 3): the mask pod_bias_act draws on the same tensor.
- *
- * work (ABI 5; may be NULL): 8 int32 device words, 16-byte aligned, ZERO before the first launch and owned by ONE stream (launches
- * that may run concurrently need their own).  With it a launch of more than one round of workgroups runs as one PERSISTENT workgroup
- * per CU: a workgroup starts on the block of its index, draws further blocks from the ticket counter of its filter slice and
- * prepares the next block (record, pixel table, first operands) behind the store pass of the current one; the last draw of a
- * launch puts the counter back to zero, so the words are zero again when the launch has completed.  NULL: one block per workgroup. */
+ * = offset + (flat index of the output element >> 3): the mask pod_bias_act draws on the same tensor. */
 int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                     int32_t* work, pod_stream_t stream);
+                     pod_stream_t stream);
 
 /* The same convolution with every fp32 product formed on the BF16 matrix cores (experimental, opt-in; csrc/k12_wino_conv_split.hip):
  * both operands are split exactly into three bf16 terms and the six significant partial products are accumulated in fp32
@@ -344,7 +338,7 @@ int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* b
 int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                            int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                           int32_t* work, pod_stream_t stream);
+                           pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

@@ -77,20 +77,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xcd = blockIdx.x & 7;
     const int ks = xcd % P.KS;
-    int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;       // this workgroup's index among those serving slice ks = its first block
+    const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
     if (tb >= P.n_blocks) return;
-    // PERSISTENT mode (P.work != null; the host launches one workgroup per CU): after its first block a workgroup draws further blocks
-    // from its slice's ticket counter instead of ending: no hand-over to a freshly dispatched workgroup, and the next block's record
-    // is in registers when the store pass ends (a new workgroup waits ~1 us for it before it can ask for anything else).  (Preparing
-    // MORE of the next block behind the store pass -- pixel table, mini stages into registers, first filter operands -- was built and
-    // measured: the latency it hides at the top comes back as in-order vmcnt waits between the store pass's loads and stores, +4 %.)
-    // Blocks are known TWO ahead (the first two of a workgroup are static: its index, its index + wgs_per_slice; block
-    // k + 2 = 2 wgs_per_slice + the ticket drawn at the top of block k), so the record of the next block is asked for at the top of a
-    // block and has the whole K loop to arrive.  A workgroup draws only while its next block exists: every drawing workgroup fails
-    // exactly once, the launch draws n_blocks - wgs_per_slice tickets per slice, and the draw that returns the last of them puts the
-    // counter back to zero.
-    const bool persistent = P.work != nullptr;
-    [[maybe_unused]] int wino_trace_id = tb * P.KS + ks;
     // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
     // both (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- the
@@ -98,16 +86,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     WINO_STAMP(0);
     WINO_STAMP_WALL(12);
     uint32_t slot_e[12];                                                  // this lane's 12 pixel slots of a stage fill (constant table: asked for first, so
-    int mini_pidx[3];                                                     // that nothing queues behind the patch loads that follow) ... and the patch pixel of
-    auto lane_slots = [&](int t) {                                        // its 3 slots of a mini-stage fill (324: none)
+#pragma unroll                                                            // that nothing queues behind the patch loads that follow)
+    for (int i = 0; i < 12; ++i) slot_e[i] = g_wino_slots.v[96 * (tid >> 6) + 8 * i + ((tid & 63) >> 3)];
+    int mini_pidx[3];                                                     // ... and the patch pixel of its 3 slots of a mini-stage fill (324: none)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) slot_e[i] = g_wino_slots.v[96 * (t >> 6) + 8 * i + ((t & 63) >> 3)];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int pp = (((t >> 6) * 3 + r) * 64 + (t & 63)) >> 1, py = pp / 21, pi = pp - py * 21, px = 4 * (pi % 5) + pi / 5;
-            mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
-        }
-    };
+    for (int r = 0; r < 3; ++r) {
+        const int pp = (((tid >> 6) * 3 + r) * 64 + (tid & 63)) >> 1, py = pp / 21, pi = pp - py * 21, px = 4 * (pi % 5) + pi / 5;
+        mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
+    }
     // the filter operands of chunk 0 do not depend on the block record either: straight from L2 into registers, asked for now
     const int nchunk = P.C >> 3;
     const int i32 = lane & 31, h = lane >> 5;
@@ -119,20 +105,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     auto filter_piece = [&](int ch, f32x4(&u)[12], int i) {              // 12 pieces: one buffer_load_dwordx4 each
         u[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, ch * (WINO_U_FLOATS * 4) + ((i >> 1) * 128 + (i & 1) * 32) * 16, 0));
     };
-    struct Block {                                                        // a decoded block record (wave-uniform)
-        int64_t base_px, out_px;                                          // first pixel of image 0 in `in` / `out`
-        int gcols, H, W, n_img, y0, x0, Wv, Hv, HWi;
-        float rWv, rHv;
-    };
-    auto decode = [](const int4 desc) {
-        Block b;
-        b.base_px = desc.x; b.out_px = desc.y;
-        b.gcols = (desc.z >> 24) & 0xFF; b.H = (desc.z >> 12) & 0xFFF; b.W = desc.z & 0xFFF; b.n_img = (desc.w >> 24) & 0xFF;
-        b.y0 = ((desc.w >> 12) & 0xFFF) * 16; b.x0 = (desc.w & 0xFFF) * 16; b.Wv = b.W + 1; b.Hv = b.H + 1; b.HWi = b.H * b.W;
-        b.rWv = 1.0f / (float)b.Wv; b.rHv = 1.0f / (float)b.Hv;
-        return b;
-    };
-    Block B = decode(P.blocks[tb]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
+    const int4 desc = P.blocks[tb];
+    const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
+    const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
+    const int y0 = ((desc.w >> 12) & 0xFFF) * 16, x0 = (desc.w & 0xFFF) * 16, Wv = W + 1, Hv = H + 1, HWi = H * W;
+    const float rWv = 1.0f / (float)Wv, rHv = 1.0f / (float)Hv;
     // canvas coordinate v >= 0 -> (grid index, coordinate inside the cell); canvas extents < 2^16: exact after the fix-up
     auto cell = [](int v, int step, float rstep, int& idx) {
         int n = (int)((float)v * rstep);
@@ -181,27 +160,23 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     }
     uint32_t amini[2];                                                    // LDS byte address in mini stage 0: [row0 / row1]; column c: + ((c & 3) 5 + (c >> 2)) 32
 #pragma unroll
-    for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + WINO_Z_BYTES + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32 + h * 16;
-    float* const mini = lds + WINO_Z_BYTES / 4;                           // the two mini stages, then the pixel table: behind the output staging
-    auto source = [&](const Block& b) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + b.base_px * P.in_stride), 0, b.n_img * b.HWi * P.in_stride * 4, 0x00020000);
-    };
-    auto r_rsrc = source(B);
+    for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32 + h * 16;
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
+                                                          n_img * HWi * P.in_stride * 4, 0x00020000);
     // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
     // (grid row, row inside the image), canvas column -> (grid column, column) -- and parks its pixel index (-1: outside every image:
     // the loads then use a buffer offset that reads 0.0) in LDS; the lanes look their pieces up there: two divisions per thread
     // instead of two per lane and piece.
-    int* pix_tab = reinterpret_cast<int*>(mini + 2 * WINO_MINI_FLOATS);       // 325 ints behind the mini stages; [328]: the next block's index
-    auto pixel_table = [&](const Block& b) {
+    int* pix_tab = reinterpret_cast<int*>(lds + 2 * WINO_SB_FLOATS + 2 * 3072);       // 324 ints behind the mini stages
 #pragma unroll
-        for (int t = tid; t < 325; t += 256) {
-            const int py = t / 18, px = t - py * 18, vy = b.y0 - 1 + py, vx = b.x0 - 1 + px;
-            int m, n;
-            const int gy = cell(vy < 0 ? 0 : vy, b.Hv, b.rHv, m), gx = cell(vx < 0 ? 0 : vx, b.Wv, b.rWv, n), img = m * b.gcols + n;
-            const bool ok = (t < 324) & (vy >= 0) & (gy < b.H) & (vx >= 0) & (gx < b.W) & (n < b.gcols) & (img < b.n_img);
-            pix_tab[t] = ok ? img * b.HWi + gy * b.W + gx : -1;          // entry 324 = -1: the "no pixel" slots of the fills point here
-        }
-    };
+    for (int t = tid; t < 325; t += 256) {
+        const int py = t / 18, px = t - py * 18, vy = y0 - 1 + py, vx = x0 - 1 + px;
+        int m, n;
+        const int gy = cell(vy < 0 ? 0 : vy, Hv, rHv, m), gx = cell(vx < 0 ? 0 : vx, Wv, rWv, n), img = m * gcols + n;
+        const bool ok = (t < 324) & (vy >= 0) & (gy < H) & (vx >= 0) & (gx < W) & (n < gcols) & (img < n_img);
+        pix_tab[t] = ok ? img * HWi + gy * W + gx : -1;              // entry 324 = -1: the "no pixel" slots of the fills point here
+    }
+    __syncthreads();
     auto byte_offset = [&](int pix, int part4) {
         int o = pix >= 0 ? (pix * P.in_stride + part4) * 4 : ((POD_WINO_VAR & 4) ? part4 * 4 : 0x7FFFFF00);
         if (POD_WINO_VAR & 8) o &= 0x3FFFF;          // (experiment: every piece from the same 256 KB)
@@ -210,7 +185,12 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // The first two chunks come from two MINI stages (8 channels each, 324 pixels x 32 B, 3 LDS-DMA instructions per wave each), so the
     // matrix cores start after 20 KB have landed instead of a 48 KB super-chunk; super-chunk 0 lands behind the first chunk's MFMAs.
     // Mini layout: 16-byte slot 2 (py 21 + (px & 3) 5 + (px >> 2)) + h: the 16 lanes of a ds_read_b128 group hit every bank group twice.
+    WINO_STAMP(8);                                     // (the block record has arrived, the pixel table stands)
     int dmini[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dmini[r] = pix_tab[mini_pidx[r]];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dmini[r] = byte_offset(dmini[r], 4 * (lane & 1));
     // LDS-DMA of a stage: 48 instructions of 8 pixel slots x 8 parts (the last 3 fetch nothing), wave a issues 12 a .. 12 a + 11.  Lane
     // (l3 = lane >> 3, q = lane & 7) of instruction I fills sub-slot q of pixel slot 8 I + l3 with part (q - rot) & 7 of its pixel.
     int doff[12];
@@ -222,7 +202,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     };
     typedef __attribute__((address_space(3))) void lds_void;
     auto mini_piece = [&](int which, int r) {                // 1 KB of the 8-channel patch of chunk `which` (0 / 1) into its mini stage
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(mini + which * WINO_MINI_FLOATS + (a * 3 + r) * 256), 16, dmini[r], which * 32, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(lds + 2 * WINO_SB_FLOATS + which * 3072 + (a * 3 + r) * 256), 16, dmini[r], which * 32, 0, 0);
     };
     auto patch_piece = [&](float* stage, int sc, int i) {    // 1 KB (8 pixels x 32 channels) of super-chunk sc, straight into LDS
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (a * 12 + i) * 256), 16, doff[i], sc * 128, 0, 0);
@@ -306,24 +286,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #define WINO_MFMA(V, U, j)                                                                                                   \
     acc[(j) % 12] = __builtin_amdgcn_mfma_f32_32x32x2f32(U[(j) % 12][(j) / 12], V[((j) % 12) >> 1][(j) / 12], acc[(j) % 12], 0, 0, 0)
     const int last = nchunk - 1, last_s = last >> 2;
-    int tb_n = persistent ? tb + P.wgs_per_slice : P.n_blocks;           // the next block of this workgroup (>= n_blocks: none)
-    for (;;) {                                         // one iteration per block of this workgroup
-    const bool more = tb_n < P.n_blocks;               // wave-uniform
-    {   // this lane's slots of the fills: worked out again for every block, from a value the compiler cannot trace -- 15 registers that
-        int t2 = tid;                                  // would otherwise stay live through the K loop, which has none to spare.  The table
-        asm volatile("" : "+v"(t2));                   // loads are asked for first, so that nothing queues behind the patch loads that follow
-        lane_slots(t2);
-    }
-    // the filter operands of chunk 0 do not depend on the block record: straight from L2 into registers, asked for now
-#pragma unroll
-    for (int i = 0; i < 12; ++i) filter_piece(0, uA, i);
-    pixel_table(B);                                    // (behind Z: the previous block's store pass may still be reading that)
-    __syncthreads();                                   // every wave has left the previous block's store pass: the stages are free
-    WINO_STAMP(8);                                     // (the block record has arrived, the pixel table stands)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dmini[r] = pix_tab[mini_pidx[r]];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dmini[r] = byte_offset(dmini[r], 4 * (lane & 1));
 #pragma unroll
     for (int r = 0; r < 3; ++r) mini_piece(0, r);
 #pragma unroll
@@ -338,16 +300,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     WINO_STAMP(11);
     __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM16);        // the mini stages and the filters of chunk 0 have landed; the 16 pieces of the stages fly on
     __builtin_amdgcn_s_barrier();
-    // the next block's record (a VECTOR load: a scalar one would sit in lgkmcnt, which the patch reads wait on) and the ticket for the
-    // block after it: asked for now -- behind the wait, so they are the youngest memory operations and have chunk 0 to come back
-    int ticket = 0;
-    int4 desc_v = int4{0, 0, 0, 0};
-    if (more) {
-        int idx = tb_n;
-        asm volatile("" : "+v"(idx));
-        desc_v = P.blocks[idx];
-        if (tid == 0) ticket = atomicAdd(P.work + ks, 1);
-    }
     WINO_STAMP(1);
     WINO_READ_MINI(0, 0); WINO_READ_MINI(0, 1); WINO_READ_MINI(0, 2); WINO_READ_MINI(0, 3); WINO_READ_MINI(0, 4); WINO_READ_MINI(0, 5);
     WINO_READ_MINI(0, 6); WINO_READ_MINI(0, 7); WINO_READ_MINI(0, 8); WINO_READ_MINI(0, 9); WINO_READ_MINI(0, 10); WINO_READ_MINI(0, 11);
@@ -406,19 +358,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #undef WINO_CHUNK
     }
 #undef WINO_MFMA
-    if (more && tid == 0) {
-        pix_tab[328] = 2 * P.wgs_per_slice + ticket;
-        if (ticket == P.n_blocks - P.wgs_per_slice - 1) P.work[ks] = 0;      // the last draw of the launch: nobody asks again
-    }
     __syncthreads();                                   // every wave is done reading the stages, no DMA in flight: they become the output staging
     WINO_STAMP(3);
-    Block Bn = B;
-    int tb_nn = P.n_blocks;
-    if (more) {
-        tb_nn = __builtin_amdgcn_readfirstlane(pix_tab[328]);
-        Bn = decode(int4{__builtin_amdgcn_readfirstlane(desc_v.x), __builtin_amdgcn_readfirstlane(desc_v.y), __builtin_amdgcn_readfirstlane(desc_v.z),
-                         __builtin_amdgcn_readfirstlane(desc_v.w)});
-    }
 
     // ---- output transform Y = At2 M At4^T, At2 = [[1,1,1,0],[0,1,-1,-1]], At4 = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].
     // Every wave applies At4 to its row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS
@@ -453,25 +394,20 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
 #if POD_WINO_ELIM & 32
     return;
 #endif
-    f32x4 bias0 = f32x4{0.f, 0.f, 0.f, 0.f}, bias1 = bias0;              // (channels-last store pass; asked for before the next block's loads: vmcnt
-    if (P.bias && P.k_planes == 0) {                                     // returns in order, and those come from HBM)
-        bias0 = *reinterpret_cast<const f32x4*>(P.bias + ks * 64 + (tid & 7) * 8);
-        bias1 = *reinterpret_cast<const f32x4*>(P.bias + ks * 64 + (tid & 7) * 8 + 4);
-    }
     constexpr int ZA = 32 * TS;                // floats per position row a
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
         int m;
-        const int gy = cell(B.y0 + oy, B.Hv, B.rHv, m);
+        const int gy = cell(y0 + oy, Hv, rHv, m);
         int64_t px0[4];                                   // output pixel (of plane 0) per column, -1: not a pixel of any image
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             int n;
-            const int gx = cell(B.x0 + ox + e, B.Wv, B.rWv, n), img = m * B.gcols + n;
-            px0[e] = (n < B.gcols && img < B.n_img && gx < B.W && gy < B.H) ? (B.out_px + (int64_t)img * B.HWi) * P.k_planes + (int64_t)gy * B.W + gx : -1;
+            const int gx = cell(x0 + ox + e, Wv, rWv, n), img = m * gcols + n;
+            px0[e] = (n < gcols && img < n_img && gx < W && gy < H) ? (out_px + (int64_t)img * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
         }
-        const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (B.HWi & 3) == 0;
+        const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (HWi & 3) == 0;
         const int tile = (oy >> 1) * 4 + (tid & 3);
 #pragma unroll 2
         for (int it = 0; it < 16; ++it) {
@@ -488,7 +424,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            float* plane = P.out + (int64_t)kg * B.HWi;
+            float* plane = P.out + (int64_t)kg * HWi;
             if (vec) {
                 *reinterpret_cast<f32x4*>(plane + px0[0]) = v;
             } else {
@@ -501,20 +437,25 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     } else {
         // thread -> 8 consecutive channels (one Philox call: 16 mask bits per element) of one pixel column, rows of one parity
         const int k8 = (tid & 7) * 8, kg = ks * 64 + k8, ox = (tid >> 3) & 15, odd = tid >> 7;
+        f32x4 bias0 = f32x4{0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+        if (P.bias) {
+            bias0 = *reinterpret_cast<const f32x4*>(P.bias + kg);
+            bias1 = *reinterpret_cast<const f32x4*>(P.bias + kg + 4);
+        }
         int n;
-        const int gx = cell(B.x0 + ox, B.Wv, B.rWv, n);
-        const bool col_ok = n < B.gcols && gx < B.W;
-        int m, gy = cell(B.y0 + odd, B.Hv, B.rHv, m) - 2;                                   // canvas row B.y0 + 2 it + odd: grid row m, image row gy (B.H: the separator)
+        const int gx = cell(x0 + ox, Wv, rWv, n);
+        const bool col_ok = n < gcols && gx < W;
+        int m, gy = cell(y0 + odd, Hv, rHv, m) - 2;                                   // canvas row y0 + 2 it + odd: grid row m, image row gy (H: the separator)
         const float* rbase = lds + (ox >> 2) * TS + (ox & 3) * 64 + k8 + (odd ? ZA : 0);      // Z[a][tile][ox & 3][k8] of row a = odd
 #pragma unroll 2
         for (int it = 0; it < 8; ++it) {
             gy += 2;
-            if (gy >= B.Hv) {
-                gy -= B.Hv;
+            if (gy >= Hv) {
+                gy -= Hv;
                 ++m;
             }
-            const int img = m * B.gcols + n;
-            if (!col_ok || gy >= B.H || img >= B.n_img) continue;
+            const int img = m * gcols + n;
+            if (!col_ok || gy >= H || img >= n_img) continue;
             const float* r = rbase + it * 4 * TS;                                     // tile (it, ox >> 2)
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(r), a1 = *reinterpret_cast<const f32x4*>(r + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(r + ZA), b1 = *reinterpret_cast<const f32x4*>(r + ZA + 4);
@@ -524,7 +465,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
                 v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                 v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
-            const int64_t e = (B.out_px + (int64_t)img * B.HWi + (int64_t)gy * B.W + gx) * P.out_stride + kg;      // a multiple of 8
+            const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
@@ -546,23 +487,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     __builtin_amdgcn_s_waitcnt(0);                      // the stores have left
     WINO_STAMP(5);
     WINO_STAMP_WALL(13);
-    if (threadIdx.x == 0 && wino_trace_id < 8192) {
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_wino_trace[wino_trace_id * 16 + 6] = ((long long)xcc << 32) | hw;
+        g_wino_trace[blockIdx.x * 16 + 6] = ((long long)xcc << 32) | hw;
     }
 #endif
-    if (!more) break;
-    B = Bn;
-    r_rsrc = source(B);
-    tb = tb_n;
-    tb_n = tb_nn;
-    wino_trace_id = tb * P.KS + ks;
-    WINO_STAMP(0);
-    WINO_STAMP_WALL(12);
-    }
 }
 
 }  // namespace pod
@@ -587,26 +519,24 @@ extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t 
 
 extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                 int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                                int32_t* work, pod_stream_t stream) {
+                                pod_stream_t stream) {
     if (!in || !out || in == out || !U || !blocks || n_blocks < 0 || C < 8 || (C & 7) != 0 || K < 64 || (K & 63) != 0 ||
         !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
         return POD_E_INVALID;
     const int32_t KS = K / 64;
     if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
     if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) |
-          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks) | reinterpret_cast<uintptr_t>(work)) & 15u) != 0)
+          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
         return POD_E_INVALID;
     if (n_blocks == 0) return POD_OK;
-    // the 156 KB dynamic-LDS opt-in is a PER-DEVICE function attribute: once per device ordinal this process launches on
+    // the 130 KB dynamic-LDS opt-in is a PER-DEVICE function attribute: once per device ordinal this process launches on
     static std::once_flag once[64];
     static hipError_t attr[64];
-    static int cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
     std::call_once(once[dev], [dev] {
         attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         pod::WINO_LDS_BYTES);
-        if (attr[dev] == hipSuccess) attr[dev] = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
     });
     if (attr[dev] != hipSuccess) return POD_E_LAUNCH;
     pod::WinoParams P;
@@ -616,18 +546,8 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
     const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
-    int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
+    const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    // More than one round of workgroups and a ticket counter from the caller: one PERSISTENT workgroup per CU (the kernel needs a
-    // whole CU anyway), `resident / KS` of them per filter slice, each starting on the block of its index and drawing the rest.
-    const int resident = cus[dev] / 8 * 8;
-    P.work = nullptr;
-    P.wgs_per_slice = 0;
-    if (work && resident >= 8 && (int64_t)n_blocks * KS > resident) {
-        P.work = work;
-        P.wgs_per_slice = resident / KS;                            // <= n_blocks
-        grid = resident;
-    }
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;

@@ -76,7 +76,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
     // both (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- the
     // partial blocks at the right and bottom edges are paid once per level instead of once per image.
-    [[maybe_unused]] const int wino_trace_id = blockIdx.x;
     WINO_STAMP(0);
     WINO_STAMP_WALL(12);
     uint32_t slot_e[12];                                                  // this lane's 12 pixel slots of a stage fill (constant table: asked for first, so
@@ -545,8 +544,7 @@ extern "C" int pod_wino_filter_transform_split(const float* weight, void* Us, in
 
 extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                       int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                                      int32_t* work, pod_stream_t stream) {
-    (void)work;      // (a block per workgroup: the persistent schedule of pod_wino_conv3x3 is not built for this kernel)
+                                      pod_stream_t stream) {
     if (!in || !out || in == out || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0 ||
         !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
         return POD_E_INVALID;
@@ -570,7 +568,7 @@ extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* U
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
-    P.seed = seed; P.offset = offset; P.work = nullptr; P.wgs_per_slice = 0;
+    P.seed = seed; P.offset = offset;
     const int per8 = 8 / KS;
     const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;

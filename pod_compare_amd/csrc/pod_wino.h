@@ -18,21 +18,18 @@ constexpr uint32_t STREAM_DROPOUT_CONV = 0x64726f70u;   // = STREAM_DROPOUT of k
 
 constexpr int WINO_U_FLOATS = 24 * 2 * 64 * 4;          // filter slab of a chunk: [24 positions][h][j][4 channels]  48 KB
 constexpr int WINO_SB_FLOATS = 384 * 32;                 // raw patch stage of a SUPER-CHUNK (32 input channels): [pixel slot 360 (+24: 48 whole DMA instructions)][8 parts of 16 B], 48 KB
-constexpr int WINO_Z_BYTES = 4 * 32 * 4 * 65 * 4;        // 133 120 B: the output staging Z[a][tile][column][64 channels + pad]; aliases the two patch stages (96 KB)
-constexpr int WINO_MINI_FLOATS = 3072;                   // a mini stage: the 8-channel patch of one of a block's first two chunks, 12 KB
-constexpr int WINO_LDS_BYTES = WINO_Z_BYTES + 2 * WINO_MINI_FLOATS * 4 + 1536;   // 159 232 B of the CU's 160 KB: + (k11) mini stages and pixel table BEHIND the
-                                                         // staging, so that a persistent workgroup can prepare its next block while the store pass still reads Z
+constexpr int WINO_LDS_BYTES = 4 * 32 * 4 * 65 * 4;      // 133 120 B of the CU's 160 KB: the output staging (the K loop needs 24 KB)
 
 // -DPOD_TRACE (diagnostics build, tools/wino_trace.py): s_memtime stamps of every workgroup's phases
 #ifdef POD_TRACE
 static __device__ long long g_wino_trace[8192 * 16];
 #define WINO_STAMP(k)                                                                                          \
     do {                                                                                                       \
-        if (threadIdx.x == 0 && wino_trace_id < 8192) g_wino_trace[wino_trace_id * 16 + (k)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
 #define WINO_STAMP_WALL(k)                                                                                     \
     do {                                                                                                       \
-        if (threadIdx.x == 0 && wino_trace_id < 8192) g_wino_trace[wino_trace_id * 16 + (k)] = wall_clock64();       \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_wino_trace[blockIdx.x * 16 + (k)] = wall_clock64();       \
     } while (0)
 #else
 #define WINO_STAMP(k)
@@ -61,8 +58,6 @@ struct WinoParams {
     uint32_t thresh;
     float scale;
     uint64_t seed, offset;
-    int32_t* work;            // persistent mode: one self-resetting ticket counter per filter slice (zero between launches); null: a block per workgroup
-    int32_t wgs_per_slice;    // persistent mode: workgroups serving one slice (<= n_blocks); a workgroup starts on block `its index` and draws the rest
 };
 
 

@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 5
+POD_ABI_VERSION = 4
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -110,9 +110,9 @@ def load() -> ctypes.CDLL:
     lib.pod_bias_act_to_nhwc.argtypes = [P, P, P, c_int64, c_int32, c_int64, c_int32, P]
     lib.pod_expand_dropout.argtypes = [P, P, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_wino_filter_transform.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_wino_conv3x3.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P, P]
+    lib.pod_wino_conv3x3.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_wino_filter_transform_split.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_wino_conv3x3_split.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P, P]
+    lib.pod_wino_conv3x3_split.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_dump_cls_normals.argtypes = [POINTER(PodConfig), POINTER(PodLevel), c_int32, P, P]
     lib.pod_dump_box_normals.argtypes = [POINTER(PodConfig), P, c_int32, P, P]

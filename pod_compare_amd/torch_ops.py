@@ -21,7 +21,7 @@ from typing import List, Tuple
 
 import torch
 
-from . import hip, hotpath, wino
+from . import hip, hotpath
 
 _LIB = torch.library.Library("pod_mi355x", "DEF")
 _LIB.define("predict(Tensor[] box_cls, Tensor[] box_delta, Tensor[] box_cls_var, Tensor[] box_reg_var, Tensor[] anchors, "
@@ -160,7 +160,7 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     with torch.cuda.device(src.device):
         hip.check(hip.load().pod_wino_conv3x3(hip.ptr(src), hip.ptr(out), hip.ptr(U), hip.ptr(bias), hip.ptr(blocks), int(blocks.shape[0]), C, Kpad,
                                               int(K) if planes else 0, 1 if relu else 0, float(dropout_p), int(seed), int(offset),
-                                              hip.ptr(wino.work_words(src.device)), hip.current_stream()), "pod_wino_conv3x3")
+                                              hip.current_stream()), "pod_wino_conv3x3")
     return out
 
 

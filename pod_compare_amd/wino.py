@@ -87,24 +87,6 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
     return t
 
 
-_WORK = {}
-PERSISTENT = os.environ.get("POD_WINO_PERSISTENT", "1") != "0"
-
-
-def work_words(device) -> Optional[torch.Tensor]:
-    """The 8 ticket counters of pod_wino_conv3x3's persistent schedule (include/pod_mi355x.h: zero between launches, owned by one
-    stream): one tensor per (device, current stream), zeroed once.  POD_WINO_PERSISTENT=0: None, a block per workgroup."""
-    if not PERSISTENT:
-        return None
-    dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), hip.current_stream())
-    w = _WORK.get(key)
-    if w is None:
-        w = torch.zeros(8, dtype=torch.int32, device=dev)
-        _WORK[key] = w
-    return w
-
-
 # POD_WINO_SPLIT=1: pod_wino_conv3x3_split (csrc/k12_wino_conv_split.hip) where the channel count allows it (C % 16 == 0): the same
 # convolution with every fp32 product formed from exact 3-way bf16 splits on the bf16 matrix cores (fp32-class accuracy, see its header)
 SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "0") == "1"
@@ -145,5 +127,5 @@ class WinoConv:
         fn = hip.load().pod_wino_conv3x3_split if self.split else hip.load().pod_wino_conv3x3
         hip.check(fn(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
                      table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
-                     seed, offset, hip.ptr(work_words(src.device)), hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
+                     seed, offset, hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
         return dst

@@ -127,15 +127,15 @@ def test_invalid_arguments_are_rejected():
     u = torch.zeros(24 * 64 * 8, device="cuda")
     t = block_table([(16, 16)], 1, "cuda")
     s = hip.current_stream()
-    ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s)
+    ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)
     assert ok == 0
-    for args in ((x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 12, 64, 0, 0, 0.0, 0, 0, None, s),      # C % 8
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 96, 0, 0, 0.0, 0, 0, None, s),       # K % 64
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 192, 0, 0, 0.0, 0, 0, None, s),      # K / 64 not in 1,2,4,8
-                 (x.data_ptr(), x.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s),       # in place
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 63, 0, 0.5, 0, 0, None, s),      # planes + dropout
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 1.0, 0, 0, None, s),       # p = 1
-                 (x.data_ptr(), y.data_ptr(), None, None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s)):
+    for args in ((x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 12, 64, 0, 0, 0.0, 0, 0, s),      # C % 8
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 96, 0, 0, 0.0, 0, 0, s),       # K % 64
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 192, 0, 0, 0.0, 0, 0, s),      # K / 64 not in 1,2,4,8
+                 (x.data_ptr(), x.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s),       # in place
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 63, 0, 0.5, 0, 0, s),      # planes + dropout
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 1.0, 0, 0, s),       # p = 1
+                 (x.data_ptr(), y.data_ptr(), None, None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)):
         assert lib.pod_wino_conv3x3(*args) == -1
     assert lib.pod_wino_filter_transform(u.data_ptr(), u.data_ptr(), 64, 12, s) == -1
 
@@ -307,40 +307,3 @@ def test_bottleneck_with_conv2_on_the_winograd_kernel_equals_the_miopen_bottlene
     assert got.shape == want.shape == (1, 4 * mid, H, W)
     assert float((got - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
     assert not torch.equal(got, want)            # (two different convolution kernels did run)
-
-
-@pytest.mark.parametrize("K,planes", [(256, False), (128, False), (63, True)])
-def test_persistent_schedule_equals_a_block_per_workgroup_and_leaves_its_counters_zero(K, planes, monkeypatch):
-    """ABI 5: with the 8 `work` words a launch of more than one round of workgroups runs as one persistent workgroup per CU that draws its
-    blocks from a ticket counter per filter slice (first two blocks static, the rest two ahead).  Same bits as a block per workgroup
-    (work = NULL), every block exactly once whatever the draw order, the counters back at zero after every launch -- also with three
-    launches in flight on three streams (one set of words per stream) and for 1, 2 and 4 filter slices."""
-    from pod_compare_amd import wino
-    levels, copies, C = [(48, 84), (24, 42), (7, 11)], 14, 64
-    w, b, xs = make(levels, copies, C, K, seed=K)
-    conv, table = WinoConv(w, b, split=False), block_table(levels, copies, "cuda")
-    assert table.shape[0] * (conv.Kpad // 64) > 256                      # more than one round on a 256-CU chip: 4.6 / 2.3 / 1.1 (the last: fewer
-                                                                         # blocks than two per workgroup -- only static ones, every draw fails)
-    src = flat(xs)
-    def run(s):
-        dst = torch.full((copies * sum(h * wd for h, wd in levels) * (K if planes else conv.Kpad),), float("nan"), device="cuda")
-        return conv(s, dst if planes else dst.view(-1, conv.Kpad), table, relu=not planes, dropout_p=0.0 if planes else 0.25, seed=3, planes=planes)
-    monkeypatch.setattr(wino, "PERSISTENT", False)
-    ref = run(src)
-    torch.cuda.synchronize()
-    assert torch.isfinite(ref).all()
-    monkeypatch.setattr(wino, "PERSISTENT", True)
-    for rep in range(3):
-        out = run(src)
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref)
-        assert int(wino.work_words("cuda").abs().sum()) == 0
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    outs = [None] * 3
-    for rep in range(3):
-        for j, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                outs[j] = run(src)
-        torch.cuda.synchronize()
-        assert all(torch.equal(o, ref) for o in outs)
-    assert len({id(t) for t in wino._WORK.values()}) >= 4 and all(int(t.abs().sum()) == 0 for t in wino._WORK.values())

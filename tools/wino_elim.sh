@@ -11,7 +11,6 @@ if [ "$cmd" = build ]; then
   done
 else
   mkdir -p gpurun_out/$TAG
-  export POD_WINO_PERSISTENT=0      # (the elimination builds leave a workgroup early: a block per workgroup, no ticket counters)
   out=gpurun_out/$TAG/wino_elim.txt; : > $out
   echo "elim 0: $(python tools/wino_only.py 20 19 bench 2>&1 | grep wino)" | tee -a $out
   for b in $bits; do
