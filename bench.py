@@ -271,7 +271,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # POD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group on device_id, device check, flush all_gather, barriers)
+    # even with one rank -- under `torch.distributed.run --nproc-per-node 1` this is RCCL's first contact on a one-GPU box
+    multi = world > 1 or (os.environ.get("POD_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if multi:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -283,7 +286,7 @@ def main():
     from pod_compare_amd import wino
     wino.SPLIT_BF16 = bool(args.split_bf16)
     rank_devices = [local_rank]
-    if world > 1:
+    if multi:
         # one process per GPU: every rank must sit on a device of its own (PCI bus id, not just the ordinal: two ranks that both see
         # "cuda:0" through different HIP_VISIBLE_DEVICES are fine, two ranks on the same physical device are not)
         bus = torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else local_rank
@@ -363,7 +366,7 @@ def main():
             return hps[s].run(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, image_size=net_hw, out_size=FRAME_HW)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     with torch.no_grad():
@@ -384,7 +387,7 @@ def main():
             streams[0].wait_stream(st)          # the flush below reads every stream's detections
         flush_ms = 0.0
         # the path's only collective: gather the fixed-stride detection records of this flush
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             t_images = time.perf_counter() - t0
             tf = time.perf_counter()
@@ -397,13 +400,13 @@ def main():
             torch.cuda.synchronize()
             flush_ms = 1e3 * (time.perf_counter() - tf)
         torch.cuda.synchronize()
-        if world == 1:
+        if not multi:
             t_images = time.perf_counter() - t0
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     per_rank = [args.steps / t_images]
-    if world > 1:
+    if multi:
         t = stage(torch.tensor([dt, flush_ms, t_images, host_enqueue_ms], device=dev, dtype=torch.float64))
         tl = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(tl, t)
@@ -445,11 +448,11 @@ def main():
                                                 "the head does not compute those 3 of its 4N subnet evaluations",
                    "members_on_this_gpu": len(members),
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
-                   "rccl_ranks": world, "collective_backend": backend if world > 1 else None, "rank_devices": rank_devices,
+                   "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
                    "conv3x3_kernel": "pod_wino_conv3x3_split (bf16 matrix cores, 3-way splits)" if args.split_bf16 else "pod_wino_conv3x3 (fp32 matrix cores)",
                    "rng": "in-kernel Philox4x32-10, fresh key per image"},
-        "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if world > 1 else None, "host_enqueue_ms_per_image": host_enqueue_ms,
+        "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "mean_detections": n_det_mean,
     }
     if second is not None:
@@ -458,7 +461,7 @@ def main():
         diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev, R, N, D, mc)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

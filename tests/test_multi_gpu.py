@@ -1,4 +1,6 @@
-"""First contact with RCCL before the driver's scaling run: skipped unless the box exposes >= 2 GPUs (the gpurun boxes have one).
+"""First contact with RCCL before the driver's scaling run.  One test runs everywhere: bench.py's multi-rank code path on backend nccl
+with ONE rank (POD_BENCH_FORCE_DIST=1 under torch.distributed.run: process group on device_id, device check, flush all_gather, barriers).
+The others are skipped unless the box exposes >= 2 GPUs (the gpurun boxes have one).
 bench.py --gpus 2 on backend nccl (image sharding, one all_gather flush), apply_net on two nccl ranks, and
 config 5 with one ensemble member per rank over RCCL point-to-point (>= 6 GPUs; the batch_isend_irecv path the gloo tests cannot see)."""
 import json
@@ -19,6 +21,17 @@ def bench(*args):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, env=ENV, timeout=1500, check=True,
                          stdout=subprocess.PIPE, universal_newlines=True).stdout
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_multi_rank_path_on_nccl_with_one_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(34500 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--no-diagnostics"]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(ENV, POD_BENCH_FORCE_DIST="1"), timeout=900, check=True, stdout=subprocess.PIPE,
+                         universal_newlines=True).stdout
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "nccl" and line["config"]["rank_devices"] == [0]
+    assert line["flush_ms"] is not None and line["flush_ms"] < 1000.0 and len(line["per_rank_images_per_s"]) == 1 and line["value"] > 0
 
 
 @pytest.mark.skipif(N_GPU < 2, reason="needs 2 GPUs (RCCL over xGMI)")
