@@ -372,7 +372,8 @@ __device__ __forceinline__ int topk_cached(TopkLds& S, Fetch fetch, int count, i
             int at = 0;
             if (ln == leader) at = atomicAdd(&S.fill, __popcll(sm));
             at = __shfl(at, leader, 64);
-            if (sel) S.keys[at + __popcll(sm & ((1ull << ln) - 1ull))] = kk[u];
+            const int slot = at + __popcll(sm & ((1ull << ln) - 1ull));
+            if (sel && slot < n_clear) S.keys[slot] = kk[u];      // (always true for distinct keys; a caller's duplicates must not write past the buffer)
         }
     }
     __syncthreads();
