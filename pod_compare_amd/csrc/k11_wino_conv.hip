@@ -29,8 +29,9 @@
 // MFMAs.  The output transform applies At4 to each wave's row in registers, parks the result in LDS (128 KB) and combines the
 // four rows (At2) in the store pass.
 //
-// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same 64-channel filter slice (1.5 MB
-// for C = 256), which therefore stays in that XCD's 4 MB L2 while the activations stream through.
+// Launch: blockIdx & 7 is the XCD (round-robin dispatch); an XCD always works on the same TWO 64-channel filter slices (3 MB for
+// C = 256), which therefore stay in that XCD's 4 MB L2, and takes a block with both slices back to back, so that the second
+// workgroup's patch comes out of the L2 as well (wino_schedule, pod_wino.h).
 #include "pod_wino.h"
 
 namespace pod {
@@ -75,9 +76,8 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* __restrict__ w
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = blockIdx.x & 7;
-    const int ks = xcd % P.KS;
-    const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
+    int ks, tb;
+    wino_schedule(P.KS, P.n_blocks, ks, tb);
     if (tb >= P.n_blocks) return;
     // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // = x0 + s x1 with wave-uniform row offsets and sign (6 columns), followed by the 6-point column transform Bt6; every
     // transformed value feeds two MFMAs (kb).
     //   * filter operands never touch LDS: a lane needs U_q[its 4 channels][its output channel] for its row's 6 positions and
-    //     both channel blocks = 12 x 16 bytes per chunk, loaded straight from L2 (the filter slice of this XCD) one chunk ahead;
+    //     both channel blocks = 12 x 16 bytes per chunk, loaded straight from L2 (the filter slices of this XCD) one chunk ahead;
     //     the four waves together read each slab byte exactly once;
     //   * the raw 18x18-pixel patch goes global -> LDS by LDS-DMA (buffer_load ... lds), 16-byte slots [h][row][col parity][col/2];
     //     out-of-range buffer offsets return 0.0 -- that IS the zero padding of the convolution; pad slots load nothing.
@@ -545,8 +545,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    const int per8 = 8 / KS;                                        // tile blocks per group of 8 consecutive workgroups
-    const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
+    const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();

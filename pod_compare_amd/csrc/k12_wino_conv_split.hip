@@ -68,9 +68,8 @@ __global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restri
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = blockIdx.x & 7;
-    const int ks = xcd % P.KS;
-    const int tb = (int)(blockIdx.x >> 3) * (8 / P.KS) + xcd / P.KS;
+    int ks, tb;
+    wino_schedule(P.KS, P.n_blocks, ks, tb);
     if (tb >= P.n_blocks) return;
     // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
@@ -569,8 +568,7 @@ extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* U
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    const int per8 = 8 / KS;
-    const int64_t grid = ((int64_t)n_blocks + per8 - 1) / per8 * 8;
+    const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();

@@ -149,8 +149,8 @@ for suffix, split in (("w", False), ("ws", True)):
               "LDS bank conflicts SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.2f;" % (pm.get("SQ_LDS_BANK_CONFLICT", 0) / max(pm.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
               "direct-convolution rate 2*9*pixels*256*256 / t = %.1f TFLOP/s.  HBM-side traffic (FETCH_SIZE x 2 on gfx950, KB units) %.2f GB read + %.2f GB written" % (
                   2 * 9 * 19 * 21486 * 65536 / avg_ns / 1e3, fetch / 1e9, write / 1e9),
-              "per launch = %.2f TB/s: the activations (0.41 GB) are read once per 64-channel filter slice (4 slices, each pinned to two XCDs so its filters" % ((fetch + write) / avg_ns / 1e3),
-              "stay in that L2) plus the 18x18 / 16x16 halo; far below the HBM roof.", ""]
+              "per launch = %.2f TB/s: the activations (0.41 GB) are read once per PAIR of 64-channel filter slices (an XCD holds two of the four slices in" % ((fetch + write) / avg_ns / 1e3),
+              "its L2 and takes a block with both, back to back) plus the 18x18 / 16x16 halo; far below the HBM roof.", ""]
     json.dump({"kernel": "pod_wino_conv3x3_split" if split else "pod_wino_conv3x3", "levels": [[96, 168], [48, 84], [24, 42], [12, 21], [6, 11]], "copies": 19,
                "traffic_bytes": fetch + write, "fetch_bytes_corrected": fetch,
                "write_bytes": write, "avg_launch_ns_rocprof": avg_ns, "mfma_busy_frac": mfma_busy,
