@@ -51,3 +51,10 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
     boxes_for_nms = boxes + offsets[:, None]
     return _nms_sorted_greedy(boxes_for_nms, scores, iou_threshold)
+
+
+class ShapeSpec:
+    """detectron2.layers.ShapeSpec: the (channels, height, width, stride) note a backbone leaves for the heads."""
+
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride

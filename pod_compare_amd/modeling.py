@@ -279,6 +279,10 @@ class ProbabilisticRetinaNetHead(nn.Module):
         self.fused_relu_dropout = True      # GPU only; falls back to torch ops on CPU tensors
         self.dropout_seed = 0x0D50ED
         self._drop_calls = 0                # distinct Philox counter block per call
+        # parity mode (the head's analogue of the hot path's eps replay): a callable (subnet 0 = cls / 1 = bbox, layer, level,
+        # copy) -> bool keep-mask (C, H, W) that replaces the Philox dropout masks, so that a head evaluation can be held to
+        # the reference's `nn.Dropout` on recorded masks (tests/test_head_reference*.py); None in production
+        self.dropout_replay = None
         self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims = compute_cls_var, compute_bbox_cov, bbox_cov_dims
         self.cls_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
         self.bbox_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
@@ -298,7 +302,12 @@ class ProbabilisticRetinaNetHead(nn.Module):
             nn.init.normal_(self.bbox_cov.weight, mean=0, std=0.0001)
             nn.init.constant_(self.bbox_cov.bias, 0)
 
-    def _trunk(self, convs, feature, copies: int, dropout: bool):
+    def _replayed(self, x: torch.Tensor, sid: int, layer: int, level: int) -> torch.Tensor:
+        """x (copies, C, H, W), any memory format, times the replayed keep-masks / (1 - p) (torch's dropout arithmetic)."""
+        keep = torch.stack([self.dropout_replay(sid, layer, level, c) for c in range(x.shape[0])]).to(x.device)
+        return x * (keep.to(x.dtype) / (1.0 - self.dropout_rate))
+
+    def _trunk(self, convs, feature, copies: int, dropout: bool, level: int = 0):
         """`copies` independent evaluations of a subnet, batched on dim 0.  The first conv+ReLU is
         identical across copies (dropout only follows it) and is computed once.
 
@@ -313,6 +322,12 @@ class ProbabilisticRetinaNetHead(nn.Module):
             for conv in convs[1:]:
                 x = conv_bias_act(conv, x, relu=True)
             return x                                  # batch 1; shared by every copy
+        sid = 0 if convs is self.cls_subnet else 1
+        if self.dropout_replay is not None:
+            x = self._replayed(x.expand(copies, -1, -1, -1), sid, 0, level)
+            for j, conv in enumerate(convs[1:], 1):
+                x = self._replayed(conv_bias_act(conv, x, relu=True) if fused else F.relu(conv(x)), sid, j, level)
+            return x.contiguous()
         if fused and x.numel() % 4 == 0:
             from . import hip
             src = x if (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)) else x.contiguous()
@@ -353,15 +368,29 @@ class ProbabilisticRetinaNetHead(nn.Module):
             return y, 1
         offn = level_pixel_offsets(levels, copies)
         a = torch.empty((offn[-1], C), dtype=x0.dtype, device=x0.device)
+        replay = self.dropout_replay is not None
+        sid = 0 if convs is self.cls_subnet else 1
+
+        def mask_in_place(buf, layer):              # parity mode: the recorded masks on the channels-last images of the buffer
+            for i, (h, w) in enumerate(levels):
+                v = buf[offn[i]:offn[i + 1]].view(copies, h, w, C)
+                v.copy_(self._replayed(v.permute(0, 3, 1, 2), sid, layer, i).permute(0, 2, 3, 1))
+
         for i, (h, w) in enumerate(levels):                                         # copies x dropout(first activation)
             self._drop_calls += 1
-            hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies, float(self.dropout_rate),
+            hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies,
+                                             0.0 if replay else float(self.dropout_rate),
                                              self.dropout_seed, self._drop_calls << 34, hip.current_stream()), "pod_expand_dropout")
+        if replay:
+            mask_in_place(a, 0)
         tn = block_table(levels, copies, x0.device)
         b = torch.empty_like(a)
-        for conv in convs[1:]:
+        for j, conv in enumerate(convs[1:], 1):
             self._drop_calls += 1
-            self._wino(conv)(a, b, tn, relu=True, dropout_p=self.dropout_rate, seed=self.dropout_seed, offset=self._drop_calls << 34)
+            self._wino(conv)(a, b, tn, relu=True, dropout_p=0.0 if replay else self.dropout_rate, seed=self.dropout_seed,
+                             offset=self._drop_calls << 34)
+            if replay:
+                mask_in_place(b, j)
             a, b = b, a
         return a, copies
 
@@ -439,9 +468,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
                 if self.compute_bbox_cov:
                     delta_covs = ex(self._predict_all_levels(self.bbox_cov, tb, levels, 1, 0, 1, 1))
             return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
-        for f in features:
-            tc = self._trunk(self.cls_subnet, f, cls_copies, dropout)
-            tb = self._trunk(self.bbox_subnet, f, box_copies, dropout)
+        for level, f in enumerate(features):
+            tc = self._trunk(self.cls_subnet, f, cls_copies, dropout, level)
+            tb = self._trunk(self.bbox_subnet, f, box_copies, dropout, level)
             if dropout:
                 # (a channels-last trunk hands its last activation over as NCHW planes: the A*K / A*4-channel predictor convs
                 #  are faster as NCHW Winograd calls than as NHWC implicit GEMMs)

@@ -26,7 +26,8 @@ def sha(tensors) -> str:
 
 def fixture_paths(prefix=""):
     skip = ("unit_functions.npz", "eval_matching.npz", "eval_metrics.npz")     # not whole-predictor fixtures
-    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if not p.endswith(skip))
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz"))
+                  if not p.endswith(skip) and not os.path.basename(p).startswith("head_"))      # head_*: model fixtures (row a1)
 
 
 def fixture_id(path):

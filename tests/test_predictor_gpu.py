@@ -257,9 +257,9 @@ def test_eval_mode_trunk_sharing_on_the_gpu():
     calls = {"n": 0}
     real = model.head._trunk
 
-    def counting(convs, feature, copies, dropout):
+    def counting(convs, feature, copies, dropout, level=0):
         calls["n"] += 1
-        return real(convs, feature, copies, dropout)
+        return real(convs, feature, copies, dropout, level)
 
     real_all = model.head._trunk_all_levels
 
