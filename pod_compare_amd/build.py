@@ -48,7 +48,11 @@ def build_library(force: bool = False, verbose: bool = False, tag: str = "") -> 
     POD_MI355X_LIB=pod_compare_amd/lib/<tag>/libpod_mi355x.so); the shipped library is only ever built without a tag.
     POD_TAG_SOURCES="k11_wino_conv.hip ..." limits what a tagged build recompiles (with its extra defines); the other
     objects are the shipped ones."""
-    tag = "" if tag == "__shipped__" else (tag or os.environ.get("POD_BUILD_TAG", ""))
+    shipped = tag == "__shipped__"
+    tag = "" if shipped else (tag or os.environ.get("POD_BUILD_TAG", ""))
+    if not tag and not shipped and (os.environ.get("POD_TRACE") == "1" or os.environ.get("POD_EXTRA_DEFINES")):
+        raise RuntimeError("POD_TRACE / POD_EXTRA_DEFINES only apply to tagged builds (set POD_BUILD_TAG=<name>; load the result with "
+                           "POD_MI355X_LIB=pod_compare_amd/lib/<name>/libpod_mi355x.so): the shipped library is always the plain source")
     libdir = os.path.join(LIBDIR, tag) if tag else LIBDIR
     lib = os.path.join(libdir, "libpod_mi355x.so")
     os.makedirs(libdir, exist_ok=True)

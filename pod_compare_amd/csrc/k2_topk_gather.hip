@@ -360,7 +360,8 @@ __device__ __forceinline__ int topk_cached(TopkLds& S, Fetch fetch, int count, i
     const int n_cand = (want - remaining) + bucket;            // exact count of present keys >= prefix
     int n_sort = 1;
     while (n_sort < n_cand) n_sort <<= 1;
-    const int n_clear = SORT ? n_sort : cap;
+    if (n_sort > SORT_CAP) n_sort = SORT_CAP;                 // only a caller's duplicate keys get here (distinct keys narrow to <= cap): the excess is dropped
+    const int n_clear = SORT ? n_sort : (cap < SORT_CAP ? cap : SORT_CAP);
     for (int i = tid; i < n_clear; i += TOPK_THREADS) S.keys[i] = 0ull;
     __syncthreads();
 #pragma unroll

@@ -182,6 +182,12 @@ class HotPath:
         self._dirty = False      # an enqueue failed half way: counters / bitmap may be non-zero, reset before the next image
 
     # ------------------------------------------------------------------------------------------
+    def set_anchors(self, anchors: Sequence[torch.Tensor]) -> None:
+        """Replaces the workspace's copy of the anchors (same geometry) in place, on the current stream."""
+        new = torch.cat([a.to(self.anchors.device, torch.float32) for a in anchors])
+        assert new.shape == self.anchors.shape, (new.shape, self.anchors.shape)
+        self.anchors.copy_(new)
+
     def _make_cfg(self) -> hip.PodConfig:
         p = self.p
         c = hip.PodConfig()

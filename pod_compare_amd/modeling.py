@@ -168,12 +168,18 @@ def wino_of(conv: nn.Conv2d):
     return cached[1]
 
 
+def _wino_limits() -> int:
+    from .wino import MAX_CANVAS_BYTES
+    return MAX_CANVAS_BYTES
+
+
 def wino_eligible(conv: Optional[nn.Conv2d], x: torch.Tensor) -> bool:
     """pod_wino_conv3x3 can stand in for `conv` on x: 3x3 / stride 1 / pad 1, fp32 on the GPU, one image, channel counts it tiles."""
     return (WINO_BACKBONE and FUSE_CONV_TAIL and conv is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1
             and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and conv.groups == 1
             and tuple(conv.dilation) == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels in (64, 128, 256, 512)
-            and x.shape[2] < 4096 and x.shape[3] < 4096)
+            and x.shape[2] < 4096 and x.shape[3] < 4096
+            and x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 4 <= _wino_limits())      # 32-bit offsets inside a canvas
 
 
 def wino_conv_nchw(conv: nn.Conv2d, x: torch.Tensor, relu: bool, pre_bias: Optional[torch.Tensor] = None, pre_relu: bool = False) -> torch.Tensor:

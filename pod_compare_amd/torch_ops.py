@@ -35,7 +35,9 @@ _LIB.define("wino_filter_transform(Tensor weight) -> Tensor")
 _LIB.define("wino_conv3x3(Tensor src, Tensor U, Tensor? bias, Tensor blocks, int K, int out_elements, bool planes=False, bool relu=False, "
             "float dropout_p=0.0, int seed=0, int offset=0) -> Tensor")
 
-_PATHS = {}
+_PATHS = {}            # key -> [HotPath, anchor identity, the anchor tensors]; insertion order = LRU order
+_MAX_PATHS = 16
+_TABLES_OK = {}        # (data_ptr, _version, shape, src pixels, out elements, per-pixel) of block tables already validated
 
 
 def _check_dense(name: str, ts: List[torch.Tensor], like: List[torch.Tensor]) -> None:
@@ -66,16 +68,27 @@ def _predict(box_cls, box_delta, box_cls_var, box_reg_var, anchors, mode, image_
     dev = box_cls[0].device
     shapes = tuple(tuple(t.shape[2:]) for t in box_cls)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    # the workspace keeps a copy of the anchors: a call with other anchor tensors (same shapes) must not decode against the first ones
-    akey = tuple((a.data_ptr(), a._version, tuple(a.shape)) for a in anchors)
     key = (shapes, A, K, n_runs, bool(box_cls_var), D, str(dev), stream, topk_candidates, score_thresh, nms_thresh, max_detections,
-           cls_var_num_samples, affinity_thresh, merge_quirk, akey)
-    hp = _PATHS.get(key)
-    if hp is None:      # one workspace per (geometry, stream), as the predictor keeps them
+           cls_var_num_samples, affinity_thresh, merge_quirk)
+    # The workspace keeps a COPY of the anchors.  The entry also keeps the caller's anchor tensors alive (so that their addresses
+    # cannot be handed to other tensors while the identity below is trusted) and re-uploads into the same workspace when a call
+    # brings different ones -- detectron2's anchor generator makes new tensors on every forward; that must neither decode
+    # against stale anchors nor grow the cache.
+    akey = tuple((a.data_ptr(), a._version, tuple(a.shape)) for a in anchors)
+    entry = _PATHS.pop(key, None)
+    if entry is None:      # one workspace per (geometry, stream), as the predictor keeps them
         p = hotpath.PathParams(num_classes=K, num_anchors=A, topk_candidates=topk_candidates, score_thresh=score_thresh,
                                nms_thresh=nms_thresh, max_detections=max_detections, cls_var_num_samples=cls_var_num_samples,
                                affinity_thresh=affinity_thresh, merge_quirk=merge_quirk)
-        hp = _PATHS[key] = hotpath.HotPath(shapes, anchors, p, n_runs=n_runs, has_cls_var=bool(box_cls_var), cov_dims=D, device=dev)
+        entry = [hotpath.HotPath(shapes, anchors, p, n_runs=n_runs, has_cls_var=bool(box_cls_var), cov_dims=D, device=dev), akey, list(anchors)]
+    elif entry[1] != akey:
+        with torch.cuda.device(dev):
+            entry[0].set_anchors(anchors)
+        entry[1], entry[2] = akey, list(anchors)
+    _PATHS[key] = entry                                   # most recently used last
+    while len(_PATHS) > _MAX_PATHS:
+        _PATHS.pop(next(iter(_PATHS)))
+    hp = entry[0]
     with torch.cuda.device(dev):
         det = hp.run(mode, list(box_cls), list(box_delta), list(box_cls_var) or None, list(box_reg_var) or None,
                      image_size=tuple(image_size), out_size=tuple(out_size), box_merge_mode=box_merge_mode,
@@ -144,17 +157,23 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == Kpad), lambda: "bias: round_up(K, 64) fp32 values")
     torch._check(planes or out_elements == src.shape[0] * Kpad, lambda: "channels-last output: out_elements == pixels * round_up(K, 64)")
     torch._check(0.0 <= dropout_p < 1.0 and not (planes and dropout_p), lambda: "dropout_p in [0, 1), 0 with planes=True")
-    if blocks.shape[0]:
-        # the kernel reads and writes at offsets taken from the table: every canvas must lie inside the two buffers
+    per_px = int(K) if planes else Kpad
+    tkey = (blocks.data_ptr(), blocks._version, int(blocks.shape[0]), int(src.shape[0]), int(out_elements), per_px, C)
+    if blocks.shape[0] and _TABLES_OK.get(tkey) is not blocks:
+        # the kernel reads and writes at offsets taken from the table: every canvas must lie inside the two buffers and inside the
+        # kernel's 32-bit byte offsets (buffer resource size; the out-of-image sentinel 0x7FFFFF00 must lie past the canvas).
+        # Validated once per table (a device round trip): the entry keeps the table alive, so its address cannot be reused.
         b = blocks.to(torch.int64)
         z, w = b[:, 2], b[:, 3]
         gcols, H, W, n = (z >> 24) & 0xFF, (z >> 12) & 0xFFF, z & 0xFFF, (w >> 24) & 0xFF
         last_in, last_out = b[:, 0] + n * H * W, b[:, 1] + n * H * W
-        per_px = int(K) if planes else Kpad
         ok = ((b[:, 0] >= 0) & (b[:, 1] >= 0) & (H > 0) & (W > 0) & (n > 0) & (n <= 127) & (gcols > 0) & (last_in <= src.shape[0])
               & (last_out * per_px <= int(out_elements)) & (((w >> 12) & 0xFFF) * 16 < ((n + gcols - 1) // gcols) * (H + 1))
-              & ((w & 0xFFF) * 16 < gcols * (W + 1)))
-        torch._check(bool(ok.all()), lambda: "blocks: a record lies outside src / the output (record {})".format(int((~ok).nonzero()[0])))
+              & ((w & 0xFFF) * 16 < gcols * (W + 1)) & (n * H * W * max(C, per_px) * 4 <= 2 ** 31 - 256))
+        torch._check(bool(ok.all()), lambda: "blocks: a record lies outside src / the output / the 32-bit canvas (record {})".format(int((~ok).nonzero()[0])))
+        if len(_TABLES_OK) >= 64:
+            _TABLES_OK.pop(next(iter(_TABLES_OK)))
+        _TABLES_OK[tkey] = blocks
     out = torch.zeros(int(out_elements), dtype=torch.float32, device=src.device) if planes else \
         torch.empty((src.shape[0], Kpad), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):

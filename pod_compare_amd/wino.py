@@ -49,25 +49,33 @@ def canvas_layout(h: int, w: int, n: int) -> Tuple[int, int, List[Tuple[int, int
     return best
 
 
+MAX_CANVAS_BYTES = 2 ** 31 - 256     # the kernels address a canvas (the images of one table record) with 32-bit byte offsets; the
+                                      # out-of-image sentinel 0x7FFFFF00 must lie past it
+
+
 def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copies: Optional[int] = None, in_first: int = 0,
-                out_copies: Optional[int] = None) -> torch.Tensor:
+                out_copies: Optional[int] = None, channels: int = 512) -> torch.Tensor:
     """int32 (n_blocks, 4) records of pod_wino_conv3x3 (include/pod_mi355x.h): {first pixel of image 0 in the input buffer, in the
     output buffer, grid_cols << 24 | H << 12 | W, n_images << 24 | block_row << 12 | block_col}, one per 16x16-pixel block of a
     CANVAS on which the `copies` images of a level stand in a grid, one zero row / column apart (`canvas_layout`): partial blocks
     at the right and bottom edges are paid once per level, not once per image (a 6 x 11 map costs 1/7 of a block instead of one).
     The input buffer holds `in_copies` images per level (level-major) of which images in_first .. in_first + copies - 1 are read;
-    the output buffer holds `out_copies` per level and images 0 .. copies - 1 are written."""
+    the output buffer holds `out_copies` per level and images 0 .. copies - 1 are written.  `channels`: the larger of the input's and
+    the (padded) output's channel count -- it bounds how many images one record may hold (32-bit byte offsets inside a canvas)."""
     in_copies = copies if in_copies is None else in_copies
     out_copies = copies if out_copies is None else out_copies
     assert in_first + copies <= in_copies and copies <= out_copies
-    key = (tuple(levels), copies, in_copies, in_first, out_copies, str(device))
+    channels = max(int(channels), 8)
+    key = (tuple(levels), copies, in_copies, in_first, out_copies, str(device), channels)
     t = _TABLES.get(key)
     if t is None:
         ioffs, ooffs = level_pixel_offsets(levels, in_copies), level_pixel_offsets(levels, out_copies)
         rows = []
         for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
             assert 0 < h < 4096 and 0 < w < 4096
-            group = max(1, min(127, (2 ** 31 - 1) // (h * w * 512 * 4)))   # 32-bit byte offsets inside a canvas (C <= 512); the image count sits in 7 bits
+            if h * w * channels * 4 > MAX_CANVAS_BYTES:
+                raise ValueError("pod_wino_conv3x3: one %d x %d image of %d channels exceeds the kernel's 32-bit canvas offsets" % (h, w, channels))
+            group = max(1, min(127, MAX_CANVAS_BYTES // (h * w * channels * 4)))   # 32-bit byte offsets inside a canvas; the image count sits in 7 bits
             done = 0
             while done < copies:
                 n = min(group, copies - done)
@@ -83,6 +91,7 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()
         t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table
         t.pod_levels = len(levels)
+        t.pod_channels = channels
         _TABLES[key] = t
     return t
 
@@ -124,6 +133,7 @@ class WinoConv:
         NCHW images with K (real) planes each, level-major like the table's output side."""
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and src.dtype == dst.dtype == torch.float32
         assert planes or dst.shape[-1] == self.Kpad
+        assert getattr(table, "pod_channels", 512) >= max(self.C, self.K if planes else self.Kpad), "block_table(channels=...) below this conv's channel count"
         fn = hip.load().pod_wino_conv3x3_split if self.split else hip.load().pod_wino_conv3x3
         hip.check(fn(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
                      table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
