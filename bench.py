@@ -88,6 +88,8 @@ def parse_args():
     ap.add_argument("--split-bf16", action="store_true",
                     help="head / backbone 3x3 convolutions on pod_wino_conv3x3_split (fp32 products from 3-way bf16 splits on the bf16 "
                          "matrix cores) instead of the fp32-MFMA kernel; without the flag that kernel is measured as a second leg (`split_bf16`)")
+    ap.add_argument("--no-graphs", action="store_true", help="issue every launch of the model forward from Python instead of replaying a HIP graph "
+                                                             "per (stream, shape) (graphs are used for forwards without active dropout only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the K1 / conv / NLL / worst-case legs after the timed region")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
@@ -331,6 +333,8 @@ def main():
                                              bbox_cov_loss="negative_log_likelihood").to(dev).eval()
         modeling.fold_frozen_bn(mm)
         members.append(mm)
+    for mm in members:
+        mm.enable_graphs(not args.no_graphs)
     net_hw = A.resize_shortest_edge(*FRAME_HW)                 # 750 x 1333
     padded = A.padded_size(*net_hw)                            # 768 x 1344
     n_img = max(1, args.images)
@@ -451,7 +455,8 @@ def main():
                    "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
                    "conv3x3_kernel": "pod_wino_conv3x3_split (bf16 matrix cores, 3-way splits)" if args.split_bf16 else "pod_wino_conv3x3 (fp32 matrix cores)",
-                   "rng": "in-kernel Philox4x32-10, fresh key per image"},
+                   "rng": "in-kernel Philox4x32-10, fresh key per image",
+                   "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not mc and not args.no_cnn) else "eager launches from Python"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "mean_detections": n_det_mean,
     }

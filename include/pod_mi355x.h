@@ -368,6 +368,9 @@ int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t 
  *                         global_anchor_ids[i] (= anchor_base_l + index inside the level). */
 int pod_dump_cls_normals(const PodConfig* cfg, const PodLevel* levels, int32_t level, float* eps_cls, pod_stream_t stream);
 int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids, int32_t n, float* eps_prop, pod_stream_t stream);
+/* test support for pod_wino_conv3x3_split's arithmetic contract: the three bf16 terms (bit patterns, terms dev uint16 [3][n]) the kernel
+ * forms of each fp32 operand x[i] (dev, n even): x == t0 + t1 + t2 exactly (tests/test_wino_conv_gpu.py). */
+int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t stream);
 
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net

@@ -18,6 +18,11 @@ HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(CSRC, "pod_candidate
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+# per-source extras.  k12: its transform arithmetic is slotted behind bf16 MFMAs, where a packed fp32 instruction (what the SLP vectoriser
+# makes of neighbouring scalar operations) costs ~40 cycles and a scalar one nothing (tools/mfma_bf16_split.hip)
+SOURCE_FLAGS = {"k12_wino_conv_split.hip": ["-fno-slp-vectorize"]}
+
+
 def _flags(tagged: bool):
     """Experiment / diagnostics defines apply to TAGGED builds only: the shipped library is always the plain source.
     POD_EXTRA_DEFINES="-DPOD_WINO_ELIM=3 ..."; POD_TRACE=1: phase time stamps inside kernels (csrc/pod_device.h, k11)."""
@@ -67,7 +72,7 @@ def build_library(force: bool = False, verbose: bool = False, tag: str = "") -> 
             objs.append(o)
             continue
         if force or _stale(o, [s] + HEADERS):
-            cmd = [_hipcc()] + _flags(bool(tag)) + ["-c", s, "-o", o]
+            cmd = [_hipcc()] + _flags(bool(tag)) + SOURCE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

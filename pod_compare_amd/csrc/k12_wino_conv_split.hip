@@ -13,7 +13,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t vu32x4 __attribute__((ext_vector_type(4)));
 constexpr int WINO_US_BYTES = 24 * 2 * 3 * 64 * 16;      // pre-split filter terms of a 16-channel chunk: [24 positions][kb][term][h][j][8 bf16]  144 KB
-constexpr int WINO_WAIT_VM18 = 0x4072;                    // lgkmcnt(0) vmcnt(18)
+constexpr int WINO_WAIT_VM24 = 0x4078;                    // lgkmcnt(0) vmcnt(24)
 
 // Filter transform U = G4 g G6t as in k_wino_filter, every value split into three bf16 terms (round to nearest: u = u0 + u1 + u2),
 // written in the order the kernel's lanes load them:
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     };
 
     // Between the 32-cycle bf16 MFMAs an LDS-DMA piece costs its ~100 issue cycles in full (behind the 64-cycle fp32 MFMAs most of it
-    // hides), so the K loop fills the stages through registers: every chunk loads 6 pieces (one buffer_load_dwordx4 per position) and
-    // parks the 6 it loaded a chunk earlier (ds_write_b128: free).  Stage s + 1 is written during the two chunks of super-chunk s.
+    // hides), so the K loop fills the stages through registers: every chunk loads 6 pieces (one buffer_load_dwordx4 each) and parks the
+    // 6 it loaded a chunk earlier (ds_write_b128: free).
     f32x4 stg[6];
 #define WINO_STG_SLOT(p, m) ((p) == 4 && (m) == 11 ? 0 : (p) == 5 && (m) == 6 ? 1 : (p) == 5 && (m) >= 8 ? (m) - 6 : -1)
     const uint32_t stg_addr = lds_base + a * 12288 + lane * 16;          // + stage * 48 KB + piece * 1 KB
@@ -221,11 +221,16 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first product multiplies into a zero C
     f32x4 x[12];                                                         // raw patch, one 4-channel half at a time: x[row][c]
     vu32x4 Vb[6][3];                                                      // the transformed patch as bf16 operands: [position][split], 8 channels (regs 0-1: channels 0-3, 2-3: 4-7)
+    float tN[6][4], vN[2][6][4];                                         // the NEXT chunk's transform in flight: row-combined columns; transformed values [half][position] (fp32, split later)
 #if POD_WINO_ELIM
 #pragma unroll
     for (int i = 0; i < 18; ++i) Vb[i / 3][i % 3] = vu32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + lane};
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
+#pragma unroll
+    for (int i = 0; i < 48; ++i) vN[i / 24][(i / 4) % 6][i % 4] = x[i / 4][i % 4];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) tN[i / 4][i % 4] = x[i / 4][i % 4];
 #endif
     // (reads as asm with hand-counted completion: see k11_wino_conv.hip)
 #define WINO_READ(par, c16, hf, i)                                                                                                  \
@@ -235,72 +240,154 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
 #define WINO_READ12(M, ...)                                                                                                          \
     M(__VA_ARGS__, 0); M(__VA_ARGS__, 1); M(__VA_ARGS__, 2); M(__VA_ARGS__, 3); M(__VA_ARGS__, 4); M(__VA_ARGS__, 5);                \
     M(__VA_ARGS__, 6); M(__VA_ARGS__, 7); M(__VA_ARGS__, 8); M(__VA_ARGS__, 9); M(__VA_ARGS__, 10); M(__VA_ARGS__, 11)
+    // the reads have landed: the wait is tied to the twelve values, so that nothing computed from them can be scheduled above it
+#define WINO_READS_LANDED()                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), \
+                 "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]))
     // Row a of V = Bt4 d Bt6^T for the lane's tile and 4 channels -- the SAME operations in the same order as the fp32 kernel's
-    // packed transform (fused multiply-adds where it has them), but as scalar instructions: beside bf16 MFMAs a packed fp32
-    // instruction costs ~40 cycles (tools/mfma_bf16_split.hip), an ordinary one nothing --, then every value split into three bf16
-    // terms by round-to-nearest (v = v0 + v1 + v2 to 2^-26 |v|; truncation would make the dropped partial products one-signed: a bias
-    // the Winograd cancellation amplifies -- measured) and packed pairwise into half hf of Vb.
-    auto make_v = [&](int hf) __attribute__((always_inline)) {
+    // packed transform (fused multiply-adds where it has them), but as scalar instructions (this file is compiled with
+    // -fno-slp-vectorize): beside bf16 MFMAs a packed fp32 instruction costs ~40 cycles (tools/mfma_bf16_split.hip), an ordinary one
+    // nothing --, then every value split into three bf16 terms by round-to-nearest (v = v0 + v1 + v2 to 2^-26 |v|; truncation would
+    // make the dropped partial products one-signed: a bias the Winograd cancellation amplifies -- measured) and packed pairwise.
+    //
+    // The pieces of that work, so that they can be slotted behind MFMAs one small unit at a time (`unit` below) or run back to back
+    // (`make_v`: the first two chunks).  A unit PINS its inputs when it starts and its results when it ends (empty volatile asm): pure
+    // arithmetic otherwise floats to wherever instruction selection likes it, i.e. away from the MFMA it was meant to hide behind.
+    auto rows_combine = [&](int c0, int c1) __attribute__((always_inline)) {              // tN[c] = x0[c] + s x1[c]
+#pragma unroll
+        for (int c = c0; c < c1; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tN[c][e] = __builtin_fmaf(sgn, x[6 + c][e], x[c][e]);
+            wino_pin(tN[c][0], tN[c][1], tN[c][2], tN[c][3]);
+        }
+    };
+    float w0s[4], w1s[4], evs[4], ods[4], fs[4], gs[4];                                   // column transform, first level (per channel e)
+    auto columns_level1 = [&](int e) __attribute__((always_inline)) {
+        wino_pin(tN[1][e], tN[2][e], tN[3][e], tN[4][e], tN[5][e]);
+        w0s[e] = __builtin_fmaf(-5.0f, tN[2][e], tN[4][e]);
+        w1s[e] = __builtin_fmaf(-5.0f, tN[3][e], tN[5][e]);
+        evs[e] = __builtin_fmaf(-4.0f, tN[2][e], tN[4][e]);
+        ods[e] = __builtin_fmaf(-4.0f, tN[1][e], tN[3][e]);
+        fs[e] = tN[4][e] - tN[2][e];
+        gs[e] = tN[3][e] - tN[1][e];
+        wino_pin(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e]);
+    };
+    auto columns_level2 = [&](int hf, int e) __attribute__((always_inline)) {
+        wino_pin(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e], tN[0][e], tN[1][e]);
+        vN[hf][0][e] = __builtin_fmaf(4.0f, tN[0][e], w0s[e]);
+        vN[hf][5][e] = __builtin_fmaf(4.0f, tN[1][e], w1s[e]);
+        vN[hf][1][e] = evs[e] + ods[e];
+        vN[hf][2][e] = evs[e] - ods[e];
+        vN[hf][3][e] = __builtin_fmaf(2.0f, gs[e], fs[e]);
+        vN[hf][4][e] = __builtin_fmaf(-2.0f, gs[e], fs[e]);
+        wino_pin(vN[hf][0][e], vN[hf][1][e], vN[hf][2][e], vN[hf][3][e], vN[hf][4][e], vN[hf][5][e]);
+    };
+    // The three bf16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in five steps whose
+    // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert -> residual -> convert):
+    // w = nearest-even bf16 pair (v_cvt_pk_bf16_f32), residual r = v - w exactly (in place: vN is dead afterwards).
+    auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
+        vu32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                                      // i = 2 hf + pair: regs 0-1 channels 0-3, 2-3 channels 4-7
+            wino_pin(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
+            w[i] = wino_bf16_pair(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
+        }
+        Vb[p][term] = w;
+        wino_pin(Vb[p][term]);
+    };
+    auto split_residual = [&](int p, int term, int i0, int i1) __attribute__((always_inline)) {      // v -= the term just made, exactly
+        wino_pin(Vb[p][term]);
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            float& lo = vN[i >> 1][p][2 * (i & 1)];
+            float& hi = vN[i >> 1][p][2 * (i & 1) + 1];
+            wino_pin(lo, hi);
+            wino_bf16_residual(Vb[p][term][i], lo, hi);
+            wino_pin(lo, hi);
+        }
+    };
+    auto split_position = [&](int p) __attribute__((always_inline)) {                      // all five steps back to back
+        split_convert(p, 0); split_residual(p, 0, 0, 4); split_convert(p, 1); split_residual(p, 1, 0, 4); split_convert(p, 2);
+    };
+    auto make_v = [&](int hf) __attribute__((always_inline)) {                             // serial form: x (12 reads of half hf) -> vN[hf]
         if (POD_WINO_ELIM & 8) return;
-        f32x4 t[6], v[6];
+        rows_combine(0, 6);
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+        for (int e = 0; e < 4; ++e) columns_level1(e);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sgn, x[6 + c][e], x[c][e]);
+        for (int e = 0; e < 4; ++e) columns_level2(hf, e);
+    };
+    auto split_all = [&]() __attribute__((always_inline)) {
+        if (POD_WINO_ELIM & 8) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float w0 = __builtin_fmaf(-5.0f, t[2][e], t[4][e]), w1 = __builtin_fmaf(-5.0f, t[3][e], t[5][e]);
-            v[0][e] = __builtin_fmaf(4.0f, t[0][e], w0);
-            v[5][e] = __builtin_fmaf(4.0f, t[1][e], w1);
-            const float ev = __builtin_fmaf(-4.0f, t[2][e], t[4][e]), od = __builtin_fmaf(-4.0f, t[1][e], t[3][e]);
-            v[1][e] = ev + od;
-            v[2][e] = ev - od;
-            const float f = t[4][e] - t[2][e], g = t[3][e] - t[1][e];
-            v[3][e] = __builtin_fmaf(2.0f, g, f);
-            v[4][e] = __builtin_fmaf(-2.0f, g, f);
-        }
-        // the three terms of the 12 channel pairs, STAGE by stage (12 independent instructions per stage: a pair's own chain is
-        // cvt -> shift / mask -> subtract -> cvt -> ..., nine dependent steps; depth-first they wait for each other's latency)
-        f32x2 vv[12], r1[12], r2[12];
-        uint32_t w0[12], w1[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) vv[i] = f32x2{v[i >> 1][2 * (i & 1)], v[i >> 1][2 * (i & 1) + 1]};           // pair i = (position i / 2, channels 2 (i & 1) ..)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) w0[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv[i], bf16x2));   // v_cvt_pk_bf16_f32: nearest even, packed
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) r1[i] = f32x2{__builtin_bit_cast(float, w0[i] << 16), __builtin_bit_cast(float, w0[i] & 0xFFFF0000u)};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) r1[i] = vv[i] - r1[i];                                                        // exact
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) w1[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1[i], bf16x2));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) r2[i] = f32x2{__builtin_bit_cast(float, w1[i] << 16), __builtin_bit_cast(float, w1[i] & 0xFFFF0000u)};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) r2[i] = r1[i] - r2[i];                                                        // exact
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            Vb[i >> 1][0][2 * hf + (i & 1)] = w0[i];
-            Vb[i >> 1][1][2 * hf + (i & 1)] = w1[i];
-            Vb[i >> 1][2][2 * hf + (i & 1)] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2[i], bf16x2));
-        }
+        for (int p = 0; p < 6; ++p) split_position(p);
     };
 
     // One chunk = 16 input channels = one k-step of v_mfma_f32_32x32x16_bf16.  Every fp32 product x * u is formed from the three bf16
     // terms of each operand: the 6 partial products that matter (x1u1, x0u2, x2u0, x0u1, x1u0, x0u0: small ones first), fp32 accumulate --
     // against fp64 as accurate as the fp32 MFMA (profiles/r03_experiments.md), at 6/16 of its matrix-pipe cycles.  72 MFMAs per
-    // chunk: positions p = 0..5 of the wave's row, two channel blocks, 6 products; the filter terms of position p + 1 (6 x 16 B per lane,
-    // pre-split, from L2) are loaded behind the first six MFMAs of position p.  The patch of the NEXT chunk is read from LDS behind the
-    // last three positions (first half) and transformed + split between the chunks (the second half behind the first's arithmetic).
-    // Super-chunk s + 1 (32 channels) is fetched by LDS-DMA into the stage s - 1 left behind during the SECOND chunk of s - 1, after a
-    // mid-chunk barrier (every wave has read that stage), and published by the barrier that ends the first chunk of s.
+    // chunk: positions p = 0..5 of the wave's row, two channel blocks, 6 products; the filter terms of position p + 2 (6 x 16 B per lane,
+    // pre-split, from L2) are loaded behind the first six MFMAs of position p.
+    //
+    // SOFTWARE PIPELINE (round 4).  The 312 VALU instructions that turn the next chunk's raw patch into bf16 operands used to run
+    // between the chunks -- 1 300 of a chunk's 5 080 cycles with the matrix pipe idle (elimination build: K loop 81.3 k -> 60.4 k cycles
+    // without them).  They now sit BEHIND the MFMAs of the running chunk, one unit of <= 4 independent instructions per slot:
+    //     A   the three terms of the running chunk's own position 5 (its values were computed during the previous chunk; Vb[5] is read
+    //         last, and could not be overwritten while the previous chunk's position 5 was still to come)
+    //     R0 T0   12 LDS reads of the next chunk's first 4-channel half, the row combination       (x -> tN)
+    //     R1 V0   the second half's reads; the first half's column transform                       (tN -> vN[0])
+    //     T1 V1   the same for the second half                                                      (-> vN[1])
+    //     C0..C4  the three terms of the next chunk's positions 0..4 -- each after the running chunk's MFMAs of that position have issued
+    // which needs the next chunk's patch to stand in a PUBLISHED stage when the chunk begins: super-chunk s + 1 is therefore complete one
+    // chunk earlier than before -- chunk (s - 1, 1) parks its pieces 0..5, chunk (s, 0) pieces 6..11 -- in the stage whose last read (for
+    // chunk (s - 1, 1), issued during (s - 1, 0)) lies a barrier behind.
+    constexpr int N_UNITS = 84;
+    auto unit = [&](auto U, auto npar_t, auto n16_t, auto hasA_t) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value, npar = decltype(npar_t)::value, n16 = decltype(n16_t)::value;
+        if constexpr (POD_WINO_ELIM & 8) { if constexpr (u >= 3 && !(u >= 16 && u < 19)) return; }
+        if constexpr (u < 3) {                                                             // R0
+            if constexpr (!(POD_WINO_ELIM & 1)) { WINO_READ(npar, n16, 0, 4 * u); WINO_READ(npar, n16, 0, 4 * u + 1); WINO_READ(npar, n16, 0, 4 * u + 2); WINO_READ(npar, n16, 0, 4 * u + 3); }
+        } else if constexpr (u < 10) {                                                     // A (7 units)
+            if constexpr (decltype(hasA_t)::value) {
+                constexpr int k = u - 3;
+                if constexpr (k == 0) split_convert(5, 0);
+                else if constexpr (k == 1) split_residual(5, 0, 0, 2);
+                else if constexpr (k == 2) split_residual(5, 0, 2, 4);
+                else if constexpr (k == 3) split_convert(5, 1);
+                else if constexpr (k == 4) split_residual(5, 1, 0, 2);
+                else if constexpr (k == 5) split_residual(5, 1, 2, 4);
+                else split_convert(5, 2);
+            }
+        } else if constexpr (u < 16) {                                                     // T0 (6 units: one column each)
+            if constexpr (u == 10) WINO_READS_LANDED();
+            rows_combine(u - 10, u - 9);
+        } else if constexpr (u < 19) {                                                     // R1
+            if constexpr (!(POD_WINO_ELIM & 1)) { WINO_READ(npar, n16, 1, 4 * (u - 16)); WINO_READ(npar, n16, 1, 4 * (u - 16) + 1); WINO_READ(npar, n16, 1, 4 * (u - 16) + 2); WINO_READ(npar, n16, 1, 4 * (u - 16) + 3); }
+        } else if constexpr (u < 31) {                                                     // V0 (12 units: level 1 and level 2 of each channel, 6 ops each)
+            constexpr int k = u - 19;
+            if constexpr (k < 4) columns_level1(k);
+            else if constexpr (k < 8) columns_level2(0, k - 4);
+        } else if constexpr (u < 37) {                                                     // T1
+            if constexpr (u == 31) WINO_READS_LANDED();
+            rows_combine(u - 31, u - 30);
+        } else if constexpr (u < 49) {                                                     // V1
+            constexpr int k = u - 37;
+            if constexpr (k < 4) columns_level1(k);
+            else if constexpr (k < 8) columns_level2(1, k - 4);
+        } else {                                                                           // C0..C4
+            constexpr int p = (u - 49) / 7, k = (u - 49) % 7;
+            if constexpr (k == 0) split_convert(p, 0);
+            else if constexpr (k == 1) split_residual(p, 0, 0, 2);
+            else if constexpr (k == 2) split_residual(p, 0, 2, 4);
+            else if constexpr (k == 3) split_convert(p, 1);
+            else if constexpr (k == 4) split_residual(p, 1, 0, 2);
+            else if constexpr (k == 5) split_residual(p, 1, 2, 4);
+            else split_convert(p, 2);
+        }
+    };
+    // units of slot j: [j * 84 / 72, (j + 1) * 84 / 72) -- C(p) starts at unit 49 + 7 p = slot 42 + 6 p >= 12 (p + 1): behind position p's MFMAs
     const int last = nchunk - 1, last_s = last >> 1;
+    const int sc1 = last_s < 1 ? last_s : 1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) mini_piece(0, r);
 #pragma unroll
@@ -311,74 +398,89 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
 #pragma unroll
     for (int i = 0; i < 12; ++i) patch_piece(lds, 0, i);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) stage_load(i, last_s < 1 ? last_s : 1, i);      // (chunk 0 parks them in stage 1)
+    for (int i = 0; i < 6; ++i) patch_piece(lds + WINO_SB_FLOATS, sc1, i);       // pieces 0..5 of super-chunk 1 straight into stage 1 ...
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stage_load(i, sc1, 6 + i);                       // ... its pieces 6..11 through registers (chunk 0 parks them)
     WINO_STAMP(11);
-    __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM18);        // the mini stages and the first filter terms have landed; stage 0's 12 pieces and 6 of stage 1's fly on
+    __builtin_amdgcn_s_waitcnt(WINO_WAIT_VM24);        // the mini stages and the first filter terms have landed; the 18 DMA pieces and the 6 register pieces fly on
     __builtin_amdgcn_s_barrier();
     WINO_STAMP(1);
     WINO_READ12(WINO_READ_MINI, 0);
-    __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+    WINO_READS_LANDED();
     __builtin_amdgcn_sched_barrier(0);
     make_v(0);
     __builtin_amdgcn_sched_barrier(0);
     WINO_READ12(WINO_READ_MINI, 1);
-    __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
+    WINO_READS_LANDED();
     __builtin_amdgcn_sched_barrier(0);
     make_v(1);
+    split_all();
     __builtin_amdgcn_sched_barrier(0);
     WINO_STAMP(2);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // chunk q = (super-chunk q >> 1, half c16 = q & 1), stage parity par = (q >> 1) & 1
-    auto chunk = [&](auto first, auto c16_t, auto par_t, int q) {
-        constexpr int c16 = decltype(c16_t)::value, par = decltype(par_t)::value;
-        constexpr bool fill = decltype(first)::value || c16 == 1;                  // the next chunk reads a stage this chunk's barrier publishes: no read-ahead
+    // chunk q = (super-chunk q >> 1, half c16 = q & 1), stage parity par = (q >> 1) & 1.
+    //   mode 0: the first chunk (accumulators start from zero; nothing of the next chunk behind its MFMAs: stage 0 is still landing)
+    //   mode 1: chunk 1 (operands made back to back after chunk 0; runs units R0 .. C4 for chunk 2)
+    //   mode 2: steady state (units A .. C4)
+    auto chunk = [&](auto mode_t, auto c16_t, auto par_t, int q) {
+        constexpr int mode = decltype(mode_t)::value, c16 = decltype(c16_t)::value, par = decltype(par_t)::value;
         constexpr int n16 = c16 ^ 1, npar = c16 == 1 ? par ^ 1 : par;             // the NEXT chunk's half and stage
         const int qn = q + 1 <= last ? q + 1 : last;
-        // this chunk parks pieces 6 c16 .. 6 c16 + 5 of super-chunk s + 1 (loaded a chunk ago) in the other stage and loads the next six:
-        // 6 .. 11 of s + 1 (c16 = 0) or 0 .. 5 of s + 2 (c16 = 1)
-        const int ls0 = (q >> 1) + 1 + c16, ls = ls0 < last_s ? ls0 : last_s;
+        // stage traffic: chunk (s, 0) parks pieces 6..11 of super-chunk s + 1 (other stage) and loads 0..5 of s + 2; chunk (s, 1) parks those in
+        // its OWN stage (nobody reads it any more: the next chunk's operands come from the other one) and loads 6..11 of s + 2
+        const int ls0 = (q >> 1) + 2, ls = ls0 < last_s ? ls0 : last_s;
         wino_static_for([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value, p = j / 12, m = j % 12, kb = m & 1, prod = m >> 1;
             constexpr int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;      // filter term of the product
             constexpr int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;   // patch term
-            if constexpr (decltype(first)::value && prod == 0)
+            if constexpr (mode == 0 && prod == 0)
                 acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), zero16, 0, 0, 0);
             else
                 acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
             if constexpr (m < 6) { if (!(POD_WINO_ELIM & 2)) filter_piece(p >= 4 ? qn : q, (p + 2) % 6, uP[(p + 2) % 3], m); }
-            else if constexpr (m == 7) { if (!(POD_WINO_ELIM & 4)) stage_write(par ^ 1, p, 6 * c16 + p); }
+            else if constexpr (m == 7) { if (!(POD_WINO_ELIM & 4)) stage_write(c16 == 0 ? par ^ 1 : par, p, c16 == 0 ? 6 + p : p); }
             else if constexpr (WINO_STG_SLOT(p, m) >= 0) {       // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
-                if (!(POD_WINO_ELIM & 4)) stage_load(WINO_STG_SLOT(p, m), ls, 6 * (c16 ^ 1) + WINO_STG_SLOT(p, m));      // order, and every filter term ahead is needed soon
-            } else if constexpr (!decltype(first)::value && !fill && p >= 1 && p <= 4 && m >= 8 && m <= 10) {   // the next chunk's first half (its stage is published)
-                if (!(POD_WINO_ELIM & 1)) WINO_READ(npar, n16, 0, (p - 1) * 3 + m - 8);
+                if (!(POD_WINO_ELIM & 4)) stage_load(WINO_STG_SLOT(p, m), ls, 6 * c16 + WINO_STG_SLOT(p, m));           // order, and every filter term ahead is needed soon
+            }
+            if constexpr (mode != 0) {
+                constexpr int u0 = j * N_UNITS / 72, u1 = (j + 1) * N_UNITS / 72;
+                wino_static_for([&](auto K) __attribute__((always_inline)) {
+                    unit(std::integral_constant<int, u0 + decltype(K)::value>{}, std::integral_constant<int, npar>{}, std::integral_constant<int, n16>{},
+                         std::integral_constant<bool, mode == 2>{});
+                }, std::make_integer_sequence<int, u1 - u0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, 72>{});
-        // No vmcnt wait: the stage the next reads touch was filled two chunks ago, and loads return in order -- the filter terms this
-        // chunk's MFMAs consumed were issued AFTER those pieces, so the pieces have landed; the barrier publishes them.  The filter terms
-        // of the next chunk's first positions may fly on through the arithmetic below (hipcc waits for them where they are used).
+        // No vmcnt wait: the pieces this chunk parked were loaded a chunk ago (hipcc waits for them where they are stored), the DMA pieces of
+        // the prologue were issued before filter terms this chunk's MFMAs have consumed, and loads return in order.  The barrier publishes the
+        // stage and retires this chunk's LDS reads.
         __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
         __builtin_amdgcn_s_barrier();
-        if (q >= last) return;
-        if constexpr ((decltype(first)::value || fill) && !(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 0);     // (not read ahead: the stage was published only now)
-        __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
-        __builtin_amdgcn_sched_barrier(0);
-        make_v(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 1);
-        __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
-        __builtin_amdgcn_sched_barrier(0);
-        make_v(1);
-        __builtin_amdgcn_sched_barrier(0);
-        // (no second barrier: the stage these reads touched is next written two chunks on, behind two chunk-end barriers)
+        if constexpr (mode == 0) {
+            if (q >= last) return;
+            // chunk 1's operands, back to back (stage 0 has landed and was published just now)
+            if constexpr (!(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 0);
+            WINO_READS_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
+            make_v(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(POD_WINO_ELIM & 1)) WINO_READ12(WINO_READ, npar, n16, 1);
+            WINO_READS_LANDED();
+            __builtin_amdgcn_sched_barrier(0);
+            make_v(1);
+            split_all();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();               // chunk 1 parks pieces in stage 0: every wave must have read its operands out of it
+        }
     };
     using std::integral_constant;
-    chunk(std::true_type{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, 0);
+    chunk(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}, 0);
+    if (nchunk > 1) chunk(integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, 1);
     for (int base = 0;; base += 4) {
 #define WINO_CHUNK(t)                                                                                                              \
     if (base + (t) >= nchunk) break;                                                                                               \
-    chunk(std::false_type{}, integral_constant<int, (t) & 1>{}, integral_constant<int, ((t) >> 1) & 1>{}, base + (t));
-        WINO_CHUNK(1) WINO_CHUNK(2) WINO_CHUNK(3) WINO_CHUNK(4)
+    chunk(integral_constant<int, 2>{}, integral_constant<int, (t) & 1>{}, integral_constant<int, ((t) >> 1) & 1>{}, base + (t));
+        WINO_CHUNK(2) WINO_CHUNK(3) WINO_CHUNK(4) WINO_CHUNK(5)
 #undef WINO_CHUNK
     }
     __syncthreads();                                   // every wave is done reading the stages, no DMA in flight: they become the output staging

@@ -91,6 +91,47 @@ inline int64_t wino_grid(int KS, int64_t n_blocks) {
     return 8 * SP * ((n_blocks * G + 7) / 8);
 }
 
+// Ties values into the instruction order at this point (no instruction is emitted): what was computed before cannot sink below, what
+// is computed from them cannot rise above.
+template <typename T>
+__device__ __forceinline__ void wino_pin_one(T& v) {
+    asm volatile("" : "+v"(v));
+}
+template <typename... T>
+__device__ __forceinline__ void wino_pin(T&... v) {
+    (wino_pin_one(v), ...);
+}
+
+// ---- an fp32 value as the exact sum of three bf16 values (k12_wino_conv_split.hip; pod_debug_bf16_split3 exposes the same code to the tests)
+// x = x0 + x1 + x2:  x0 = bf16(x) (round to nearest even), r1 = x - x0 (exact: |r1| <= 2^-9 |x|, 16 significant bits), x1 = bf16(r1),
+// r2 = r1 - x1 (exact, 8 significant bits), x2 = bf16(r2) = r2.  Exact for every finite x whose residuals stay normal (|x| >= 2^-110);
+// below that the last terms are fp32 denormals, which v_cvt_pk_bf16_f32 / the subtraction keep or flush as the kernel's denormal mode
+// says -- either way the sum is within 2^-126 of x.  +-inf / nan give (x, nan, nan): the products are nan, as an fp32 product would be.
+typedef __bf16 wino_bf16x2 __attribute__((ext_vector_type(2)));
+#ifndef POD_SPLIT_DOT2C
+#define POD_SPLIT_DOT2C 1
+#endif
+__device__ __forceinline__ uint32_t wino_bf16_pair(float lo, float hi) {              // v_cvt_pk_bf16_f32: nearest even, lo in bits 15:0
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, wino_bf16x2));
+}
+__device__ __forceinline__ void wino_bf16_residual(uint32_t w, float& lo, float& hi) {   // (lo, hi) -= the bf16 pair w, exactly
+#if POD_SPLIT_DOT2C
+    // v_dot2c_f32_bf16: D += A.lo B.lo + A.hi B.hi with B = (-1, 0) / (0, -1): ONE instruction per value instead of shift / mask + subtract
+    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, 0x0000BF80u), lo, false);
+    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, 0xBF800000u), hi, false);
+#else
+    lo -= __builtin_bit_cast(float, w << 16);
+    hi -= __builtin_bit_cast(float, w & 0xFFFF0000u);
+#endif
+}
+__device__ __forceinline__ void wino_bf16_split3(float lo, float hi, uint32_t (&w)[3]) {
+    w[0] = wino_bf16_pair(lo, hi);
+    wino_bf16_residual(w[0], lo, hi);
+    w[1] = wino_bf16_pair(lo, hi);
+    wino_bf16_residual(w[1], lo, hi);
+    w[2] = wino_bf16_pair(lo, hi);
+}
+
 template <typename F, int... Js>
 __device__ __forceinline__ void wino_static_for(F&& f, std::integer_sequence<int, Js...>) {
     (f(std::integral_constant<int, Js>{}), ...);

@@ -524,6 +524,8 @@ class ProbabilisticRetinaNet(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(PIXEL_MEAN_BGR).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(3, 1, 1), persistent=False)
         self._anchor_cache: Dict[Tuple[int, int], List[torch.Tensor]] = {}
+        self.use_graphs = False
+        self._graphs: Dict[tuple, tuple] = {}
 
     @property
     def device(self):
@@ -544,6 +546,41 @@ class ProbabilisticRetinaNet(nn.Module):
                 torch.cuda.current_stream(self.device).synchronize()   # made once, then read from any stream
         return self._anchor_cache[padded_hw]
 
+    # ---- HIP graphs --------------------------------------------------------------------------------------------------------
+    # One image's forward is ~200 launches (MIOpen calls, pod_* kernels, torch element-wise ops) issued from Python: 2.3 - 2.5 ms of
+    # host time, which is the whole step of the single-run configurations (BASELINE configs[1], [3]: 2.75 ms of GPU time).  With
+    # `enable_graphs()` the forward of a given (stream, frame shape, flags) is captured once into a HIP graph and replayed: one
+    # host call per image.  Not captured: forwards with active dropout (the Philox counter offsets of the masks are launch
+    # arguments: a replay would repeat the first image's masks; those configurations are 4x further from the host limit) and
+    # anything off the GPU.  The returned tensors belong to the graph: they are valid until the next forward of the same
+    # (stream, shape, flags) -- on the same stream, so a consumer enqueued there before that is safe.
+    def enable_graphs(self, on: bool = True) -> "ProbabilisticRetinaNet":
+        self.use_graphs = bool(on)
+        if not on:
+            self._graphs.clear()
+        return self
+
+    def _forward_graphed(self, image: torch.Tensor, n: int, skip: bool) -> HeadOutputs:
+        stream = torch.cuda.current_stream(image.device)
+        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, skip)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = image.clone()
+            for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
+                self._forward_eager(static_in, n, False, skip)
+            stream.synchronize()
+            side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
+            side.wait_stream(stream)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out = self._forward_eager(static_in, n, False, skip)
+            stream.wait_stream(side)
+            ent = self._graphs[key] = (graph, static_in, out)
+        graph, static_in, out = ent
+        static_in.copy_(image, non_blocking=True)
+        graph.replay()
+        return out
+
     @torch.no_grad()
     def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False,
                 mc_dropout: Optional[bool] = None) -> HeadOutputs:
@@ -551,11 +588,17 @@ class ProbabilisticRetinaNet(nn.Module):
         num_mc_dropout_runs > 1 batches that many dropout-perturbed head evaluations (PR:103-108).
         mc_dropout: dropout active in the head subnets -- the reference's `model.train()` (PI:53-56), which it sets
         whenever MC_DROPOUT.ENABLE is true, also for a single run; default: active iff several runs are requested."""
-        x = self.preprocess_image(image)
-        feats = self.fpn(self.bottom_up(x))
         n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
         if mc_dropout is None:
             mc_dropout = n > 1
+        dropout = bool(mc_dropout) and self.use_dropout
+        if self.use_graphs and not dropout and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None:
+            return self._forward_graphed(image, n, skip_unused_last_run)
+        return self._forward_eager(image, n, dropout, skip_unused_last_run)
+
+    def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
+        x = self.preprocess_image(image)
+        feats = self.fpn(self.bottom_up(x))
         cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
                                                  skip_unused_last_run=skip_unused_last_run)
         padded = tuple(x.shape[-2:])

@@ -72,22 +72,15 @@ BENCH_LEVELS = [(96, 168), (48, 84), (24, 42), (12, 21), (6, 11)]      # the fiv
 C_BOUND = 32.0
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
-@pytest.mark.parametrize("K,planes", [(256, False), (63, True), (36, True)], ids=["trunk-256", "cls_score-63", "bbox_pred-36"])
-def test_error_against_an_fp64_direct_convolution(K, planes, split):
-    """The referee that is not MIOpen: F.conv2d in fp64 on the CPU, on the benchmark launch's shapes (C = 256, five levels) with
-    post-ReLU activations.  Per ELEMENT  |err| <= c 2^-24 (|w| * |x| + |b|)  -- the unit every forward error bound of an fp32
-    evaluation is written in (a length-n fp32 dot product guarantees c <= n = 2304).  Measured c (tools/wino_fp64_check.py, MI355X):
-    pod_wino_conv3x3 11.6 / 10.8 / 13.6 (trunk / cls_score / bbox_pred), MIOpen's fp32 conv2d 2.5 - 2.8, mkldnn's fp32 conv2d on the
-    CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class.
-    pod_wino_conv3x3_split (every product from 3-way bf16 splits, 6 partial products, fp32 accumulate): 10.6 / 9.6 / 8.5 -- the same
-    bound is asserted for both kernels."""
+def _c_against_fp64(K, planes, split):
+    """max over output elements of |err| / (2^-24 (|w| * |x| + |b|)) on the benchmark launch's shapes, referee = fp64 direct convolution"""
     C, copies, u = 256, 1, 2.0 ** -24
     g = torch.Generator().manual_seed(K)
     w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
     b = torch.randn(K, generator=g)
     xs = [torch.randn(copies, C, h, wd, generator=g).relu() for h, wd in BENCH_LEVELS]
     conv = WinoConv(w.cuda(), b.cuda(), split=split)
+    assert conv.split == split
     src = flat([x.cuda() for x in xs])
     offs = level_pixel_offsets(BENCH_LEVELS, copies)
     dst = torch.full((offs[-1] * K,) if planes else (src.shape[0], K), float("nan"), device="cuda")
@@ -100,8 +93,100 @@ def test_error_against_an_fp64_direct_convolution(K, planes, split):
                else dst[offs[i]:offs[i + 1]].view(copies, h, wd, K).permute(0, 3, 1, 2)).cpu().double()
         assert torch.isfinite(got).all()
         c_max = max(c_max, float(((got - want).abs() / (u * bound)).max()))
-    print("c = %.2f" % c_max)
-    assert c_max <= C_BOUND
+    return c_max
+
+
+@pytest.mark.parametrize("K,planes", [(256, False), (63, True), (36, True)], ids=["trunk-256", "cls_score-63", "bbox_pred-36"])
+def test_error_against_an_fp64_direct_convolution(K, planes):
+    """The referee that is not MIOpen: F.conv2d in fp64 on the CPU, on the benchmark launch's shapes (C = 256, five levels) with
+    post-ReLU activations.  Per ELEMENT  |err| <= c 2^-24 (|w| * |x| + |b|)  -- the unit every forward error bound of an fp32
+    evaluation is written in (a length-n fp32 dot product guarantees c <= n = 2304).  Measured c (tools/wino_fp64_check.py, MI355X):
+    pod_wino_conv3x3 11.6 / 10.8 / 13.6 (trunk / cls_score / bbox_pred), MIOpen's fp32 conv2d 2.5 - 2.8, mkldnn's fp32 conv2d on the
+    CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class.
+    pod_wino_conv3x3_split (every product from exact 3-way bf16 splits, 6 partial products, fp32 accumulate): 10.6 / 9.6 / 8.5.
+    THE CONTRACT OF THE SPLIT KERNEL, per shape: c(K12) <= c(K11) -- it is at least as close to the fp64 result as the fp32-MFMA
+    kernel on every shape it replaces it on (same Winograd, same operation order: the two differ only in how a product is formed)."""
+    c11 = _c_against_fp64(K, planes, False)
+    c12 = _c_against_fp64(K, planes, True)
+    print("c(K11) = %.2f  c(K12) = %.2f" % (c11, c12))
+    assert c11 <= C_BOUND and c12 <= C_BOUND
+    assert c12 <= c11, "the split kernel must not be further from fp64 than the fp32-MFMA kernel (%.2f vs %.2f)" % (c12, c11)
+
+
+def _split3(x):
+    n = x.numel()
+    terms = torch.empty((3, n), dtype=torch.int16, device="cuda")
+    hip.check(hip.load().pod_debug_bf16_split3(x.data_ptr(), terms.data_ptr(), n, hip.current_stream()), "pod_debug_bf16_split3")
+    # bf16 bit pattern -> the fp32 value with those top 16 bits (exact)
+    return (terms.to(torch.int32) << 16).view(torch.float32)
+
+
+def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
+    """The arithmetic contract of pod_wino_conv3x3_split, first half: x == x0 + x1 + x2 BIT FOR BIT for the values the kernel's own
+    split code produces (pod_debug_bf16_split3 runs pod_wino.h: wino_bf16_split3, the functions the K loop calls) -- over normals of
+    every binade incl. the extremes, values with long carry chains and ties, both signs; each term is a bf16 by construction, the
+    residuals shrink by >= 2^8 per term.  What happens below: when a residual falls under 2^-126 (|x| < 2^-110) it is an fp32
+    denormal; the conversion keeps or flushes it -- either way |x - sum| < 2^-126, asserted here and irrelevant to a convolution
+    whose other operand is finite.  +-inf and nan stay inf / nan in the first term."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    n = 1 << 20
+    mant = torch.randint(0, 1 << 23, (n,), device="cuda", generator=g, dtype=torch.int32)
+    expo = torch.randint(1, 255, (n,), device="cuda", generator=g, dtype=torch.int32)          # every normal binade
+    sign = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.int32)
+    x = ((sign << 31) | (expo << 23) | mant).view(torch.float32)
+    special = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.4028234663852886e38, -3.4028234663852886e38, 1.17549435e-38, -1.17549435e-38,
+                            1.0 + 2 ** -23, 1.0 - 2 ** -24, 1.00390625, 1.01171875, 0.99609375 + 2 ** -24, 255.99998474121094,
+                            1.0 + 2 ** -8 + 2 ** -16, 1.0 + 2 ** -9, 1.0 + 2 ** -9 + 2 ** -23, 1.0 + 2 ** -17, 3.0 * 2 ** -9 + 1.0, 2 ** -100, 0.1, 1 / 3.0],
+                           device="cuda")
+    patterns = ((torch.arange(1 << 16, device="cuda", dtype=torch.int32) << 7) | 0x3F800000).view(torch.float32)     # every 16-bit tail in [1, 2)
+    x = torch.cat([special, patterns, x[: n - special.numel() - patterns.numel()]])
+    t = _split3(x)
+    total = t[0].double() + t[1].double() + t[2].double()                                     # exact in fp64 (<= 24 + 16 significant bits)
+    big = x.abs() >= 2.0 ** -100
+    assert torch.equal(total[big], x[big].double()), "x != x0 + x1 + x2 for %d values" % int((total[big] != x[big].double()).sum())
+    assert bool(((total - x.double()).abs()[~big] < 2.0 ** -126).all())
+    assert bool((t[1].abs()[big] <= 2.0 ** -8 * t[0].abs()[big]).all()) and bool((t[2].abs()[big] <= 2.0 ** -8 * t[1].abs()[big]).all())
+    assert bool((t[2].abs()[big] <= 2.0 ** -16 * t[0].abs()[big]).all())
+    # the dropped partial products x1 u2 + x2 u1 + x2 u2 of an operand pair are below 2^-26 |x u|: a quarter of an fp32 rounding of the product
+    x1, x2 = t[1].abs().double(), t[2].abs().double()
+    assert bool(((x1 * x2 * 2 + x2 * x2)[big] <= 2.0 ** -26 * (x.double() ** 2)[big]).all())
+    # the first term is the nearest-even bf16 (same as torch's conversion), also for inf / nan
+    odd = torch.tensor([float("inf"), -float("inf"), float("nan"), 1.0], device="cuda")
+    assert torch.equal(_split3(odd)[0][:2], odd[:2]) and bool(torch.isnan(_split3(odd)[0][2]))
+    assert torch.equal(t[0][big], x[big].to(torch.bfloat16).float())
+
+
+def test_split_filter_terms_sum_to_the_fp32_winograd_filter_exactly():
+    """Second operand: pod_wino_filter_transform_split's three terms of every Winograd-domain filter value sum to the fp32 value
+    pod_wino_filter_transform computes (same transform arithmetic), exactly."""
+    K, C = 64, 32
+    g = torch.Generator(device="cuda").manual_seed(4)
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * 0.05
+    U = WinoConv(w, None, split=False).U.view(-1).double().cpu()                 # fp32 kernel's slab order: [chunk8][24][h][j][4]
+    Us = (WinoConv(w, None, split=True).U.to(torch.int32) << 16).view(torch.float32).double().cpu()
+    # compare as multisets per Winograd position is layout-free: both slabs hold, for every (position q, k, c), one value / three terms
+    # split slab: [chunk16][q][kb][term][h][j][e]; fp32 slab: [chunk8][q][h2][j64][4]
+    S = Us.view(C // 16, 24, 2, 3, 2, 32, 8).sum(dim=3)                           # [chunk16][q][kb][h][j][e]: channel 16 chunk + 8 h + e, k = 32 kb + j
+    S = S.permute(1, 2, 4, 0, 3, 5).reshape(24, 64, C)                             # [q][k][c]
+    F32 = U.view(C // 8, 24, 2, 64, 4).permute(1, 3, 0, 2, 4).reshape(24, 64, C)  # [q][k][c]: channel 8 chunk + 4 h2 + e
+    assert torch.equal(S, F32)
+
+
+def test_split_kernel_is_deterministic_and_independent_of_the_pipeline_position():
+    """The software-pipelined K loop (next chunk's operands made behind the running chunk's MFMAs) must give the same bits whatever C
+    is (1, 2, 3, 4, 5, 16 chunks: the first two chunks take the serial path, the rest the pipelined one) -- checked against the same
+    convolution with the channels zero-padded to the next multiple: extra zero channels add exact zeros."""
+    levels, copies, K = [(23, 40), (6, 10)], 2, 64
+    for C in (16, 32, 48, 64, 80, 256):
+        w, b, xs = make(levels, copies, C, K, seed=C)
+        src, table = flat(xs), block_table(levels, copies, "cuda")
+        a = WinoConv(w, b, split=True)(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True)
+        again = WinoConv(w, b, split=True)(src, torch.empty(src.shape[0], K, device="cuda"), table, relu=True)
+        assert torch.equal(a, again)
+        wp = torch.cat([w, torch.zeros(K, 32, 3, 3, device="cuda")], dim=1)
+        sp = torch.cat([src, torch.zeros(src.shape[0], 32, device="cuda")], dim=1).contiguous()
+        padded = WinoConv(wp, b, split=True)(sp, torch.empty(src.shape[0], K, device="cuda"), table, relu=True)
+        assert torch.equal(a, padded), C
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
