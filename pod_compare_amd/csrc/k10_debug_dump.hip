@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(256) k_debug_bf16_split3(const float* __restri
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
     uint32_t w[3];
-    wino_bf16_split3(x[i], x[i + 1], w);
+    const WinoSplitSel sel;
+    wino_bf16_split3(x[i], x[i + 1], w, sel);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         terms[t * n + i] = (uint16_t)(w[t] & 0xFFFFu);

@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // The three bf16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in five steps whose
     // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert -> residual -> convert):
     // w = nearest-even bf16 pair (v_cvt_pk_bf16_f32), residual r = v - w exactly (in place: vN is dead afterwards).
+    const WinoSplitSel split_sel;
     auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
         vu32x4 w;
 #pragma unroll
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             float& lo = vN[i >> 1][p][2 * (i & 1)];
             float& hi = vN[i >> 1][p][2 * (i & 1) + 1];
             wino_pin(lo, hi);
-            wino_bf16_residual(Vb[p][term][i], lo, hi);
+            wino_bf16_residual(Vb[p][term][i], lo, hi, split_sel);
             wino_pin(lo, hi);
         }
     };

@@ -114,21 +114,29 @@ typedef __bf16 wino_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t wino_bf16_pair(float lo, float hi) {              // v_cvt_pk_bf16_f32: nearest even, lo in bits 15:0
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, wino_bf16x2));
 }
-__device__ __forceinline__ void wino_bf16_residual(uint32_t w, float& lo, float& hi) {   // (lo, hi) -= the bf16 pair w, exactly
+struct WinoSplitSel {                     // the two operand selectors of the residual's v_dot2c_f32_bf16, made once per kernel
+    uint32_t lo, hi;
+    __device__ __forceinline__ WinoSplitSel() : lo(0x0000BF80u), hi(0xBF800000u) {
+        // scalar registers the compiler cannot see through: as an INLINE constant a 16-bit operand's -1.0 is the fp16 pattern 0xBC00,
+        // which read as bf16 is -2^-7
+        asm volatile("" : "+s"(lo), "+s"(hi));
+    }
+};
+__device__ __forceinline__ void wino_bf16_residual(uint32_t w, float& lo, float& hi, const WinoSplitSel& sel) {   // (lo, hi) -= the bf16 pair w, exactly
 #if POD_SPLIT_DOT2C
     // v_dot2c_f32_bf16: D += A.lo B.lo + A.hi B.hi with B = (-1, 0) / (0, -1): ONE instruction per value instead of shift / mask + subtract
-    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, 0x0000BF80u), lo, false);
-    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, 0xBF800000u), hi, false);
+    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, sel.lo), lo, false);
+    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, sel.hi), hi, false);
 #else
     lo -= __builtin_bit_cast(float, w << 16);
     hi -= __builtin_bit_cast(float, w & 0xFFFF0000u);
 #endif
 }
-__device__ __forceinline__ void wino_bf16_split3(float lo, float hi, uint32_t (&w)[3]) {
+__device__ __forceinline__ void wino_bf16_split3(float lo, float hi, uint32_t (&w)[3], const WinoSplitSel& sel) {
     w[0] = wino_bf16_pair(lo, hi);
-    wino_bf16_residual(w[0], lo, hi);
+    wino_bf16_residual(w[0], lo, hi, sel);
     w[1] = wino_bf16_pair(lo, hi);
-    wino_bf16_residual(w[1], lo, hi);
+    wino_bf16_residual(w[1], lo, hi, sel);
     w[2] = wino_bf16_pair(lo, hi);
 }
 

@@ -127,7 +127,9 @@ def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
     every binade incl. the extremes, values with long carry chains and ties, both signs; each term is a bf16 by construction, the
     residuals shrink by >= 2^8 per term.  What happens below: when a residual falls under 2^-126 (|x| < 2^-110) it is an fp32
     denormal; the conversion keeps or flushes it -- either way |x - sum| < 2^-126, asserted here and irrelevant to a convolution
-    whose other operand is finite.  +-inf and nan stay inf / nan in the first term."""
+    whose other operand is finite.  At the other end, |x| >= 2^127 (2 - 2^-8) = 3.396e38 (the last 2^-9 of the fp32 range) rounds to
+    +-inf as a bf16, like any conversion to bf16: such an operand gives inf / nan where an fp32 product would only overflow in the sum.
+    +-inf and nan stay inf / nan in the first term."""
     g = torch.Generator(device="cuda").manual_seed(12)
     n = 1 << 20
     mant = torch.randint(0, 1 << 23, (n,), device="cuda", generator=g, dtype=torch.int32)
@@ -142,9 +144,11 @@ def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
     x = torch.cat([special, patterns, x[: n - special.numel() - patterns.numel()]])
     t = _split3(x)
     total = t[0].double() + t[1].double() + t[2].double()                                     # exact in fp64 (<= 24 + 16 significant bits)
-    big = x.abs() >= 2.0 ** -100
+    over = x.abs() >= 2.0 ** 127 * (2.0 - 2.0 ** -8)
+    assert bool(torch.isinf(t[0][over]).all()) and int(over.sum()) >= 2
+    big = (x.abs() >= 2.0 ** -100) & ~over
     assert torch.equal(total[big], x[big].double()), "x != x0 + x1 + x2 for %d values" % int((total[big] != x[big].double()).sum())
-    assert bool(((total - x.double()).abs()[~big] < 2.0 ** -126).all())
+    assert bool(((total - x.double()).abs()[~big & ~over] < 2.0 ** -126).all())
     assert bool((t[1].abs()[big] <= 2.0 ** -8 * t[0].abs()[big]).all()) and bool((t[2].abs()[big] <= 2.0 ** -8 * t[1].abs()[big]).all())
     assert bool((t[2].abs()[big] <= 2.0 ** -16 * t[0].abs()[big]).all())
     # the dropped partial products x1 u2 + x2 u1 + x2 u2 of an operand pair are below 2^-26 |x u|: a quarter of an fp32 rounding of the product
