@@ -85,9 +85,12 @@ def parse_args():
                     help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="head / backbone 3x3 convolutions on pod_wino_conv3x3_split (fp32 products from 3-way bf16 splits on the bf16 "
-                         "matrix cores) instead of the fp32-MFMA kernel; without the flag that kernel is measured as a second leg (`split_bf16`)")
+    ap.add_argument("--fp32-mfma", action="store_true",
+                    help="3x3 convolutions on pod_wino_conv3x3 (fp32 matrix instructions) instead of pod_wino_conv3x3_split (every fp32 product "
+                         "formed from EXACT 3-way bf16 splits of both operands on the bf16 matrix cores, fp32 accumulate: the production kernel "
+                         "since round 4, contract in tests/test_wino_conv_gpu.py); the other kernel is always measured as a second leg "
+                         "(`fp32_mfma` / `split_bf16`)")
+    ap.add_argument("--split-bf16", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of the model forward from Python instead of replaying a HIP graph "
                                                              "per (stream, shape) (graphs are used for forwards without active dropout only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,7 +98,9 @@ def parse_args():
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
     ap.add_argument("--k1-traffic-bytes", type=float, default=None,
                     help="HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/): 2*FETCH_SIZE + WRITE_SIZE")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.split_bf16 = not a.fp32_mfma
+    return a
 
 
 def relaunch(args):
@@ -224,6 +229,11 @@ def head_conv_roofline(model, net_hw, N, quirk, dev):
             "frac": mfma_flop / avg / 1e9 / peak, "direct_equivalent_tflops": direct_flop / avg / 1e9,
             "algorithmic_flop": mfma_flop, "direct_flop": direct_flop, "avg_launch_us": 1e3 * avg, "min_launch_us": 1e3 * ms[0],
             "tiles": tiles, "tiles_executed_with_block_padding": int(table.shape[0]) * 32, "traffic": traffic,
+            # each fp32 product counted ONCE (the fp32-MFMA kernel's accounting), against the fp32 matrix peak: the figure that compares
+            # the two kernels -- the split kernel spends 6 bf16 partial products per fp32 product and is limited by the power cap, not by
+            # issue slots (profiles/r04_k12_elimination.md: 12 % fewer cycles in round 4 bought no wall time)
+            "fp32_products_tflops": mfma_flop / (6 if conv.split else 1) / avg / 1e9,
+            "fp32_products_vs_fp32_mfma_peak": mfma_flop / (6 if conv.split else 1) / avg / 1e9 / FP32_MFMA_PEAK_TF,
             "share_of_step": "the head's 12 launches of this kernel are ~90 % of a step's GPU time (conv_roofline.by_kind)"}
 
 
@@ -441,7 +451,7 @@ def main():
         "metric": "images/sec (BayesOD+MC-dropout, 1280x720)" if args.config == "cfg3" else "images/sec (%s, 1280x720)" % spec["mode"],
         "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if not args.split_bf16 else "f32 (3x3 convolutions: every product from 3-way bf16 splits of both operands, fp32 accumulate)",
+        "dtype": "f32" if not args.split_bf16 else "f32 (3x3 convolutions: products from exact 3xbf16 splits of both fp32 operands, fp32 accumulate)",
         "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
         "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
                    "classes": params.num_classes, "synthetic_mode": args.synth, "planted_boxes": args.boxes, "conv_net_in_timed_region": not args.no_cnn,
@@ -454,7 +464,10 @@ def main():
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
                    "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
-                   "conv3x3_kernel": "pod_wino_conv3x3_split (bf16 matrix cores, 3-way splits)" if args.split_bf16 else "pod_wino_conv3x3 (fp32 matrix cores)",
+                   "conv3x3_kernel": "pod_wino_conv3x3_split (fp32 Winograd; every product from exact 3xbf16 splits on the bf16 matrix cores, 6 partial "
+                                     "products, fp32 accumulate; per shape at least as close to fp64 as the fp32-MFMA kernel: tests/test_wino_conv_gpu.py); "
+                                     "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
+                                     "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
                    "rng": "in-kernel Philox4x32-10, fresh key per image",
                    "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not mc and not args.no_cnn) else "eager launches from Python"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
@@ -607,7 +620,8 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
             _w.SPLIT_BF16 = not args.split_bf16
             r2 = head_conv_roofline(model, net_hw, N, params.merge_quirk, dev)
             _w.SPLIT_BF16 = bool(args.split_bf16)
-            out[other]["head_conv_launch"] = {k: r2[k] for k in ("kernel", "peak", "achieved", "frac", "direct_equivalent_tflops", "avg_launch_us", "min_launch_us")}
+            out[other]["head_conv_launch"] = {k: r2[k] for k in ("kernel", "peak", "achieved", "frac", "direct_equivalent_tflops", "avg_launch_us", "min_launch_us",
+                                                                 "fp32_products_vs_fp32_mfma_peak")}
 
     # ---- the whole conv net of a step against the fp32 MFMA peak ---------------------------------------------
     if not args.no_cnn and spec.get("members", 1) == 1:

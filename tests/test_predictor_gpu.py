@@ -203,11 +203,15 @@ class Fp64Conv:
         return dst
 
 
-def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(tmp_path):
-    """Detection level, model -> hot path: a calibrated checkpoint with the head sharpened so that detections exist, N = 10 MC
+@pytest.mark.parametrize("split", [True, False], ids=["K12-bf16x6", "K11-fp32-mfma"])
+def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(tmp_path, split, monkeypatch):
+    """(both convolution kernels: the production split kernel and the fp32-MFMA kernel)
+    Detection level, model -> hot path: a calibrated checkpoint with the head sharpened so that detections exist, N = 10 MC
     dropout runs, the same dropout masks and the same hot-path draws; once with every head convolution on pod_wino_conv3x3 and
     once with every head convolution evaluated in fp64 (Fp64Conv).  Same detections: classes and order identical, scores,
     boxes and covariances within the parity tolerance -- fp32 Winograd in the head moves no detection."""
+    from pod_compare_amd import wino
+    monkeypatch.setattr(wino, "SPLIT_BF16", split)
     src, frame = _calibrated_checkpoint(tmp_path, 33)
     cfg = config.setup_config(M + "retinanet_R_50_FPN_1x_reg_cls_var_dropout.yaml", I + "bayes_od_mc_dropout.yaml", random_seed=0,
                               data_dir=str(tmp_path), is_testing=True)
@@ -225,6 +229,7 @@ def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(t
     inp = [{"image": frame.cuda(), "height": 96, "width": 160, "image_id": 7}]      # accumulate with atomics: not bit-reproducible)
     head._drop_calls = 0
     got = pred(inp)
+    assert modeling_wino_split(head) == split
     real = head._wino
     try:
         head._wino = lambda conv: Fp64Conv(conv)
@@ -241,6 +246,11 @@ def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(t
     scale = want.pred_boxes_covariance.cpu().abs().amax(dim=(1, 2), keepdim=True).clamp(min=1.0)       # per detection: an off-diagonal
     assert_close(got.pred_boxes_covariance.cpu() / scale, want.pred_boxes_covariance.cpu() / scale, "cov")   # entry is small against ITS matrix
     assert_close(got.pred_cls_probs.cpu(), want.pred_cls_probs.cpu(), "probs")
+
+
+def modeling_wino_split(head) -> bool:
+    from pod_compare_amd import modeling
+    return modeling.wino_of(head.cls_subnet[1]).split
 
 
 def test_eval_mode_trunk_sharing_on_the_gpu():
