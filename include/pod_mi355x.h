@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 4
+#define POD_ABI_VERSION 5
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -125,6 +125,18 @@ int64_t pod_maybe_words(const PodConfig* cfg, const PodLevel* levels);
  *               emitted here are stored at its row, so that the gather kernel does not evaluate them a second time. */
 int pod_score_maybe(const PodConfig* cfg, const PodLevel* levels, const float* mean_cls, const float* mean_cls_var,
                     uint64_t* maybe_bits, uint64_t* cand_keys, int32_t* cand_count, float* probs_dense, pod_stream_t stream);
+
+/* ---- K1f merge_score_fused (round 4): pod_mc_merge_score's prune mode + pod_score_maybe in ONE streaming launch ---------------
+ * Replaces: PI:211-270 for box_cls / box_cls_var, PI:289-297, PI:301, PI:304 -- the job SURVEY 8 a3 + a4 defines ("merge and score").
+ * Native draws only (every levels[l].eps_cls NULL: the prune bound needs the sampler's |eps| < 4.9); with or without a variance head.
+ * A lane keeps all K classes of its 4 cells in registers through the run loop; cells that may pass are parked in LDS and scored by the
+ * whole workgroup exactly as pod_score_maybe scores them: identical candidate keys (any order inside a level), identical probs_dense rows.
+ * mean_cls / mean_cls_var : merged class planes as pod_mc_merge_score writes them, or both NULL: not stored (nothing downstream of the
+ *                           product path reads them; the gather kernel merges box_delta / box_reg_var at the candidates).
+ * cand_keys / cand_count / probs_dense : as for pod_mc_merge_score / pod_score_maybe (cand_count zero on entry).
+ * HBM-bound; algorithmic bytes per image = 4 * R * 2K * (N - 1) read (quirk on) [+ 4 * R * 2K written when the planes are asked for]. */
+int pod_merge_score_fused(const PodConfig* cfg, const PodLevel* levels, float* mean_cls, float* mean_cls_var, uint64_t* cand_keys,
+                          int32_t* cand_count, float* probs_dense, pod_stream_t stream);
 
 /* Zeroes `n` int32 device words on the stream (graph-capturable memset node). */
 int pod_reset_counters(int32_t* counters, int32_t n, pod_stream_t stream);
@@ -375,7 +387,7 @@ int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t s
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net
  * (PI:86-111 -> PI:178-388 -> the mode's post-processing -> IU:374-425), i.e. the launch sequence
- *   pod_mc_merge_score [+ pod_score_maybe] -> pod_level_topk -> pod_gather_decode (= pod_gather_candidates + pod_decode_cov)
+ *   pod_merge_score_fused (= pod_mc_merge_score + pod_score_maybe) -> pod_level_topk -> pod_gather_decode (= pod_gather_candidates + pod_decode_cov)
  *   -> pod_nms_cluster -> {pod_bayes_fuse | pod_anchor_stats_merge | -} -> pod_finalize
  * enqueued from C on `stream`, in-kernel Philox draws (levels[].eps_cls must be NULL: the eps-replay parity
  * mode needs the host between launches and uses the individual entry points).  Nothing here

@@ -34,12 +34,10 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     if (!ws->cat_keys || !ws->cat_level || !ws->n_total) return POD_E_INVALID;
     if (mode == POD_MODE_BAYES_OD && !has_cov) return POD_E_INVALID;
 
-    POD_TRY(pod_mc_merge_score(cfg, levels, merged ? ws->mean_cls : nullptr, merged ? ws->mean_cls_var : nullptr,
-                               merged ? ws->mean_delta : nullptr, merged ? ws->mean_reg_var : nullptr, ws->cand_keys,
-                               ws->cand_count, prune ? ws->maybe_bits : nullptr, stream));
-    if (prune)
-        POD_TRY(pod_score_maybe(cfg, levels, ws->mean_cls, ws->mean_cls_var, ws->maybe_bits, ws->cand_keys, ws->cand_count,
-                                ws->probs_dense, stream));
+    // merge + score in one streaming launch (round 4; k1f_merge_score_fused.hip).  The merged class planes are not stored: nothing
+    // downstream reads them (the gather kernel merges the box channels at the candidates and takes the class probabilities from
+    // probs_dense, or evaluates them itself when there is no variance head).
+    POD_TRY(pod_merge_score_fused(cfg, levels, nullptr, nullptr, ws->cand_keys, ws->cand_count, prune ? ws->probs_dense : nullptr, stream));
     POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, ws->cat_keys, ws->cat_level,
                            ws->n_total, stream));
     POD_TRY(pod_gather_decode(cfg, levels, ws->anchors, ws->cat_keys, ws->cat_level, ws->n_total, ws->cand_count,

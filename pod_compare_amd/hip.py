@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 4
+POD_ABI_VERSION = 5
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -24,7 +24,7 @@ POD_MAX_CLS_SAMPLES = 64
 POD_MAX_CANDIDATES = 8192
 POD_MAX_DETECTIONS = 128
 
-EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates", "pod_gather_decode",
+EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_merge_score_fused", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates", "pod_gather_decode",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
@@ -93,6 +93,7 @@ def load() -> ctypes.CDLL:
     lib.pod_maybe_words.argtypes = [POINTER(PodConfig), POINTER(PodLevel)]
     lib.pod_maybe_words.restype = c_int64
     lib.pod_score_maybe.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P, P]
+    lib.pod_merge_score_fused.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P]
     lib.pod_level_topk.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P, P, P]
     lib.pod_gather_candidates.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 16
     lib.pod_gather_decode.argtypes = [POINTER(PodConfig), POINTER(PodLevel)] + [P] * 19

@@ -260,16 +260,18 @@ class HotPath:
 
     # ------------------------------------------------------------------------------------------
     def candidates(self, cls, delta, cls_var=None, reg_var=None, eps_cls=None, write_merged: bool = True,
-                   draw_id: Optional[int] = None):
-        """K1 + K2 + K2b: dense tensors -> level-concatenated candidate arrays (device-resident)."""
+                   draw_id: Optional[int] = None, fused: bool = False):
+        """K1 + K2 + K2b: dense tensors -> level-concatenated candidate arrays (device-resident).
+        fused (native draws only): merge + score by pod_merge_score_fused, the one launch pod_run_image uses, instead of
+        pod_mc_merge_score + pod_score_maybe."""
         self._clean()
         self._begin_draw(draw_id)
         self._dirty = True
-        lv = self._candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged)
+        lv = self._candidates(cls, delta, cls_var, reg_var, eps_cls, write_merged, fused)
         self._dirty = False
         return lv
 
-    def _candidates(self, cls, delta, cls_var, reg_var, eps_cls, write_merged):
+    def _candidates(self, cls, delta, cls_var, reg_var, eps_cls, write_merged, fused=False):
         lib, cfg, st = self.lib, self.cfg, hip.current_stream()
         lv = self._levels(cls, delta, cls_var, reg_var, eps_cls)
         self._lv_keepalive = (lv, eps_cls)
@@ -278,14 +280,14 @@ class HotPath:
         # prune mode: native RNG with a variance head -> dense pass flags, K1b samples (see k1_mc_merge_score.hip)
         prune = self.has_cls_var and eps_cls is None
         wm = (write_merged or prune) and self.n_runs > 1
-        hip.check(lib.pod_mc_merge_score(cfg, lv, P(self.mean_cls) if wm else None, P(self.mean_cls_var) if wm else None,
-                                         P(self.mean_delta) if wm and self.dense_box_merge else None,
-                                         P(self.mean_reg_var) if wm and self.dense_box_merge and self.cov_dims else None,
-                                         P(self.cand_keys), P(self.cand_count), P(self.maybe_bits) if prune else None, st),
-                  "pod_mc_merge_score")
-        if prune:
-            hip.check(lib.pod_score_maybe(cfg, lv, P(self.mean_cls), P(self.mean_cls_var), P(self.maybe_bits),
-                                          P(self.cand_keys), P(self.cand_count), P(self.probs_dense), st), "pod_score_maybe")
+        if fused:
+            assert eps_cls is None, "pod_merge_score_fused draws its own normals"
+            hip.check(lib.pod_merge_score_fused(cfg, lv, P(self.mean_cls) if write_merged and self.n_runs > 1 else None,
+                                                P(self.mean_cls_var) if write_merged and self.n_runs > 1 and self.has_cls_var else None,
+                                                P(self.cand_keys), P(self.cand_count), P(self.probs_dense) if prune else None, st),
+                      "pod_merge_score_fused")
+        else:
+            self._merge_score_two_launches(lib, cfg, lv, wm, prune, st)
         hip.check(lib.pod_level_topk(cfg, lv, P(self.cand_keys), P(self.cand_count), P(self.sel_keys), P(self.sel_count),
                                      P(self.cat_keys), P(self.cat_level), P(self.n_total), st), "pod_level_topk")
         hip.check(lib.pod_gather_candidates(cfg, lv, P(self.anchors), P(self.cat_keys), P(self.cat_level), P(self.n_total),
@@ -295,6 +297,17 @@ class HotPath:
                                             P(self.cand_anchor), P(self.cand_run_delta), st),
                   "pod_gather_candidates")
         return lv
+
+    def _merge_score_two_launches(self, lib, cfg, lv, wm, prune, st):
+        P = hip.ptr
+        hip.check(lib.pod_mc_merge_score(cfg, lv, P(self.mean_cls) if wm else None, P(self.mean_cls_var) if wm else None,
+                                         P(self.mean_delta) if wm and self.dense_box_merge else None,
+                                         P(self.mean_reg_var) if wm and self.dense_box_merge and self.cov_dims else None,
+                                         P(self.cand_keys), P(self.cand_count), P(self.maybe_bits) if prune else None, st),
+                  "pod_mc_merge_score")
+        if prune:
+            hip.check(lib.pod_score_maybe(cfg, lv, P(self.mean_cls), P(self.mean_cls_var), P(self.maybe_bits),
+                                          P(self.cand_keys), P(self.cand_count), P(self.probs_dense), st), "pod_score_maybe")
 
     # -- test support: the native-RNG draws of one draw id, in the reference's tensor layouts ----------------------
     def dump_cls_normals(self, draw_id: int) -> List[torch.Tensor]:

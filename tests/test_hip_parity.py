@@ -199,6 +199,59 @@ def test_prune_bound_is_exact(mode, runs, K):
         assert sum(maybe) > 0.9 * hp.R
 
 
+def _fused_candidates(hp, hd, store_planes):
+    from pod_compare_amd import hip
+    P, st, lib = hip.ptr, hip.current_stream(), hp.lib
+    lv = hp._levels(hd.cls, hd.delta, hd.cls_var, hd.reg_var, None)
+    hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")
+    hip.check(lib.pod_merge_score_fused(hp.cfg, lv, P(hp.mean_cls) if store_planes else None,
+                                        P(hp.mean_cls_var) if store_planes and hp.has_cls_var else None, P(hp.cand_keys), P(hp.cand_count),
+                                        P(hp.probs_dense) if hp.has_cls_var else None, st), "k1f")
+    torch.cuda.synchronize()
+    counts = hp.cand_count.cpu().tolist()
+    hip.check(lib.pod_reset_counters(P(hp.counters), 8, st), "reset")
+    keys = [torch.sort(hp.cand_keys[b:b + c].cpu())[0] for b, c in zip(hp.anchor_base, counts)]
+    return counts, keys
+
+
+@pytest.mark.parametrize("mode,runs,K,padded,cls_var", [
+    ("planted", 10, 7, (384, 512), True), ("worst", 3, 7, (384, 512), True), ("planted", 1, 7, (384, 512), True),
+    ("planted", 2, 12, (384, 512), True), ("worst", 2, 3, (160, 224), True),
+    ("planted", 5, 7, (96, 352), True),                  # ragged maps: H*W % 4 != 0 on the small levels (scalar path)
+    ("planted", 1, 7, (384, 512), False), ("planted", 4, 7, (160, 224), False), ("worst", 1, 7, (96, 352), False),    # no variance head
+])
+@pytest.mark.parametrize("quirk", [True, False])
+def test_fused_merge_score_equals_the_two_launch_form(mode, runs, K, padded, cls_var, quirk):
+    """pod_merge_score_fused (one streaming launch: the form pod_run_image enqueues) against pod_mc_merge_score + pod_score_maybe:
+    the same candidate keys on every level, the same stored class probabilities at the emitted anchors, the same merged planes when
+    they are asked for -- bit for bit (same Philox key, same functions)."""
+    ho = synthetic.planted_head_outputs(padded, runs, seed=77 + runs, num_boxes=12, mode=mode, num_classes=K, with_cls_var=cls_var).to("cuda")
+    params = hotpath.PathParams(num_classes=ho.num_classes, num_anchors=ho.num_anchors, merge_quirk=quirk)
+    hp = hotpath.HotPath(ho.shapes, ho.anchors, params, n_runs=runs, has_cls_var=cls_var, cov_dims=4, device="cuda")
+    hp._begin_draw(3)
+    planes = [t for t in (hp.mean_cls, hp.mean_cls_var) if t is not None]
+    if cls_var:
+        hp.probs_dense.fill_(-1.0)
+    c0, k0, _ = _native_candidates(hp, ho, prune=cls_var)
+    planes0 = [t.clone() for t in planes]
+    probs0 = hp.probs_dense.clone() if cls_var else None
+    if cls_var:
+        hp.probs_dense.fill_(-1.0)
+    for t in planes:
+        t.fill_(float("nan"))
+    c1, k1 = _fused_candidates(hp, ho, store_planes=runs > 1)
+    assert c0 == c1 and sum(c0) > 0
+    for a, b in zip(k0, k1):
+        assert torch.equal(a, b)
+    if cls_var:
+        assert torch.equal(probs0, hp.probs_dense)
+    for a, b in zip(planes0, planes):
+        assert torch.equal(a, b)
+    # without the planes: the same keys again
+    c2, k2 = _fused_candidates(hp, ho, store_planes=False)
+    assert c2 == c0 and all(torch.equal(a, b) for a, b in zip(k0, k2))
+
+
 def test_native_mode_is_deterministic_and_close_to_replay():
     g = Golden([p for p in SMALL if "cfg3_bayes_od_mc10_s31" in p][0])
     ho = g.head_outputs()

@@ -128,7 +128,8 @@ def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
     residuals shrink by >= 2^8 per term.  What happens below: when a residual falls under 2^-126 (|x| < 2^-110) it is an fp32
     denormal; the conversion keeps or flushes it -- either way |x - sum| < 2^-126, asserted here and irrelevant to a convolution
     whose other operand is finite.  At the other end, |x| >= 2^127 (2 - 2^-8) = 3.396e38 (the last 2^-9 of the fp32 range) rounds to
-    +-inf as a bf16, like any conversion to bf16: such an operand gives inf / nan where an fp32 product would only overflow in the sum.
+    +-inf as a bf16, like any conversion to bf16: such an operand (and the channel it is paired with) gives inf / nan where an fp32
+    product would only overflow in the sum over the channels.
     +-inf and nan stay inf / nan in the first term."""
     g = torch.Generator(device="cuda").manual_seed(12)
     n = 1 << 20
@@ -146,6 +147,9 @@ def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
     total = t[0].double() + t[1].double() + t[2].double()                                     # exact in fp64 (<= 24 + 16 significant bits)
     over = x.abs() >= 2.0 ** 127 * (2.0 - 2.0 ** -8)
     assert bool(torch.isinf(t[0][over]).all()) and int(over.sum()) >= 2
+    # values are converted in pairs (two channels of a pixel): the residual of the partner of an out-of-range value is 0 x inf = nan too
+    # -- both feed the same dot product over the channels, which is non-finite either way
+    over = over | over.view(-1, 2).flip(1).reshape(-1)
     big = (x.abs() >= 2.0 ** -100) & ~over
     assert torch.equal(total[big], x[big].double()), "x != x0 + x1 + x2 for %d values" % int((total[big] != x[big].double()).sum())
     assert bool(((total - x.double()).abs()[~big & ~over] < 2.0 ** -126).all())
