@@ -9,7 +9,7 @@
 // Why the first fusion (round 3) lost and what is different here.  There a lane owned ONE class of its cells: an anchor that might
 // pass had to be claimed, its other classes re-loaded from HBM (18 scattered loads per class lane) and scored by the wavefront that
 // found it -- and flagged anchors are spatially clustered, so a few wavefronts carried all the scoring after everybody else had
-// finished.  Here a LANE OWNS ALL K CLASSES OF ITS 4 CELLS: 2K accumulators (float4 each) stay in registers through the run loop
+// finished.  Here a LANE OWNS ALL K CLASSES OF ITS CELL(S): 2K accumulators stay in registers through the run loop
 // (the run loop is outside, every load instruction of a wavefront still reads 1 KiB of one plane of one run: the streaming pattern
 // of the flat kernel), the prune test runs on the merged values where they are, and nothing is ever re-loaded.  The cells that may
 // pass are parked in LDS with their 2K merged values, and the WHOLE WORKGROUP -- whose wavefronts stream chunks that lie far apart
@@ -17,14 +17,26 @@
 // class), exactly as K1b does: same function (class_prob_cell), same butterfly, same keys, same stored probabilities.  No bitmap,
 // no second launch, no claim atomics; one aggregated global atomic per level and workgroup.
 //
-// Geometry at BASELINE size (R = 193 374, A = 9, K = 7, N = 10): 765 wave-units of 256 cells x one anchor shape; every lane keeps
-// 2 runs x 14 planes = 28 independent 16-byte non-temporal loads in flight.  No MFMA: element-wise + reductions.
+// Geometry at BASELINE size (R = 193 374, A = 9, K = 7, N = 10): ONE cell per lane -- 3 060 wave-units of 64 cells x one anchor shape,
+// every lane with 2 runs x 14 planes = 28 independent non-temporal loads in flight, 12 wavefronts per CU.  (Four cells per lane --
+// 16-byte loads, 765 wavefronts, less than one per SIMD -- walk their 9 runs as a chain of dependent round trips: 36 us; what hides the
+// HBM latency is wavefronts in flight.  Measured on one box, planted image: K1 + K1b 24.7 + 11.9 us; this kernel 25.9 us, of which the
+// streaming part alone 21 us -- profiles/r04_experiments.md.)  No MFMA: element-wise + reductions.
 #include <mutex>
 
 #include "pod_device.h"
 
 #ifndef POD_K1F_WAVES
-#define POD_K1F_WAVES 2      // wavefronts per workgroup (each streams its own, distant, 256-cell chunk; all of them score the parked cells)
+#define POD_K1F_WAVES 4      // wavefronts per workgroup (each streams its own, distant, chunk; all of them score the parked cells)
+#endif
+#ifndef POD_K1F_WPE
+#define POD_K1F_WPE 3        // wavefronts per SIMD the register allocation aims at: 12 per CU = all 3 060 wavefronts of a BASELINE launch resident
+#endif
+#ifndef POD_K1F_BATCH
+#define POD_K1F_BATCH 2      // runs whose loads are in flight together (CPL < 4): 2 x 2K loads per lane
+#endif
+#ifndef POD_K1F_CELLS
+#define POD_K1F_CELLS 1      // consecutive cells of a plane per lane (1, 2 or 4: 4-, 8- or 16-byte loads)
 #endif
 
 namespace pod {
@@ -44,71 +56,94 @@ struct K1fParams {
     float* probs_dense;      // (R, K): the K probabilities of every anchor emitted, or null
 };
 
+// CPL consecutive cells of one plane per lane: 16-, 8- or 4-byte loads (a wavefront instruction reads 64 * CPL contiguous floats of one
+// plane of one run).  Fewer cells per lane = more wavefronts with fewer registers each: what hides the HBM latency here is wavefronts
+// in flight, as in the flat kernel -- with 4 cells per lane the launch is 765 wavefronts, less than one per SIMD, and every one of them
+// walks its 9 runs as a chain of dependent round trips (measured: 36 us against 25 for K1 alone).
+template <int CPL>
+struct K1fVals {
+    float v[CPL];
+};
 typedef float k1f_f32x4 __attribute__((ext_vector_type(4)));
+typedef float k1f_f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool VEC>
-__device__ __forceinline__ float4 k1f_ld(const float* p, int64_t i, int hw0, int HW) {
-    if (VEC) {
+template <bool VEC, int CPL>
+__device__ __forceinline__ K1fVals<CPL> k1f_ld(const float* p, int64_t i, int hw0, int HW) {
+    K1fVals<CPL> r;
+    if (VEC && CPL == 4) {
         const k1f_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const k1f_f32x4*>(p + i));
-        return float4{v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r.v[j] = v[j];
+    } else if (VEC && CPL == 2) {
+        const k1f_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const k1f_f32x2*>(p + i));
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r.v[j] = v[j];
+    } else if (VEC) {
+        r.v[0] = __builtin_nontemporal_load(p + i);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r.v[j] = hw0 + j < HW ? p[i + j] : 0.0f;
     }
-    float4 v;
-    v.x = hw0 + 0 < HW ? p[i + 0] : 0.0f;
-    v.y = hw0 + 1 < HW ? p[i + 1] : 0.0f;
-    v.z = hw0 + 2 < HW ? p[i + 2] : 0.0f;
-    v.w = hw0 + 3 < HW ? p[i + 3] : 0.0f;
-    return v;
+    return r;
 }
-template <bool VEC>
-__device__ __forceinline__ void k1f_st(float* p, int64_t i, int hw0, int HW, float4 v) {
-    if (VEC) {
-        const k1f_f32x4 w = {v.x, v.y, v.z, v.w};
+template <bool VEC, int CPL>
+__device__ __forceinline__ void k1f_st(float* p, int64_t i, int hw0, int HW, const K1fVals<CPL>& a) {
+    if (VEC && CPL == 4) {
+        const k1f_f32x4 w = {a.v[0], a.v[1 % CPL], a.v[2 % CPL], a.v[3 % CPL]};
         __builtin_nontemporal_store(w, reinterpret_cast<k1f_f32x4*>(p + i));
-        return;
+    } else if (VEC && CPL == 2) {
+        const k1f_f32x2 w = {a.v[0], a.v[1 % CPL]};
+        __builtin_nontemporal_store(w, reinterpret_cast<k1f_f32x2*>(p + i));
+    } else if (VEC) {
+        __builtin_nontemporal_store(a.v[0], p + i);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if (hw0 + j < HW) p[i + j] = a.v[j];
     }
-    if (hw0 + 0 < HW) p[i + 0] = v.x;
-    if (hw0 + 1 < HW) p[i + 1] = v.y;
-    if (hw0 + 2 < HW) p[i + 2] = v.z;
-    if (hw0 + 3 < HW) p[i + 3] = v.w;
 }
-__device__ __forceinline__ float4 k1f_add(float4 a, float4 b) { return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-__device__ __forceinline__ float4 k1f_div(float4 a, float d) { return float4{__fdiv_rn(a.x, d), __fdiv_rn(a.y, d), __fdiv_rn(a.z, d), __fdiv_rn(a.w, d)}; }
+template <int CPL>
+__device__ __forceinline__ void k1f_add(K1fVals<CPL>& a, const K1fVals<CPL>& b) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) a.v[j] = a.v[j] + b.v[j];
+}
 
 // CNT runs x (1 or 2) tensors x K planes of independent loads, then the adds in the reference's order (run after run)
-template <bool VEC, bool VAR, int KP, int CNT>
-__device__ __forceinline__ void k1f_batch(float4 (&mc)[KP], float4 (&mv)[KP], const PodLevel& lv, int K, int64_t i0, int64_t plane_stride, int hw0, int HW, int run0) {
-    float4 c[CNT][KP], v[CNT][KP];
+template <bool VEC, bool VAR, int KP, int CPL, int CNT>
+__device__ __forceinline__ void k1f_batch(K1fVals<CPL> (&mc)[KP], K1fVals<CPL> (&mv)[KP], const PodLevel& lv, int K, int64_t i0, int64_t plane_stride, int hw0, int HW,
+                                          int run0) {
+    K1fVals<CPL> c[CNT][KP], v[CNT][KP];
 #pragma unroll
     for (int j = 0; j < CNT; ++j)
 #pragma unroll
         for (int k = 0; k < KP; ++k)
             if (k < K) {
-                c[j][k] = k1f_ld<VEC>(lv.cls + (int64_t)(run0 + j) * lv.run_stride_cls, i0 + k * plane_stride, hw0, HW);
-                if (VAR) v[j][k] = k1f_ld<VEC>(lv.cls_var + (int64_t)(run0 + j) * lv.run_stride_cls, i0 + k * plane_stride, hw0, HW);
+                c[j][k] = k1f_ld<VEC, CPL>(lv.cls + (int64_t)(run0 + j) * lv.run_stride_cls, i0 + k * plane_stride, hw0, HW);
+                if (VAR) v[j][k] = k1f_ld<VEC, CPL>(lv.cls_var + (int64_t)(run0 + j) * lv.run_stride_cls, i0 + k * plane_stride, hw0, HW);
             }
 #pragma unroll
     for (int j = 0; j < CNT; ++j)
 #pragma unroll
         for (int k = 0; k < KP; ++k)
             if (k < K) {
-                mc[k] = k1f_add(mc[k], c[j][k]);
-                if (VAR) mv[k] = k1f_add(mv[k], v[j][k]);
+                k1f_add(mc[k], c[j][k]);
+                if (VAR) k1f_add(mv[k], v[j][k]);
             }
 }
 
-// PI:216-222 for the 2K planes of one (anchor shape, 4 cells):  quirk: acc = x0; acc += x0; acc += x1 .. x_{N-2}; acc /= N
-//                                                                true mean: acc = x0; acc += x1 .. x_{N-1}; acc /= N
-template <bool VEC, bool VAR, int KP>
-__device__ __forceinline__ void k1f_merge(float4 (&mc)[KP], float4 (&mv)[KP], const K1fParams& P, const PodLevel& lv, int64_t i0, int64_t plane_stride,
+// PI:216-222 for the 2K planes of one (anchor shape, CPL cells):  quirk: acc = x0; acc += x0; acc += x1 .. x_{N-2}; acc /= N
+//                                                                  true mean: acc = x0; acc += x1 .. x_{N-1}; acc /= N
+template <bool VEC, bool VAR, int KP, int CPL>
+__device__ __forceinline__ void k1f_merge(K1fVals<CPL> (&mc)[KP], K1fVals<CPL> (&mv)[KP], const K1fParams& P, const PodLevel& lv, int64_t i0, int64_t plane_stride,
                                           int hw0, int HW) {
     const int K = P.K;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        mc[k] = float4{0.f, 0.f, 0.f, 0.f};
-        mv[k] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) mc[k].v[j] = mv[k].v[j] = 0.0f;
         if (k < K) {
-            mc[k] = k1f_ld<VEC>(lv.cls, i0 + k * plane_stride, hw0, HW);
-            if (VAR) mv[k] = k1f_ld<VEC>(lv.cls_var, i0 + k * plane_stride, hw0, HW);
+            mc[k] = k1f_ld<VEC, CPL>(lv.cls, i0 + k * plane_stride, hw0, HW);
+            if (VAR) mv[k] = k1f_ld<VEC, CPL>(lv.cls_var, i0 + k * plane_stride, hw0, HW);
         }
     }
     if (P.n_runs == 1) return;
@@ -116,27 +151,34 @@ __device__ __forceinline__ void k1f_merge(float4 (&mc)[KP], float4 (&mv)[KP], co
     if (P.quirk) {
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            mc[k] = k1f_add(mc[k], mc[k]);
-            mv[k] = k1f_add(mv[k], mv[k]);
+            k1f_add(mc[k], mc[k]);
+            k1f_add(mv[k], mv[k]);
         }
         last = P.n_runs - 1;
     }
-    while (r + 2 <= last) {
-        k1f_batch<VEC, VAR, KP, 2>(mc, mv, lv, K, i0, plane_stride, hw0, HW, r);
+    constexpr int B = CPL == 4 ? 2 : POD_K1F_BATCH;  // runs per batch: 2K * B * CPL registers of loads in flight per lane
+    while (r + B <= last) {
+        k1f_batch<VEC, VAR, KP, CPL, B>(mc, mv, lv, K, i0, plane_stride, hw0, HW, r);
+        r += B;
+    }
+    if (B > 2 && r + 2 <= last) {
+        k1f_batch<VEC, VAR, KP, CPL, 2>(mc, mv, lv, K, i0, plane_stride, hw0, HW, r);
         r += 2;
     }
-    if (r < last) k1f_batch<VEC, VAR, KP, 1>(mc, mv, lv, K, i0, plane_stride, hw0, HW, r);
+    if (r < last) k1f_batch<VEC, VAR, KP, CPL, 1>(mc, mv, lv, K, i0, plane_stride, hw0, HW, r);
     const float fn = (float)P.n_runs;
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        mc[k] = k1f_div(mc[k], fn);
-        mv[k] = k1f_div(mv[k], fn);
-    }
+    for (int k = 0; k < KP; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            mc[k].v[j] = __fdiv_rn(mc[k].v[j], fn);
+            mv[k].v[j] = __fdiv_rn(mv[k].v[j], fn);
+        }
 }
 
-template <int KP, int WAVES>
+template <int KP, int WAVES, int CPL>
 struct K1fLds {
-    static constexpr int CAP = 256 * WAVES;          // every cell of the workgroup may be parked
+    static constexpr int CAP = 64 * CPL * WAVES;     // every cell of the workgroup may be parked
     float val[CAP][2 * KP];                          // merged logits, merged log-variances of a parked cell
     int32_t meta[CAP][2];                            // level << 8 | a, hw
     uint64_t key[CAP];                               // keys above the threshold ...
@@ -145,10 +187,10 @@ struct K1fLds {
     int32_t lvl_count[POD_MAX_LEVELS], lvl_base[POD_MAX_LEVELS];
 };
 
-template <int KP, int WAVES, bool VAR>
-__global__ void __launch_bounds__(64 * WAVES) k1f_merge_score(const K1fParams P) {
+template <int KP, int WAVES, int CPL, bool VAR>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(POD_K1F_WPE, POD_K1F_WPE))) k1f_merge_score(const K1fParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1f_lds_raw[];
-    K1fLds<KP, WAVES>& S = *reinterpret_cast<K1fLds<KP, WAVES>*>(k1f_lds_raw);
+    K1fLds<KP, WAVES, CPL>& S = *reinterpret_cast<K1fLds<KP, WAVES, CPL>*>(k1f_lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = P.n_levels, K = P.K, A = P.A;
     if (tid == 0) {
@@ -159,31 +201,35 @@ __global__ void __launch_bounds__(64 * WAVES) k1f_merge_score(const K1fParams P)
     __syncthreads();
 
     // ---- stream: wavefront w of workgroup b takes wave-unit b + w * gridDim.x (units of one workgroup lie far apart) -----------------
+#ifdef POD_K1F_ADJ
+    const int u = (int)blockIdx.x * WAVES + wave;            // (experiment: the wavefronts of a workgroup stream ADJACENT chunks)
+#else
     const int u = (int)blockIdx.x + wave * (int)gridDim.x;
+#endif
     if (u < P.unit_begin[L]) {
         int l = 0;
         while (l + 1 < L && u >= P.unit_begin[l + 1]) ++l;
         const PodLevel& lv = P.lv[l];
         const int local = u - P.unit_begin[l];
-        const int a = local / P.chunks[l], chunk = local - a * P.chunks[l];
+        const int a = local / P.chunks[l], chunk = local - a * P.chunks[l];          // chunk = 64 * CPL cells
         const int HW = lv.H * lv.W;
-        const int hw0 = chunk * 256 + lane * 4;
+        const int hw0 = (chunk * 64 + lane) * CPL;
         if (hw0 < HW) {
             const int64_t i0 = (int64_t)a * K * HW + hw0;          // element of plane (a, k = 0); plane (a, k) is k * HW further
-            float4 mc[KP], mv[KP];
-            if (P.vec[l]) k1f_merge<true, VAR, KP>(mc, mv, P, lv, i0, HW, hw0, HW);
-            else k1f_merge<false, VAR, KP>(mc, mv, P, lv, i0, HW, hw0, HW);
+            K1fVals<CPL> mc[KP], mv[KP];
+            if (P.vec[l]) k1f_merge<true, VAR, KP, CPL>(mc, mv, P, lv, i0, HW, hw0, HW);
+            else k1f_merge<false, VAR, KP, CPL>(mc, mv, P, lv, i0, HW, hw0, HW);
             if (P.n_runs > 1 && P.mean_cls) {
                 const int64_t off = (int64_t)lv.anchor_base * K + i0;
 #pragma unroll
                 for (int k = 0; k < KP; ++k)
                     if (k < K) {
                         if (P.vec[l]) {
-                            k1f_st<true>(P.mean_cls, off + (int64_t)k * HW, hw0, HW, mc[k]);
-                            if (VAR && P.mean_cls_var) k1f_st<true>(P.mean_cls_var, off + (int64_t)k * HW, hw0, HW, mv[k]);
+                            k1f_st<true, CPL>(P.mean_cls, off + (int64_t)k * HW, hw0, HW, mc[k]);
+                            if (VAR && P.mean_cls_var) k1f_st<true, CPL>(P.mean_cls_var, off + (int64_t)k * HW, hw0, HW, mv[k]);
                         } else {
-                            k1f_st<false>(P.mean_cls, off + (int64_t)k * HW, hw0, HW, mc[k]);
-                            if (VAR && P.mean_cls_var) k1f_st<false>(P.mean_cls_var, off + (int64_t)k * HW, hw0, HW, mv[k]);
+                            k1f_st<false, CPL>(P.mean_cls, off + (int64_t)k * HW, hw0, HW, mc[k]);
+                            if (VAR && P.mean_cls_var) k1f_st<false, CPL>(P.mean_cls_var, off + (int64_t)k * HW, hw0, HW, mv[k]);
                         }
                     }
             }
@@ -192,20 +238,21 @@ __global__ void __launch_bounds__(64 * WAVES) k1f_merge_score(const K1fParams P)
 #pragma unroll
             for (int k = 0; k < KP; ++k)
                 if (k < K) {
-                    const float lg[4] = {mc[k].x, mc[k].y, mc[k].z, mc[k].w};
-                    const float vr[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float top = VAR ? fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * vr[j]), lg[j]) : lg[j];
+                    for (int j = 0; j < CPL; ++j) {
+                        const float top = VAR ? fmaf(POD_EPS_MAX, __builtin_amdgcn_exp2f(0.7213475204444817f * mv[k].v[j]), mc[k].v[j]) : mc[k].v[j];
                         if (top > P.skip_logit) flags |= 1u << j;
                     }
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CPL; ++j)
                 if (hw0 + j >= HW) flags &= ~(1u << j);
+#ifdef POD_K1F_NOSCORE
+            flags = 0;                                       // (experiment: the streaming part alone)
+#endif
             // park the flagged cells with their 2K merged values
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CPL; ++j) {
                 const bool f = (flags >> j) & 1u;
                 const unsigned long long m = __ballot(f);
                 if (m == 0ull) continue;
@@ -218,10 +265,8 @@ __global__ void __launch_bounds__(64 * WAVES) k1f_merge_score(const K1fParams P)
                     S.meta[slot][1] = hw0 + j;
 #pragma unroll
                     for (int k = 0; k < KP; ++k) {
-                        const float lgk[4] = {mc[k].x, mc[k].y, mc[k].z, mc[k].w};
-                        const float vrk[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w};
-                        S.val[slot][k] = lgk[j];
-                        S.val[slot][KP + k] = vrk[j];
+                        S.val[slot][k] = mc[k].v[j];
+                        S.val[slot][KP + k] = mv[k].v[j];
                     }
                 }
             }
@@ -271,21 +316,20 @@ __global__ void __launch_bounds__(64 * WAVES) k1f_merge_score(const K1fParams P)
 
 }  // namespace pod
 
-static inline bool k1f_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int KP, int WAVES, bool VAR>
+template <int KP, int WAVES, int CPL, bool VAR>
 static int k1f_launch(const pod::K1fParams& P, int units, hipStream_t stream) {
-    constexpr size_t lds = sizeof(pod::K1fLds<KP, WAVES>);
+    constexpr size_t lds = sizeof(pod::K1fLds<KP, WAVES, CPL>);
     static std::once_flag once[64];
     static hipError_t attr[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
     std::call_once(once[dev], [dev] {
-        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k1f_merge_score<KP, WAVES, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k1f_merge_score<KP, WAVES, CPL, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr[dev] != hipSuccess) return POD_E_LAUNCH;
     const int blocks = (units + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL((pod::k1f_merge_score<KP, WAVES, VAR>), dim3(blocks), dim3(64 * WAVES), lds, stream, P);
+    hipLaunchKernelGGL((pod::k1f_merge_score<KP, WAVES, CPL, VAR>), dim3(blocks), dim3(64 * WAVES), lds, stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
@@ -297,6 +341,7 @@ extern "C" int pod_merge_score_fused(const PodConfig* cfg, const PodLevel* level
     if (L < 1 || L > POD_MAX_LEVELS || K < 1 || K > POD_MAX_CLASSES || A < 1 || A > 255 || N < 1 || N > POD_MAX_RUNS) return POD_E_INVALID;
     if (cfg->has_cls_var && (cfg->cls_samples < 1 || cfg->cls_samples > POD_MAX_CLS_SAMPLES)) return POD_E_INVALID;
     if ((mean_cls == nullptr) != (mean_cls_var == nullptr) && cfg->has_cls_var) return POD_E_INVALID;
+    constexpr int CPL = POD_K1F_CELLS;
     pod::K1fParams P;
     int32_t ub = 0;
     for (int l = 0; l < L; ++l) {
@@ -306,11 +351,13 @@ extern "C" int pod_merge_score_fused(const PodConfig* cfg, const PodLevel* level
         const int64_t HW = (int64_t)lv.H * lv.W;
         if ((int64_t)A * K * HW >= (int64_t)1 << 31) return POD_E_INVALID;
         P.lv[l] = lv;
-        P.chunks[l] = (int32_t)((HW + 255) / 256);
+        P.chunks[l] = (int32_t)((HW + 64 * CPL - 1) / (64 * CPL));
         P.unit_begin[l] = ub;
         ub += A * P.chunks[l];
-        P.vec[l] = (HW % 4 == 0) && k1f_aligned16(lv.cls) && (lv.run_stride_cls % 4 == 0) && (!cfg->has_cls_var || k1f_aligned16(lv.cls_var)) &&
-                   ((int64_t)lv.anchor_base * K % 4 == 0) && k1f_aligned16(mean_cls) && k1f_aligned16(mean_cls_var);
+        const uintptr_t am = 4 * CPL - 1;
+        auto al = [am](const void* p) { return (reinterpret_cast<uintptr_t>(p) & am) == 0; };
+        P.vec[l] = (HW % CPL == 0) && al(lv.cls) && (lv.run_stride_cls % CPL == 0) && (!cfg->has_cls_var || al(lv.cls_var)) &&
+                   ((int64_t)lv.anchor_base * K % CPL == 0) && al(mean_cls) && al(mean_cls_var);
     }
     P.unit_begin[L] = ub;
     P.n_levels = L; P.n_runs = N; P.A = A; P.K = K; P.has_cls_var = cfg->has_cls_var; P.quirk = cfg->merge_quirk; P.cls_samples = cfg->cls_samples;
@@ -321,6 +368,6 @@ extern "C" int pod_merge_score_fused(const PodConfig* cfg, const PodLevel* level
     }
     P.mean_cls = mean_cls; P.mean_cls_var = mean_cls_var; P.cand_keys = cand_keys; P.cand_count = cand_count; P.probs_dense = probs_dense;
     const hipStream_t st = (hipStream_t)stream;
-    if (cfg->has_cls_var) return K <= 8 ? k1f_launch<8, POD_K1F_WAVES, true>(P, ub, st) : k1f_launch<16, POD_K1F_WAVES, true>(P, ub, st);
-    return K <= 8 ? k1f_launch<8, POD_K1F_WAVES, false>(P, ub, st) : k1f_launch<16, POD_K1F_WAVES, false>(P, ub, st);
+    if (cfg->has_cls_var) return K <= 8 ? k1f_launch<8, POD_K1F_WAVES, CPL, true>(P, ub, st) : k1f_launch<16, POD_K1F_WAVES, CPL, true>(P, ub, st);
+    return K <= 8 ? k1f_launch<8, POD_K1F_WAVES, CPL, false>(P, ub, st) : k1f_launch<16, POD_K1F_WAVES, CPL, false>(P, ub, st);
 }

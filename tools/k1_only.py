@@ -23,9 +23,16 @@ st = current_stream()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
 prune = os.environ.get("K1_PRUNE", "1") == "1"
 evb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+fused = os.environ.get("K1_FUSED", "0") == "1"      # pod_merge_score_fused (K1f) instead of K1 + K1b; K1_FUSED_PLANES=1: also store the merged planes
 def launch(j):
     hp.lib.pod_reset_counters(P(hp.counters), 8, st)
     if j >= 0: ev[j][0].record()
+    if fused:
+        pl = os.environ.get("K1_FUSED_PLANES", "0") == "1"
+        check(hp.lib.pod_merge_score_fused(hp.cfg, lvs[j % n_img], P(hp.mean_cls) if pl else None, P(hp.mean_cls_var) if pl else None,
+                                           P(hp.cand_keys), P(hp.cand_count), P(hp.probs_dense), st), "k1f")
+        if j >= 0: ev[j][1].record()
+        return
     check(hp.lib.pod_mc_merge_score(hp.cfg, lvs[j % n_img], P(hp.mean_cls), P(hp.mean_cls_var), P(hp.mean_delta),
                                     P(hp.mean_reg_var), P(hp.cand_keys), P(hp.cand_count), P(hp.maybe_bits) if prune else None, st), "k1")
     if j >= 0: ev[j][1].record()
@@ -41,7 +48,7 @@ for j in range(iters): launch(j)
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 print("K1 events: avg %.2f us  min %.2f  med %.2f  max %.2f  (R=%d N=%d, %s, %s)" % (1e3 * sum(ms) / len(ms), 1e3 * ms[0], 1e3 * ms[len(ms) // 2], 1e3 * ms[-1], hp.R, N, synth, "all channels" if hp.dense_box_merge else "class channels"))
-if prune:
+if prune and not fused:
     mb = sorted(a.elapsed_time(b) for a, b in evb)
     print("K1b events: avg %.2f us  min %.2f" % (1e3 * sum(mb) / len(mb), 1e3 * mb[0]))
-print("cand counts", hp.counters[:5].tolist(), "maybe anchors", int(sum(bin(int(x) & (2**64 - 1)).count("1") for x in hp.maybe_bits.tolist())) if prune else 0)
+print("cand counts", hp.counters[:5].tolist(), "maybe anchors", int(sum(bin(int(x) & (2**64 - 1)).count("1") for x in hp.maybe_bits.tolist())) if prune and not fused else 0)
