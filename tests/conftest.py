@@ -24,3 +24,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """On a GPU box: what the parity tolerances actually used (tests/helpers.py: PARITY_LOG) -> gpurun_out/parity_errors.{json,md}."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        from tests import helpers
+        helpers.write_parity_report(os.path.join(ROOT, "gpurun_out"))
+    except Exception as e:  # pragma: no cover  (a report must never fail a test run)
+        print("parity report not written:", e)

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-idx = [i for i, r in enumerate(rows) if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if any(t in r["Kernel_Name"] for t in ("k1f_merge_score", "k1_prune_stream", "k1_mc_merge_score"))]
 # K1 of image j comes AFTER image j's conv net: the span between K1 of image first-1 and K1 of image first-1+n covers n
 # hot-path tails + n conv nets
 a, b = idx[first - 1], idx[first - 1 + n]

@@ -45,7 +45,7 @@ def k1_counters(prefix):
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if "k1_prune_stream" in r["Kernel_Name"] or "k1_mc_merge_score" in r["Kernel_Name"]:
+            if any(t in r["Kernel_Name"] for t in ("k1f_merge_score", "k1_prune_stream", "k1_mc_merge_score")):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             pm[k] = (sum(v) / len(v), min(v), max(v), len(v))

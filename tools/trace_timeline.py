@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # an image starts at k_reset_counters / the K1 launch; take the last 3 complete images
-starts = [i for i, n in enumerate(names) if "k1_prune_stream" in n or "k1_mc_merge_score" in n]
+starts = [i for i, n in enumerate(names) if any(t in n for t in ("k1f_merge_score", "k1_prune_stream", "k1_mc_merge_score"))]
 if len(starts) < 4:
     sys.exit("not enough images in the trace")
 for img in range(len(starts) - 4, len(starts) - 1):
