@@ -99,7 +99,7 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
 # Which kernel serves a 3x3 convolution.  Default (round 4): pod_wino_conv3x3_split (csrc/k12_wino_conv_split.hip) where the channel
 # count allows it (C % 16 == 0) -- the same fp32 Winograd with every product formed from EXACT 3-way bf16 splits of both fp32 operands
 # on the bf16 matrix cores (6 partial products, fp32 accumulate).  Its contract is tested, not assumed (tests/test_wino_conv_gpu.py):
-# x == x0 + x1 + x2 bit for bit, the dropped partial products are below 2^-25 |x u|, and on every benchmark shape its error against an
+# x == x0 + x1 + x2 bit for bit, the three dropped partial products are below 2^-23 |x u| in the worst case (a quarter of that on average), and on every benchmark shape its error against an
 # fp64 convolution is no larger than the fp32-MFMA kernel's.  POD_WINO_SPLIT=0: pod_wino_conv3x3 (fp32 matrix instructions) everywhere.
 SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"
 
