@@ -582,7 +582,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
     kd_bytes = k1_algorithmic_bytes(R, K, D, N, spec["cls_var"], params.merge_quirk, dense_box=True)
     # HBM traffic of K1 comes from separate rocprofv3 --pmc passes (a counter run cannot share a process with this timing
     # run); the committed summary of the latest pass is read back when it was taken on this very workload.
-    traffic, traffic_src, traffic_dense = args.k1_traffic_bytes, "--k1-traffic-bytes", None
+    traffic, traffic_src, traffic_dense, traffic_fused = args.k1_traffic_bytes, "--k1-traffic-bytes", None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_k1_traffic.json")), reverse=True):
         t = json.load(open(path))
         w = t.get("workload", {})
@@ -591,6 +591,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
             if traffic is None and t.get(key) is not None:
                 traffic, traffic_src = t[key], os.path.relpath(path, ROOT) + ": " + t.get("source", "")
             traffic_dense = t.get("k1_dense_traffic_bytes")
+            traffic_fused = t.get("k1_fused_traffic_bytes")
             break
     achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
     out["roofline"] = {"kernel": "pod_mc_merge_score (k1_prune_stream)" if prune else "pod_mc_merge_score (k1_mc_merge_score)",
@@ -603,7 +604,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                        # (pod_merge_score_fused); algorithmic bytes = the runs it must read (+ the merged planes when they are stored)
                        "merge_and_score": {"what": "pod_merge_score_fused: merge + score in one launch (what pod_run_image enqueues); the merged planes "
                                                    "are not stored (nothing downstream reads them)",
-                                           "algorithmic_bytes": kf_bytes, "avg_us": 1e3 * kf_avg_ms, "min_us": 1e3 * kf_min_ms,
+                                           "algorithmic_bytes": kf_bytes, "traffic": traffic_fused, "avg_us": 1e3 * kf_avg_ms, "min_us": 1e3 * kf_min_ms,
                                            "achieved": kf_bytes / (kf_avg_ms * 1e-3) / 1e9, "frac": kf_bytes / (kf_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "with_merged_planes_stored": {"algorithmic_bytes": k1_bytes, "avg_us": 1e3 * kfp_avg_ms,
                                                                          "frac": k1_bytes / (kfp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

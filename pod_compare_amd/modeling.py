@@ -525,6 +525,7 @@ class ProbabilisticRetinaNet(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(3, 1, 1), persistent=False)
         self._anchor_cache: Dict[Tuple[int, int], List[torch.Tensor]] = {}
         self.use_graphs = False
+        self.max_graphs = 12                                   # (stream, frame shape, flags) entries kept; each owns its activations
         self._graphs: Dict[tuple, tuple] = {}
 
     @property
@@ -575,7 +576,13 @@ class ProbabilisticRetinaNet(nn.Module):
             with torch.cuda.graph(graph, stream=side):
                 out = self._forward_eager(static_in, n, False, skip)
             stream.wait_stream(side)
-            ent = self._graphs[key] = (graph, static_in, out)
+            while len(self._graphs) >= self.max_graphs:          # frames of many different sizes: keep the most recent shapes only
+                torch.cuda.synchronize(image.device)             # (a consumer of the evicted graph's tensors may still be queued)
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = (graph, static_in, out)
+        else:
+            self._graphs.pop(key)
+        self._graphs[key] = ent                                # most recently used last
         graph, static_in, out = ent
         static_in.copy_(image, non_blocking=True)
         graph.replay()

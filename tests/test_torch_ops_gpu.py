@@ -36,6 +36,28 @@ def test_predict_operator_equals_hotpath_and_reference_counts():
     assert_close(c1.cpu(), g1.t("pred_boxes_covariance"), "cov")
 
 
+def test_predict_operator_follows_new_anchor_tensors_without_growing_its_cache():
+    """detectron2's anchor generator returns NEW tensors on every forward.  The operator's workspace keeps a copy of the
+    anchors: a call with other anchor tensors of the same geometry must decode against THOSE (not the cached copy), must not be
+    fooled by a recycled address, and must not add a workspace per call."""
+    from pod_compare_amd import torch_ops
+    g = Golden(os.path.join(GOLDEN, "cfg2_bayes_od_regclsvar_s21.npz"))
+    ho = g.head_outputs().to("cuda")
+    image, out = list(g.meta["image"]), list(g.meta["out"])
+    call = lambda anchors: torch.ops.pod_mi355x.predict(ho.cls, ho.delta, ho.cls_var, ho.reg_var, anchors, "bayes_od", image, out, draw_id=9)
+    ref = call(ho.anchors)
+    n_paths = len(torch_ops._PATHS)
+    for rep in range(5):
+        shifted = [a + 3.0 for a in ho.anchors]                  # new tensors (possibly at recycled addresses), other values
+        got = call(shifted)
+        assert torch.equal(got[3], ref[3]) and not torch.equal(got[0], ref[0])          # same classes, boxes moved with the anchors
+        del shifted
+        same = call([a.clone() for a in ho.anchors])             # new tensors again, the original values
+        assert all(torch.equal(x, y) for x, y in zip(same, ref))
+    assert len(torch_ops._PATHS) == n_paths
+    assert len(torch_ops._PATHS) <= torch_ops._MAX_PATHS
+
+
 def test_nms_and_nll_operators():
     boxes, scores, classes = clustered(1000, 5, (1344.0, 768.0))
     keep = torch.ops.pod_mi355x.nms_cluster(boxes.cuda(), scores.cuda(), classes.cuda(), 0.5, 100, 3)

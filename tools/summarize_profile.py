@@ -31,6 +31,7 @@ def table(name, title, only_pod=False, top=24):
 
 table("k1_class", "K1 alone, product configuration (2K class channels): `rocprofv3 --kernel-trace --stats -- python tools/k1_only.py 120`", True)
 table("k1_dense", "K1 alone, dense merge of all 2K+4+D channels: `K1_DENSE=1 rocprofv3 --kernel-trace --stats -- python tools/k1_only.py 120`", True)
+table("k1_fused", "K1f alone (merge + score in one launch, the product form since round 4): `K1_FUSED=1 rocprofv3 --kernel-trace --stats -- python tools/k1_only.py 120`", True)
 ev = os.path.join(src, "k1_events.txt")
 if os.path.exists(ev):
     lines += ["K1 alone, HIP events per launch (`python tools/k1_only.py 120`, class channels then `K1_DENSE=1`):", "", "```"] + \
@@ -55,11 +56,14 @@ def k1_counters(prefix):
 traffic = {"workload": {"anchors_R": 193374, "mc_runs": 10, "config": "cfg3", "synthetic_mode": "planted"},
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/k1_only.py 12; FETCH_SIZE x2 (gfx950)"}
 for prefix, key, what in (("", "k1_class_traffic_bytes", "product path: K1 streams the 2K class channels"),
-                          ("dense_", "k1_dense_traffic_bytes", "K1_DENSE=1: dense merge of all 2K+4+D channels")):
+                          ("dense_", "k1_dense_traffic_bytes", "K1_DENSE=1: dense merge of all 2K+4+D channels"),
+                          ("fused_", "k1_fused_traffic_bytes", "K1_FUSED=1: pod_merge_score_fused (k1f_merge_score), merge + score in one launch, planes not "
+                                                               "stored; 4-byte loads per lane: the x2 correction of FETCH_SIZE is calibrated for 16-byte "
+                                                               "loads only, so the figure is an upper bound here")):
     pm = k1_counters(prefix)
     if not pm:
         continue
-    lines += ["## PMC counters of K1 (`k1_prune_stream`), %s (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)" % what, "",
+    lines += ["## PMC counters of K1 / K1f, %s (separate `rocprofv3 --pmc` passes, `python tools/k1_only.py 12`)" % what, "",
               "| counter | mean per launch | min | max | launches |", "|---|---|---|---|---|"]
     for k, (m, lo, hi, n) in sorted(pm.items()):
         lines.append("| %s | %.6g | %.6g | %.6g | %d |" % (k, m, lo, hi, n))
