@@ -204,6 +204,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #ifdef POD_K1F_ADJ
     const int u = (int)blockIdx.x * WAVES + wave;            // (experiment: the wavefronts of a workgroup stream ADJACENT chunks)
 #else
+    // (rotating the quarters against each other so that the four units of a workgroup lie in different parts of the IMAGE as well:
+    //  measured, no difference -- the 4 us this kernel takes beyond its streaming part are the barrier, one scoring round and the
+    //  emission, not a cluster that piled up in one workgroup)
     const int u = (int)blockIdx.x + wave * (int)gridDim.x;
 #endif
     if (u < P.unit_begin[L]) {

@@ -152,6 +152,7 @@ def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
 WINO_HEAD = True              # GPU only: the head subnets' 3x3 convs on pod_wino_conv3x3 (all levels, all runs per launch)
 WINO_BACKBONE = __import__("os").environ.get("POD_WINO_BACKBONE", "1") != "0"   # GPU only: the bottlenecks' and the FPN's 3x3 / stride-1 convs on pod_wino_conv3x3 too (batch 1: few
                               # workgroups per launch, but a third of MIOpen's CU-time per FLOP -- the other streams' images fill the idle CUs)
+WINO_BACKBONE_MIN_CELLS = int(__import__("os").environ.get("POD_WINO_MIN_CELLS", "0"))   # (experiment knob: smaller maps stay on MIOpen)
 NHWC_TRUNK_MIN_CELLS = 8192   # head trunks of maps at least this large run channels-last (p3 of a 768x1344 input: 16128)
 
 
@@ -178,7 +179,7 @@ def wino_eligible(conv: Optional[nn.Conv2d], x: torch.Tensor) -> bool:
     return (WINO_BACKBONE and FUSE_CONV_TAIL and conv is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1
             and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and conv.groups == 1
             and tuple(conv.dilation) == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels in (64, 128, 256, 512)
-            and x.shape[2] < 4096 and x.shape[3] < 4096
+            and x.shape[2] < 4096 and x.shape[3] < 4096 and x.shape[2] * x.shape[3] >= WINO_BACKBONE_MIN_CELLS
             and x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 4 <= _wino_limits())      # 32-bit offsets inside a canvas
 
 
