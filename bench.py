@@ -661,6 +661,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                         "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF,
                                         "achieved": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0),
                                         "frac": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0) / (BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF),
+                                        "fp32_products_vs_fp32_mfma_peak": bb["mfma_tflops_executed"] / FP32_MFMA_PEAK_TF,     # every fp32 product counted once
                                         "direct_equivalent_tflops": bb["tflops"], "gflop_direct": bb["gflop"], "ms_per_image": bb["ms"],
                                         "traffic": None,
                                         "note": "HIP events around each launch on one stream (launch gaps included); MIOpen's Winograd on the same "
