@@ -574,7 +574,9 @@ class ProbabilisticRetinaNet(nn.Module):
             side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
             side.wait_stream(stream)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events must
+            # not abort it)
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 out = self._forward_eager(static_in, n, False, skip)
             stream.wait_stream(side)
             while len(self._graphs) >= self.max_graphs:          # frames of many different sizes: keep the most recent shapes only
