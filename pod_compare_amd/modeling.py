@@ -86,7 +86,7 @@ FUSE_CONV_TAIL = True     # GPU only: conv without bias + ONE pod_bias_act pass 
 
 def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None, residual_module=None,
                   residual_input: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
-                  out_nchw: bool = False) -> torch.Tensor:
+                  out_nchw: bool = False, residual_raw: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(m(x) [+ residual]) with the element-wise tail in one HIP pass.
 
     torch's conv on ROCm is MIOpen's kernel plus a separate bias `add_`; followed by clamp (and the bottleneck's add, and
@@ -112,7 +112,7 @@ def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[tor
     y = F.conv2d(x, _weight_for(conv, nhwc), None, conv.stride, conv.padding, conv.dilation, conv.groups)
     res_bias = None
     if rconv is not None:
-        residual = F.conv2d(residual_input, rconv.weight, None, rconv.stride, rconv.padding, rconv.dilation, rconv.groups)
+        residual = residual_raw if residual_raw is not None else shortcut_raw(rconv, residual_input)
         res_bias = rconv.bias
     C, HW = y.shape[1], y.shape[2] * y.shape[3]
     if nhwc and residual is None and y.is_contiguous(memory_format=torch.channels_last):
@@ -132,6 +132,11 @@ def conv_bias_act(m, x: torch.Tensor, relu: bool = False, residual: Optional[tor
     hip.check(lib.pod_bias_act(y.data_ptr(), hip.ptr(conv.bias), hip.ptr(residual), hip.ptr(res_bias), y.numel(), C, HW,
                                1 if relu else 0, float(dropout_p), seed, offset, hip.current_stream()), "pod_bias_act")
     return y
+
+
+def shortcut_raw(rconv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A shortcut conv without its bias (the bias rides on the pass that adds the residual)."""
+    return F.conv2d(x, rconv.weight, None, rconv.stride, rconv.padding, rconv.dilation, rconv.groups)
 
 
 def _weight_for(conv: nn.Conv2d, channels_last: bool) -> torch.Tensor:
@@ -198,6 +203,34 @@ def wino_conv_nchw(conv: nn.Conv2d, x: torch.Tensor, relu: bool, pre_bias: Optio
     return out
 
 
+_SIDE_STREAMS: Dict[Tuple[int, int], List["torch.cuda.Stream"]] = {}
+
+
+def branches(fns):
+    """Runs independent pieces of a forward.  Eagerly: one after the other on the current stream.  While the forward is being CAPTURED
+    into a HIP graph: each on its own stream, forked from and joined back into the capturing stream -- the graph then holds them as
+    parallel branches, and launches that fill a fraction of the chip (a single-run head layer is 372 workgroups for 256 CUs, a
+    predictor 93, an FPN output conv of p5 24) run side by side instead of one after the other.  (Capture only: there every tensor
+    comes from the graph's private pool, so memory handed from a side stream to the main one needs no `record_stream`.)"""
+    if len(fns) < 2 or not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index or 0, cur.cuda_stream)
+    side = _SIDE_STREAMS.setdefault(key, [])
+    while len(side) < len(fns) - 1:
+        side.append(torch.cuda.Stream(device=cur.device))
+    outs = [None] * len(fns)
+    for st in side[:len(fns) - 1]:
+        st.wait_stream(cur)
+    for i, f in enumerate(fns[1:]):
+        with torch.cuda.stream(side[i]):
+            outs[i + 1] = f()
+    outs[0] = fns[0]()
+    for st in side[:len(fns) - 1]:
+        cur.wait_stream(st)
+    return outs
+
+
 def _conv_bn(cin, cout, k, stride=1, padding=0):
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill
@@ -214,15 +247,20 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         c1, c2 = _plain_conv(self.conv1), _plain_conv(self.conv2)
-        if c1 is not None and c1.bias is not None and c2 is not None and c2.bias is not None and wino_eligible(c2, x):
-            y = F.conv2d(x, c1.weight, None, c1.stride, c1.padding)                       # conv1 without its bias (MIOpen, NCHW)
-            out = wino_conv_nchw(c2, y, relu=True, pre_bias=c1.bias, pre_relu=True)       # its bias + ReLU, then conv2 + bias + ReLU
-        else:
-            out = conv_bias_act(self.conv1, x, relu=True)
-            out = conv_bias_act(self.conv2, out, relu=True)
+
+        def main():
+            if c1 is not None and c1.bias is not None and c2 is not None and c2.bias is not None and wino_eligible(c2, x):
+                y = F.conv2d(x, c1.weight, None, c1.stride, c1.padding)                   # conv1 without its bias (MIOpen, NCHW)
+                return wino_conv_nchw(c2, y, relu=True, pre_bias=c1.bias, pre_relu=True)  # its bias + ReLU, then conv2 + bias + ReLU
+            return conv_bias_act(self.conv2, conv_bias_act(self.conv1, x, relu=True), relu=True)
+
         if self.shortcut is None:
-            return conv_bias_act(self.conv3, out, relu=True, residual=x)
-        return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x)
+            return conv_bias_act(self.conv3, main(), relu=True, residual=x)
+        rconv = _plain_conv(self.shortcut)
+        if rconv is None or rconv.bias is None or not (FUSE_CONV_TAIL and x.is_cuda and x.dtype == torch.float32):
+            return conv_bias_act(self.conv3, main(), relu=True, residual_module=self.shortcut, residual_input=x)
+        out, raw = branches([main, lambda: shortcut_raw(rconv, x)])                       # (parallel graph branches when captured)
+        return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x, residual_raw=raw)
 
 
 class ResNet50(nn.Module):
@@ -269,9 +307,12 @@ class FPN(nn.Module):
         l5 = self.lateral[2](c5)
         l4 = self.lateral[1](c4) + F.interpolate(l5, size=c4.shape[-2:], mode="nearest")
         l3 = self.lateral[0](c3) + F.interpolate(l4, size=c3.shape[-2:], mode="nearest")
-        p3, p4, p5 = (wino_conv_nchw(m, l, relu=False) if wino_eligible(m, l) else m(l) for m, l in zip(self.output, (l3, l4, l5)))
-        p6 = self.p6(c5)
-        p7 = self.p7(F.relu(p6))
+        out = lambda m, l: (lambda: wino_conv_nchw(m, l, relu=False) if wino_eligible(m, l) else m(l))
+
+        def top():
+            p6 = self.p6(c5)
+            return p6, self.p7(F.relu(p6))
+        p3, p4, p5, (p6, p7) = branches([out(self.output[0], l3), out(self.output[1], l4), out(self.output[2], l5), top])
         return [p3, p4, p5, p6, p7]
 
 
@@ -457,8 +498,8 @@ class ProbabilisticRetinaNetHead(nn.Module):
             # every conv of the head on pod_wino_conv3x3: one launch per layer over all levels and all runs
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
             x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
-            tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
-            tb, nb = self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)
+            (tc, nc), (tb, nb) = branches([lambda: self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout),
+                                           lambda: self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)])
             if dropout:
                 logits = self._predict_all_levels(self.cls_score, tc, levels, nc, 0, m, n)
                 deltas = self._predict_all_levels(self.bbox_pred, tb, levels, nb, 0, n, n)
@@ -468,12 +509,10 @@ class ProbabilisticRetinaNetHead(nn.Module):
                     delta_covs = self._predict_all_levels(self.bbox_cov, tb, levels, nb, n, m, n)
             else:
                 ex = (lambda ts: [t.expand(n, -1, -1, -1).contiguous() for t in ts]) if n > 1 else (lambda ts: ts)
-                logits = ex(self._predict_all_levels(self.cls_score, tc, levels, 1, 0, 1, 1))
-                deltas = ex(self._predict_all_levels(self.bbox_pred, tb, levels, 1, 0, 1, 1))
-                if self.compute_cls_var:
-                    logit_vars = ex(self._predict_all_levels(self.cls_var, tc, levels, 1, 0, 1, 1))
-                if self.compute_bbox_cov:
-                    delta_covs = ex(self._predict_all_levels(self.bbox_cov, tb, levels, 1, 0, 1, 1))
+                pred = lambda conv, buf: (lambda: None if conv is None else ex(self._predict_all_levels(conv, buf, levels, 1, 0, 1, 1)))
+                logits, deltas, logit_vars, delta_covs = branches([pred(self.cls_score, tc), pred(self.bbox_pred, tb),
+                                                                   pred(self.cls_var if self.compute_cls_var else None, tc),
+                                                                   pred(self.bbox_cov if self.compute_bbox_cov else None, tb)])
             return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
         for level, f in enumerate(features):
             tc = self._trunk(self.cls_subnet, f, cls_copies, dropout, level)
