@@ -206,13 +206,18 @@ def wino_conv_nchw(conv: nn.Conv2d, x: torch.Tensor, relu: bool, pre_bias: Optio
 _SIDE_STREAMS: Dict[Tuple[int, int], List["torch.cuda.Stream"]] = {}
 
 
-def branches(fns):
-    """Runs independent pieces of a forward.  Eagerly: one after the other on the current stream.  While the forward is being CAPTURED
-    into a HIP graph: each on its own stream, forked from and joined back into the capturing stream -- the graph then holds them as
-    parallel branches, and launches that fill a fraction of the chip (a single-run head layer is 372 workgroups for 256 CUs, a
-    predictor 93, an FPN output conv of p5 24) run side by side instead of one after the other.  (Capture only: there every tensor
-    comes from the graph's private pool, so memory handed from a side stream to the main one needs no `record_stream`.)"""
-    if len(fns) < 2 or not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+BRANCHES = set(x for x in __import__("os").environ.get("POD_GRAPH_BRANCHES", "").split(",") if x)    # which forks are taken: head, pred, fpn, shortcut
+
+
+def branches(fns, kind=""):
+    """Runs independent pieces of a forward: one after the other on the current stream -- or, for the kinds named in
+    POD_GRAPH_BRANCHES and while the forward is being CAPTURED into a HIP graph, each on its own stream, forked from and joined back
+    into the capturing stream, so that the graph holds them as parallel branches (a single-run head layer is 372 workgroups for 256
+    CUs, a predictor 93, an FPN output conv of p5 24: side by side they would fill the chip).  MEASURED (round 4, cfg2, images/s): no
+    branches 398; cls / bbox trunks 393; the four predictors 241; FPN output convs 277; bottleneck shortcuts 351 -- and 1.0 - 1.6 ms
+    of host time per replay instead of 0.13: ROCm's graph executor pays more for every fork / join than the idle CUs were worth.
+    Off by default; kept as the switch that reproduces the measurement."""
+    if len(fns) < 2 or kind not in BRANCHES or not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
         return [f() for f in fns]
     cur = torch.cuda.current_stream()
     key = (cur.device.index or 0, cur.cuda_stream)
@@ -259,7 +264,7 @@ class Bottleneck(nn.Module):
         rconv = _plain_conv(self.shortcut)
         if rconv is None or rconv.bias is None or not (FUSE_CONV_TAIL and x.is_cuda and x.dtype == torch.float32):
             return conv_bias_act(self.conv3, main(), relu=True, residual_module=self.shortcut, residual_input=x)
-        out, raw = branches([main, lambda: shortcut_raw(rconv, x)])                       # (parallel graph branches when captured)
+        out, raw = branches([main, lambda: shortcut_raw(rconv, x)], "shortcut")           # (parallel graph branches when captured)
         return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x, residual_raw=raw)
 
 
@@ -312,7 +317,7 @@ class FPN(nn.Module):
         def top():
             p6 = self.p6(c5)
             return p6, self.p7(F.relu(p6))
-        p3, p4, p5, (p6, p7) = branches([out(self.output[0], l3), out(self.output[1], l4), out(self.output[2], l5), top])
+        p3, p4, p5, (p6, p7) = branches([out(self.output[0], l3), out(self.output[1], l4), out(self.output[2], l5), top], "fpn")
         return [p3, p4, p5, p6, p7]
 
 
@@ -499,7 +504,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
             x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
             (tc, nc), (tb, nb) = branches([lambda: self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout),
-                                           lambda: self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)])
+                                           lambda: self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)], "head")
             if dropout:
                 logits = self._predict_all_levels(self.cls_score, tc, levels, nc, 0, m, n)
                 deltas = self._predict_all_levels(self.bbox_pred, tb, levels, nb, 0, n, n)
@@ -512,7 +517,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
                 pred = lambda conv, buf: (lambda: None if conv is None else ex(self._predict_all_levels(conv, buf, levels, 1, 0, 1, 1)))
                 logits, deltas, logit_vars, delta_covs = branches([pred(self.cls_score, tc), pred(self.bbox_pred, tb),
                                                                    pred(self.cls_var if self.compute_cls_var else None, tc),
-                                                                   pred(self.bbox_cov if self.compute_bbox_cov else None, tb)])
+                                                                   pred(self.bbox_cov if self.compute_bbox_cov else None, tb)], "pred")
             return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
         for level, f in enumerate(features):
             tc = self._trunk(self.cls_subnet, f, cls_copies, dropout, level)
