@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 5
+#define POD_ABI_VERSION 6
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -351,6 +351,15 @@ int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, in
 int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                            int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                            pod_stream_t stream);
+/* Small maps (round 4): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  pod_wino_conv3x3_split_partial
+ * cuts the INPUT channels into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): `partials` receives
+ * n_splits channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart (K = round_up(real K, 64));
+ * pod_wino_reduce adds them in a fixed order, applies bias (K values, zero-padded) + ReLU and writes the k_real planes of ONE NCHW
+ * image (HW = out_pixels).  Replaces the same reference lines as pod_wino_conv3x3 (detectron2 BottleneckBlock.conv2, FPN.output_convs). */
+int pod_wino_conv3x3_split_partial(const float* in, float* partials, const void* Us, const int32_t* blocks, int32_t n_blocks, int32_t C,
+                                   int32_t K, int32_t n_splits, int64_t split_stride, pod_stream_t stream);
+int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
+                    int32_t K, int32_t k_real, int32_t relu, pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

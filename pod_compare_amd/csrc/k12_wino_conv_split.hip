@@ -87,10 +87,12 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         mini_pidx[r] = py < 18 && pi < 20 && px < 18 ? py * 18 + px : 324;
     }
     // the filter operands of the first position of chunk 0 do not depend on the block record either: asked for now
-    const int nchunk = P.C >> 4;                                          // chunks of 16 input channels (one bf16 MFMA k-step)
+    const int nchunk_all = P.C >> 4;                                      // chunks of 16 input channels (one bf16 MFMA k-step)
+    const int nchunk = P.c_split ? P.c_split : nchunk_all;                // ... of which this workgroup set (blockIdx.y) accumulates its own range
+    const int chunk0 = (int)blockIdx.y * nchunk;
     const int i32 = lane & 31, h = lane >> 5;
     const int a = __builtin_amdgcn_readfirstlane(wave);
-    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(P.U) + ((int64_t)ks * nchunk) * WINO_US_BYTES), 0,
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(P.U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
                                                           nchunk * WINO_US_BYTES, 0x00020000);
     const int u_off = (a * 6 * 6 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*3 + split) KB, + chunk * 144 KB
     vu32x4 uP[3][6];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
@@ -158,8 +160,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     uint32_t amini[2];                                                    // LDS byte address in mini stage h (the lane's 8 channels of chunk 0): [row0 / row1]; + 16: second half
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + h * 12288 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32;
-    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride), 0,
-                                                          n_img * HWi * P.in_stride * 4, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride + chunk0 * 16), 0,
+                                                          n_img * HWi * P.in_stride * 4 - chunk0 * 64, 0x00020000);
     // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
     // (grid row, row inside the image), canvas column -> (grid column, column) -- and parks its pixel index (-1: outside every image:
     // the loads then use a buffer offset that reads 0.0) in LDS; the lanes look their pieces up there: two divisions per thread
@@ -521,6 +523,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     return;
 #endif
     constexpr int ZA = 32 * TS;                // floats per position row a
+    float* const out_base = P.out + (int64_t)blockIdx.y * P.split_out_stride;
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            float* plane = P.out + (int64_t)kg * HWi;
+            float* plane = out_base + (int64_t)kg * HWi;
             if (vec) {
                 *reinterpret_cast<f32x4*>(plane + px0[0]) = v;
             } else {
@@ -605,8 +608,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 v1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
                 v1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
             }
-            *reinterpret_cast<f32x4*>(P.out + e) = v0;
-            *reinterpret_cast<f32x4*>(P.out + e + 4) = v1;
+            *reinterpret_cast<f32x4*>(out_base + e) = v0;
+            *reinterpret_cast<f32x4*>(out_base + e + 4) = v1;
         }
     }
 #ifdef POD_TRACE
@@ -644,6 +647,18 @@ extern "C" int pod_wino_filter_transform_split(const float* weight, void* Us, in
     return POD_OK;
 }
 
+static int wino_split_prepare() {        // the kernel's dynamic LDS size, once per device
+    static std::once_flag once[64];
+    static hipError_t attr[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
+    std::call_once(once[dev], [dev] {
+        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        pod::WINO_LDS_BYTES);
+    });
+    return attr[dev] == hipSuccess ? POD_OK : POD_E_LAUNCH;
+}
+
 extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                       int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                                       pod_stream_t stream) {
@@ -656,24 +671,42 @@ extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* U
           reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
         return POD_E_INVALID;
     if (n_blocks == 0) return POD_OK;
-    static std::once_flag once[64];
-    static hipError_t attr[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return POD_E_LAUNCH;
-    std::call_once(once[dev], [dev] {
-        attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(pod::k_wino_conv3x3_split), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        pod::WINO_LDS_BYTES);
-    });
-    if (attr[dev] != hipSuccess) return POD_E_LAUNCH;
+    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
     pod::WinoParams P;
     P.in = in; P.out = out; P.U = reinterpret_cast<const float*>(Us); P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
+    P.c_split = 0; P.split_out_stride = 0;
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+// The same convolution with the input channels cut into n_splits ranges, one workgroup set each: `partials` receives n_splits
+// channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart; pod_wino_reduce finishes them.
+extern "C" int pod_wino_conv3x3_split_partial(const float* in, float* partials, const void* Us, const int32_t* blocks, int32_t n_blocks, int32_t C,
+                                              int32_t K, int32_t n_splits, int64_t split_stride, pod_stream_t stream) {
+    if (!in || !partials || in == partials || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0) return POD_E_INVALID;
+    if (n_splits < 1 || n_splits > 16 || (C / 16) % n_splits != 0 || ((C / 16 / n_splits) & 1) != 0 || split_stride < 0 || (split_stride & 3) != 0)
+        return POD_E_INVALID;                                   // whole 32-channel super-chunks (full 128-byte lines) per split
+    const int32_t KS = K / 64;
+    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(Us) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
+        return POD_E_INVALID;
+    if (n_blocks == 0) return POD_OK;
+    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
+    pod::WinoParams P;
+    P.in = in; P.out = partials; P.U = reinterpret_cast<const float*>(Us); P.bias = nullptr; P.blocks = reinterpret_cast<const int4*>(blocks);
+    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = 0; P.k_planes = 0;
+    P.thresh = 0; P.scale = 1.0f; P.seed = 0; P.offset = 0;
+    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride;
+    const int64_t grid = pod::wino_grid(KS, n_blocks);
+    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -357,8 +357,7 @@ extern "C" int pod_merge_score_fused(const PodConfig* cfg, const PodLevel* level
         P.chunks[l] = (int32_t)((HW + 64 * CPL - 1) / (64 * CPL));
         P.unit_begin[l] = ub;
         ub += A * P.chunks[l];
-        const uintptr_t am = 4 * CPL - 1;
-        auto al = [am](const void* p) { return (reinterpret_cast<uintptr_t>(p) & am) == 0; };
+        auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(4 * CPL - 1)) == 0; };
         P.vec[l] = (HW % CPL == 0) && al(lv.cls) && (lv.run_stride_cls % CPL == 0) && (!cfg->has_cls_var || al(lv.cls_var)) &&
                    ((int64_t)lv.anchor_base * K % CPL == 0) && al(mean_cls) && al(mean_cls_var);
     }

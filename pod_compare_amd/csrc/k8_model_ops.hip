@@ -182,6 +182,55 @@ __global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restric
     }
 }
 
+// pod_wino_reduce: finishes a convolution that pod_wino_conv3x3_split_partial cut over its input channels -- the n_splits channels-last
+// partial sums (pixels, Kpad) are added in a FIXED order (split 0 first: the result does not depend on scheduling), bias and ReLU
+// applied, and the K real channels written as NCHW planes of one image (HW = pixels): what the consumer of a backbone convolution
+// reads.  64 (pixels) x 64 (channels) tiles through LDS: 16-byte loads along the channels, 16-byte stores along H*W.
+__global__ void __launch_bounds__(256) k_wino_reduce(const float* __restrict__ partials, int32_t n_splits, int64_t split_stride, const float* __restrict__ bias,
+                                                     float* __restrict__ planes, int64_t HW, int32_t Kpad, int32_t K, int32_t relu, int32_t tiles_c) {
+    __shared__ float tile[64][65];   // [pixel][channel], padded
+    const int tid = threadIdx.x;
+    const int tc = (int)(blockIdx.x % tiles_c);
+    const int64_t hw0 = (int64_t)(blockIdx.x / tiles_c) * 64;
+    const int c0 = tc * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4;
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (hw0 + r < HW && c0 + c4 < Kpad) {
+            const float* src = partials + (hw0 + r) * Kpad + c0 + c4;
+            v = *reinterpret_cast<const float4*>(src);
+            for (int s = 1; s < n_splits; ++s) {
+                const float4 w = *reinterpret_cast<const float4*>(src + (int64_t)s * split_stride);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (bias) {                                   // (Kpad values: the caller's bias is padded with zeros)
+                const float4 b = *reinterpret_cast<const float4*>(bias + c0 + c4);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+        }
+        tile[r][c4 + 0] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    const bool vec = (HW & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (tid >> 4) + 16 * it, h4 = (tid & 15) * 4;
+        if (c0 + c >= K || hw0 + h4 >= HW) continue;
+        float* dst = planes + (int64_t)(c0 + c) * HW + hw0 + h4;
+        if (vec) {
+            *reinterpret_cast<float4*>(dst) = float4{tile[h4 + 0][c], tile[h4 + 1][c], tile[h4 + 2][c], tile[h4 + 3][c]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (hw0 + h4 + j < HW) dst[j] = tile[h4 + j][c];
+        }
+    }
+}
+
 // pod_bias_act_to_nhwc: the reverse trip, for a conv whose CONSUMER is pod_wino_conv3x3 (channels-last input): the bias + ReLU pass
 // that follows an NCHW (MIOpen) conv anyway writes [pixel][C] instead of planes.  64 (cells) x 64 (channels) tiles through LDS:
 // 16-byte loads along H*W (scalar when H*W % 4 != 0), 16-byte stores along C.
@@ -260,6 +309,18 @@ extern "C" int pod_bias_act_to_nchw(const float* src, float* dst, const float* b
     const uint32_t thresh = POD_DROPOUT_THRESH16(p);
     hipLaunchKernelGGL(pod::k_bias_act_to_nchw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, bias, C, HW, relu, thresh,
                        1.0f / (1.0f - p), seed, offset, (int32_t)tiles_hw, (int32_t)tiles_c);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
+                               int32_t Kpad, int32_t K, int32_t relu, pod_stream_t stream) {
+    if (!partials || !planes || n_splits < 1 || n_splits > 16 || HW < 1 || Kpad < 4 || (Kpad & 3) != 0 || K < 1 || K > Kpad) return POD_E_INVALID;
+    if (n_splits > 1 && (split_stride < HW * Kpad || (split_stride & 3) != 0)) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(bias)) & 15u) != 0) return POD_E_INVALID;
+    const int64_t tiles_hw = (HW + 63) / 64, tiles_c = (K + 63) / 64;
+    hipLaunchKernelGGL(pod::k_wino_reduce, dim3((unsigned)(tiles_hw * tiles_c)), dim3(256), 0, (hipStream_t)stream, partials, n_splits, split_stride, bias,
+                       planes, HW, Kpad, K, relu, (int32_t)tiles_c);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -58,6 +58,11 @@ struct WinoParams {
     uint32_t thresh;
     float scale;
     uint64_t seed, offset;
+    // split over the input channels (pod_wino_conv3x3_split only; small maps: a res5 convolution is 48 workgroups of 32 chunks each):
+    // grid.y = C / (16 c_split) workgroup sets, set z accumulates chunks [z c_split, (z + 1) c_split) and stores its partial sums at
+    // out + z split_out_stride (channels-last, no bias / ReLU / dropout); pod_wino_reduce adds the partials in a fixed order.  0: no split.
+    int32_t c_split;
+    int64_t split_out_stride;
 };
 
 

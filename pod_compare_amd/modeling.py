@@ -199,7 +199,7 @@ def wino_conv_nchw(conv: nn.Conv2d, x: torch.Tensor, relu: bool, pre_bias: Optio
     hip.check(hip.load().pod_bias_act_to_nhwc(x.contiguous().data_ptr(), a.data_ptr(), hip.ptr(pre_bias), 1, C, H * W, 1 if pre_relu else 0,
                                               hip.current_stream()), "pod_bias_act_to_nhwc")
     out = torch.empty((1, conv.out_channels, H, W), dtype=x.dtype, device=x.device)
-    wino_of(conv)(a, out.view(-1), block_table([(H, W)], 1, x.device), relu=relu, planes=True)
+    wino_of(conv).planes_of_one_image(a, out.view(-1), block_table([(H, W)], 1, x.device), relu=relu)     # (small maps: split over C)
     return out
 
 

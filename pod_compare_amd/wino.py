@@ -142,3 +142,30 @@ class WinoConv:
                      table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
                      seed, offset, hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
         return dst
+
+    def splits_for(self, n_blocks: int, cus: int = 256) -> int:
+        """How many ways to cut the input channels of a launch of n_blocks output blocks (pod_wino_conv3x3_split_partial): small maps
+        give this tiling too few workgroups for the chip (res5 of a 768 x 1344 frame: 6 blocks x 8 filter slices = 48), each walking all
+        C / 16 chunks; cutting C makes n_splits x as many workgroups of 1 / n_splits the chunks.  1 = no split."""
+        if not self.split:
+            return 1
+        wgs, nchunk, s = n_blocks * (self.Kpad // 64), self.C // 16, 1
+        while s < 4 and wgs * s * 2 <= cus and nchunk % (s * 2) == 0 and (nchunk // (s * 2)) % 2 == 0 and nchunk // (s * 2) >= 4:
+            s *= 2
+        return s
+
+    def planes_of_one_image(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, relu: bool = False, n_splits: Optional[int] = None) -> torch.Tensor:
+        """conv + bias (+ ReLU) of ONE image (src (H*W, C) channels-last) as NCHW planes (dst: K x H*W floats), cutting the input channels
+        over workgroup sets when the map is small (`splits_for`); partial sums are added in a fixed order (pod_wino_reduce)."""
+        s = self.splits_for(int(table.shape[0])) if n_splits is None else int(n_splits)
+        if s <= 1:
+            return self(src, dst, table, relu=relu, planes=True)
+        hw = int(src.shape[0])
+        partials = torch.empty((s, hw, self.Kpad), dtype=torch.float32, device=src.device)
+        lib = hip.load()
+        hip.check(lib.pod_wino_conv3x3_split_partial(src.data_ptr(), partials.data_ptr(), self.U.data_ptr(), table.data_ptr(), table.shape[0], self.C, self.Kpad,
+                                                     s, hw * self.Kpad, hip.current_stream()), "pod_wino_conv3x3_split_partial")
+        hip.check(lib.pod_wino_reduce(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), dst.data_ptr(), hw, self.Kpad, self.K, 1 if relu else 0,
+                                      hip.current_stream()), "pod_wino_reduce")
+        return dst
+

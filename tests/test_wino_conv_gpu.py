@@ -216,6 +216,35 @@ def test_dropout_mask_is_the_one_pod_bias_act_draws(split):
     assert 0.5 < dropped < 0.8                                  # ReLU zeroes half, dropout 30 % of the rest
 
 
+@pytest.mark.parametrize("H,W,C,K,splits", [(24, 42, 512, 512, 4), (48, 84, 256, 256, 2), (24, 42, 256, 256, 4), (6, 11, 128, 64, 2), (13, 17, 64, 36, 2)])
+def test_small_maps_split_over_the_input_channels(H, W, C, K, splits):
+    """pod_wino_conv3x3_split_partial + pod_wino_reduce (backbone convolutions on small maps: res4 / res5 / p4 / p5): the input channels
+    cut into ranges, one workgroup set each, partial sums added in a fixed order.  Equal to conv2d within the kernel's usual bound,
+    equal to the unsplit launch to rounding, bit-reproducible, and the policy picks a split for the shapes it was made for."""
+    g = torch.Generator(device="cuda").manual_seed(H * W + C)
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    x = torch.randn(1, C, H, W, device="cuda", generator=g).relu()
+    conv = WinoConv(w, b, split=True)
+    src = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    table = block_table([(H, W)], 1, "cuda")
+    want = F.conv2d(x, w, b, padding=1).relu()
+    outs = []
+    for s in (1, splits, splits):
+        dst = torch.full((K * H * W,), float("nan"), device="cuda")
+        conv.planes_of_one_image(src, dst, table, relu=True, n_splits=s)
+        outs.append(dst.view(1, K, H, W))
+        assert float((outs[-1] - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[1], outs[2])
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * max(1.0, float(want.abs().max()))
+    if (H, W, C, K) == (24, 42, 512, 512):
+        assert conv.splits_for(int(table.shape[0])) == 4          # res5 of the benchmark frame: 48 workgroups -> 192
+    if (H, W, C, K) == (48, 84, 256, 256):
+        assert conv.splits_for(int(table.shape[0])) == 2          # res4 / p4: 72 -> 144
+    assert WinoConv(w, b, split=False).splits_for(int(table.shape[0])) == 1
+    assert hip.load().pod_wino_conv3x3_split_partial(src.data_ptr(), src.data_ptr(), conv.U.data_ptr(), table.data_ptr(), 1, C, conv.Kpad, 3, 0, hip.current_stream()) == -1
+
+
 def test_invalid_arguments_are_rejected():
     lib = hip.load()
     x = torch.zeros(256, 8, device="cuda")
