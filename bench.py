@@ -143,7 +143,24 @@ def conv_census(model, img, N, quirk, dev):
     from pod_compare_amd import wino
     real_wino = wino.WinoConv.__call__
 
+    real_planes = wino.WinoConv.planes_of_one_image
+    inside = [False]
+
+    def probe_planes(self, src, dst, table, **kw):      # a backbone / FPN convolution: one launch, or (small maps) split launch + reduce
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        inside[0] = True
+        try:
+            y = real_planes(self, src, dst, table, **kw)
+        finally:
+            inside[0] = False
+        e1.record()
+        calls.append(("3x3_backbone_fpn_winograd_hip", 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))
+        return y
+
     def probe_wino(self, src, dst, table, **kw):
+        if inside[0]:
+            return real_wino(self, src, dst, table, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = real_wino(self, src, dst, table, **kw)
@@ -156,6 +173,7 @@ def conv_census(model, img, N, quirk, dev):
     reps = 3
     F.conv2d = probe
     wino.WinoConv.__call__ = probe_wino
+    wino.WinoConv.planes_of_one_image = probe_planes
     try:
         with torch.no_grad():
             for _ in range(reps):
@@ -164,6 +182,7 @@ def conv_census(model, img, N, quirk, dev):
     finally:
         F.conv2d = real
         wino.WinoConv.__call__ = real_wino
+        wino.WinoConv.planes_of_one_image = real_planes
     out = {}
     for cat, flops, e0, e1 in calls:
         d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
@@ -657,7 +676,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
         bb = census.get("3x3_backbone_fpn_winograd_hip")
         if bb:      # the bottlenecks' and the FPN's 3x3 / stride-1 convolutions on pod_wino_conv3x3: one NCHW feature map per launch
             out["roofline_backbone"] = {"kernel": "pod_wino_conv3x3 on the backbone's and the FPN's 3x3 / stride-1 convolutions (%d launches per image, "
-                                                  "one feature map each, batch 1: 24-1008 workgroups)" % bb["calls"],
+                                                  "one feature map each, batch 1: 24-1008 workgroups; small maps cut over their input channels: pod_wino_conv3x3_split_partial + pod_wino_reduce)" % bb["calls"],
                                         "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF,
                                         "achieved": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0),
                                         "frac": bb["mfma_tflops_executed"] * (6.0 if args.split_bf16 else 1.0) / (BF16_MFMA_PEAK_TF if args.split_bf16 else FP32_MFMA_PEAK_TF),
