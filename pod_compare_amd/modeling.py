@@ -602,7 +602,8 @@ class ProbabilisticRetinaNet(nn.Module):
     # (stream, shape, flags) -- on the same stream, so a consumer enqueued there before that is safe.
     def enable_graphs(self, on: bool = True) -> "ProbabilisticRetinaNet":
         self.use_graphs = bool(on)
-        if not on:
+        if not on and self._graphs:
+            torch.cuda.synchronize(self.device)          # (a consumer of a graph's tensors may still be queued)
             self._graphs.clear()
         return self
 
