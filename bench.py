@@ -92,7 +92,7 @@ def parse_args():
                          "(`fp32_mfma` / `split_bf16`)")
     ap.add_argument("--split-bf16", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of the model forward from Python instead of replaying a HIP graph "
-                                                             "per (stream, shape) (graphs are used for forwards without active dropout only)")
+                                                             "per (stream, shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the K1 / conv / NLL / worst-case legs after the timed region")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
@@ -495,7 +495,7 @@ def main():
                                      "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
                                      "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
                    "rng": "in-kernel Philox4x32-10, fresh key per image",
-                   "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not mc and not args.no_cnn) else "eager launches from Python"},
+                   "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not args.no_cnn) else "eager launches from Python"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "host_loop_ms_per_image": host_loop_ms,
         "mean_detections": n_det_mean,

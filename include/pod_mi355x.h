@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 6
+#define POD_ABI_VERSION 7
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -315,9 +315,11 @@ int pod_bias_act_to_nhwc(const float* src, float* dst, const float* bias, int64_
 /* ---- conv-net side: broadcast + dropout -------------------------------------------------------------
  * Replaces: feeding the SAME first-conv activation to every MC run's `nn.Dropout(p)` (PR:104-106 replicates the feature
  * lists N times; PR:403-424).  dst[c][i] = dropout(src[i], p), c < copies, independent masks; n % 4 == 0, flat arrays
- * (any memory format shared by src and each copy). */
+ * (any memory format shared by src and each copy).  * epoch (pod_expand_dropout, pod_wino_conv3x3, pod_wino_conv3x3_split; ABI 7): NULL, or a device word: the Philox key of the masks is then
+ * seed ^ (*epoch * 0x9E3779B97F4A7C15).  seed and offset are launch arguments -- constants of a launch captured in a HIP graph -- so a
+ * replayed MC-dropout forward bumps this word (one captured add at the start of the forward) to draw fresh masks for every image. */
 int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, float p, uint64_t seed, uint64_t offset,
-                       pod_stream_t stream);
+                       const uint64_t* epoch, pod_stream_t stream);
 
 /* ---- conv-net side: the head subnets' 3x3 convolutions -------------------------------------------------
  * Replaces: the `nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(), nn.Dropout(p)` triples of cls_subnet / bbox_subnet
@@ -341,7 +343,7 @@ int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, 
 int pod_wino_filter_transform(const float* weight, float* U, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                     pod_stream_t stream);
+                     const uint64_t* epoch, pod_stream_t stream);
 
 /* The same convolution with every fp32 product formed on the BF16 matrix cores (experimental, opt-in; csrc/k12_wino_conv_split.hip):
  * both operands are split exactly into three bf16 terms and the six significant partial products are accumulated in fp32
@@ -350,7 +352,7 @@ int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* b
 int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                            int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                           pod_stream_t stream);
+                           const uint64_t* epoch, pod_stream_t stream);
 /* Small maps (round 4): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  pod_wino_conv3x3_split_partial
  * cuts the INPUT channels into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): `partials` receives
  * n_splits channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart (K = round_up(real K, 64));

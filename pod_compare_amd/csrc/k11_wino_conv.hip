@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             bias0 = *reinterpret_cast<const f32x4*>(P.bias + kg);
             bias1 = *reinterpret_cast<const f32x4*>(P.bias + kg + 4);
         }
+        const uint64_t drop_key = P.thresh ? dropout_key(P.seed, P.epoch) : 0ull;
         int n;
         const int gx = cell(x0 + ox, Wv, rWv, n);
         const bool col_ok = n < gcols && gx < W;
@@ -468,8 +469,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
             const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
-                const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)P.seed,
-                                               (uint32_t)(P.seed >> 32));
+                const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
+                                               (uint32_t)(drop_key >> 32));
                 v0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
                 v0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
                 v0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
@@ -519,7 +520,7 @@ extern "C" int pod_wino_filter_transform(const float* weight, float* U, int32_t 
 
 extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                 int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                                pod_stream_t stream) {
+                                const uint64_t* epoch, pod_stream_t stream) {
     if (!in || !out || in == out || !U || !blocks || n_blocks < 0 || C < 8 || (C & 7) != 0 || K < 64 || (K & 63) != 0 ||
         !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
         return POD_E_INVALID;
@@ -545,7 +546,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0;
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch;
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);

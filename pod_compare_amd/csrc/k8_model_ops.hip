@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActParams P) {
 // inputs of the second conv in one pass (torch: expand + fused_dropout, which also writes a mask tensor).  Flat arrays:
 // any memory format, as long as src and every dst copy use the same one.
 __global__ void __launch_bounds__(256) k_expand_dropout(const float* __restrict__ src, float* __restrict__ dst, int64_t n4, int32_t copies,
-                                                        uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+                                                        uint32_t thresh, float scale, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ epoch) {
+    seed = dropout_key(seed, epoch);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
@@ -326,7 +327,7 @@ extern "C" int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t 
 }
 
 extern "C" int pod_expand_dropout(const float* src, float* dst, int64_t n, int32_t copies, float p, uint64_t seed, uint64_t offset,
-                                  pod_stream_t stream) {
+                                  const uint64_t* epoch, pod_stream_t stream) {
     if (!src || !dst || n < 0 || (n & 3) != 0 || copies < 1 || !(p >= 0.0f && p < 1.0f)) return POD_E_INVALID;
     if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return POD_E_INVALID;
     if (n == 0) return POD_OK;
@@ -336,7 +337,7 @@ extern "C" int pod_expand_dropout(const float* src, float* dst, int64_t n, int32
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(pod::k_expand_dropout, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n4, copies, thresh, scale,
-                       seed, offset);
+                       seed, offset, epoch);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -61,6 +61,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 // Philox4x32-10 call.  Float4 group g (elements 4g .. 4g+3 of the flat tensor a kernel writes) owns words 2 (g & 1) and
 // 2 (g & 1) + 1 of the call with counter base + (g >> 1); element j of the group keeps its value iff field j -- low / high half
 // of the two words -- is >= thresh16 = (uint32_t)(p * 2^16) (0: no dropout), and is scaled by 1 / (1 - p).
+// Philox key of a dropout launch: `seed`, or with a device-resident epoch word (launches replayed from a HIP graph) seed ^ mix(epoch)
+__device__ __forceinline__ uint64_t dropout_key(uint64_t seed, const uint64_t* epoch) {
+    return epoch ? seed ^ (*epoch * 0x9E3779B97F4A7C15ull) : seed;
+}
+
 __device__ __forceinline__ void dropout_words(uint64_t base, uint64_t g, uint32_t c2, uint32_t stream, uint64_t seed, uint32_t& w0, uint32_t& w1) {
     const uint64_t ctr = base + (g >> 1);
     const u32x4 r = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), c2, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));

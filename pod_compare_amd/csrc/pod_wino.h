@@ -63,6 +63,9 @@ struct WinoParams {
     // out + z split_out_stride (channels-last, no bias / ReLU / dropout); pod_wino_reduce adds the partials in a fixed order.  0: no split.
     int32_t c_split;
     int64_t split_out_stride;
+    // dropout masks of a REPLAYED launch (HIP graph): the Philox key is seed ^ mix(*epoch), epoch a device word the graph itself bumps
+    // at the start of every replay -- seed and offset are launch arguments, i.e. constants of a captured launch.  null: key = seed.
+    const uint64_t* epoch;
 };
 
 

@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 6
+POD_ABI_VERSION = 7
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -109,11 +109,11 @@ def load() -> ctypes.CDLL:
     lib.pod_relu_dropout.argtypes = [P, c_int64, c_float, c_uint64, c_uint64, P]
     lib.pod_bias_act_to_nchw.argtypes = [P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_bias_act_to_nhwc.argtypes = [P, P, P, c_int64, c_int32, c_int64, c_int32, P]
-    lib.pod_expand_dropout.argtypes = [P, P, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
+    lib.pod_expand_dropout.argtypes = [P, P, c_int64, c_int32, c_float, c_uint64, c_uint64, P, P]
     lib.pod_wino_filter_transform.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_wino_conv3x3.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P]
+    lib.pod_wino_conv3x3.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P, P]
     lib.pod_wino_filter_transform_split.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_wino_conv3x3_split.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P]
+    lib.pod_wino_conv3x3_split.argtypes = [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_uint64, P, P]
     lib.pod_wino_conv3x3_split_partial.argtypes = [P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int64, P]
     lib.pod_wino_reduce.argtypes = [P, c_int32, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P]
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]

@@ -336,6 +336,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
         # copy) -> bool keep-mask (C, H, W) that replaces the Philox dropout masks, so that a head evaluation can be held to
         # the reference's `nn.Dropout` on recorded masks (tests/test_head_reference*.py); None in production
         self.dropout_replay = None
+        # device word folded into the Philox key of every dropout mask of the Winograd head path (include/pod_mi355x.h: `epoch`): a
+        # forward replayed from a HIP graph bumps it (the launch arguments seed / offset are constants of a captured launch)
+        self.register_buffer("_epoch", torch.zeros(1, dtype=torch.int64), persistent=False)
         self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims = compute_cls_var, compute_bbox_cov, bbox_cov_dims
         self.cls_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
         self.bbox_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
@@ -388,7 +391,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
                             memory_format=torch.channels_last if (nhwc and not src.is_contiguous()) else torch.contiguous_format)
             self._drop_calls += 1
             hip.check(hip.load().pod_expand_dropout(src.data_ptr(), x.data_ptr(), src.numel(), copies, float(self.dropout_rate),
-                                                    self.dropout_seed, self._drop_calls << 34, hip.current_stream()), "pod_expand_dropout")
+                                                    self.dropout_seed, self._drop_calls << 34, None, hip.current_stream()), "pod_expand_dropout")
         else:
             x = F.dropout(x.expand(copies, -1, -1, -1), self.dropout_rate, training=True)
         for conv in convs[1:]:
@@ -433,7 +436,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
             self._drop_calls += 1
             hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies,
                                              0.0 if replay else float(self.dropout_rate),
-                                             self.dropout_seed, self._drop_calls << 34, hip.current_stream()), "pod_expand_dropout")
+                                             self.dropout_seed, self._drop_calls << 34, self._epoch.data_ptr(), hip.current_stream()), "pod_expand_dropout")
         if replay:
             mask_in_place(a, 0)
         tn = block_table(levels, copies, x0.device)
@@ -441,7 +444,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         for j, conv in enumerate(convs[1:], 1):
             self._drop_calls += 1
             self._wino(conv)(a, b, tn, relu=True, dropout_p=0.0 if replay else self.dropout_rate, seed=self.dropout_seed,
-                             offset=self._drop_calls << 34)
+                             offset=self._drop_calls << 34, epoch=self._epoch)
             if replay:
                 mask_in_place(b, j)
             a, b = b, a
@@ -458,6 +461,12 @@ class ProbabilisticRetinaNetHead(nn.Module):
         table = block_table(levels, count, buf.device, in_copies=buf_copies, in_first=first, out_copies=out_copies)
         self._wino(conv)(buf, out, table, planes=True)
         return [out[offs[i] * K:offs[i + 1] * K].view(out_copies, K, h, w) for i, (h, w) in enumerate(levels)]
+
+    def takes_wino_path(self) -> bool:
+        """Every conv of the head runs on pod_wino_conv3x3[_split] (GPU, fp32, one image): then all its dropout masks take the `_epoch` word."""
+        return (WINO_HEAD and self.fused_relu_dropout and FUSE_CONV_TAIL and self.cls_subnet[0].in_channels % 8 == 0
+                and self.cls_subnet[0].out_channels in (64, 128, 256, 512)
+                and max(c.out_channels for c in (self.cls_score, self.bbox_pred, self.cls_var, self.bbox_cov) if c is not None) <= 512)
 
     def _relu_dropout(self, x: torch.Tensor) -> torch.Tensor:
         """ReLU + Dropout(p) after a subnet conv (PR:403-424).  On the GPU one fused in-place HIP pass
@@ -496,9 +505,8 @@ class ProbabilisticRetinaNetHead(nn.Module):
         logits, deltas, logit_vars, delta_covs = [], [], [], []
         cls_copies = m * (2 if self.compute_cls_var else 1)
         box_copies = n + (m if self.compute_bbox_cov else 0)
-        wino = (WINO_HEAD and self.fused_relu_dropout and FUSE_CONV_TAIL and features[0].is_cuda and features[0].dtype == torch.float32
-                and features[0].shape[0] == 1 and features[0].shape[1] % 8 == 0 and self.cls_subnet[0].out_channels in (64, 128, 256, 512)
-                and max(c.out_channels for c in (self.cls_score, self.bbox_pred, self.cls_var, self.bbox_cov) if c is not None) <= 512)
+        wino = (self.takes_wino_path() and features[0].is_cuda and features[0].dtype == torch.float32 and features[0].shape[0] == 1
+                and features[0].shape[1] == self.cls_subnet[0].in_channels)
         if wino:
             # every conv of the head on pod_wino_conv3x3: one launch per layer over all levels and all runs
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
@@ -594,12 +602,13 @@ class ProbabilisticRetinaNet(nn.Module):
 
     # ---- HIP graphs --------------------------------------------------------------------------------------------------------
     # One image's forward is ~200 launches (MIOpen calls, pod_* kernels, torch element-wise ops) issued from Python: 2.3 - 2.5 ms of
-    # host time, which is the whole step of the single-run configurations (BASELINE configs[1], [3]: 2.75 ms of GPU time).  With
+    # host time, which is the whole step of the single-run configurations (BASELINE configs[1], [3]: 2.5 ms of GPU time).  With
     # `enable_graphs()` the forward of a given (stream, frame shape, flags) is captured once into a HIP graph and replayed: one
-    # host call per image.  Not captured: forwards with active dropout (the Philox counter offsets of the masks are launch
-    # arguments: a replay would repeat the first image's masks; those configurations are 4x further from the host limit) and
-    # anything off the GPU.  The returned tensors belong to the graph: they are valid until the next forward of the same
-    # (stream, shape, flags) -- on the same stream, so a consumer enqueued there before that is safe.
+    # host call per image.  MC-dropout forwards too, when the head runs on the Winograd kernels: their masks' Philox key folds in a
+    # device word (`head._epoch`) that the captured forward itself bumps first thing, so every replay draws fresh masks although
+    # seed / offset are constants of the captured launches.  Not captured: a dropout forward on the MIOpen head path, anything off
+    # the GPU, the parity mode (`dropout_replay`).  The returned tensors belong to the graph: they are valid until the next forward
+    # of the same (stream, shape, flags) -- on the same stream, so a consumer enqueued there before that is safe.
     def enable_graphs(self, on: bool = True) -> "ProbabilisticRetinaNet":
         self.use_graphs = bool(on)
         if not on and self._graphs:
@@ -607,14 +616,14 @@ class ProbabilisticRetinaNet(nn.Module):
             self._graphs.clear()
         return self
 
-    def _forward_graphed(self, image: torch.Tensor, n: int, skip: bool) -> HeadOutputs:
+    def _forward_graphed(self, image: torch.Tensor, n: int, dropout: bool, skip: bool) -> HeadOutputs:
         stream = torch.cuda.current_stream(image.device)
-        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, skip)
+        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = image.clone()
             for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
-                self._forward_eager(static_in, n, False, skip)
+                self._forward_eager(static_in, n, dropout, skip)
             stream.synchronize()
             side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
             side.wait_stream(stream)
@@ -622,7 +631,9 @@ class ProbabilisticRetinaNet(nn.Module):
             # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events must
             # not abort it)
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                out = self._forward_eager(static_in, n, False, skip)
+                if dropout:
+                    self.head._epoch.add_(1)           # (captured: every replay starts by moving on to the next set of masks)
+                out = self._forward_eager(static_in, n, dropout, skip)
             stream.wait_stream(side)
             while len(self._graphs) >= self.max_graphs:          # frames of many different sizes: keep the most recent shapes only
                 torch.cuda.synchronize(image.device)             # (a consumer of the evicted graph's tensors may still be queued)
@@ -647,8 +658,9 @@ class ProbabilisticRetinaNet(nn.Module):
         if mc_dropout is None:
             mc_dropout = n > 1
         dropout = bool(mc_dropout) and self.use_dropout
-        if self.use_graphs and not dropout and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None:
-            return self._forward_graphed(image, n, skip_unused_last_run)
+        if (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
+                and (not dropout or self.head.takes_wino_path())):
+            return self._forward_graphed(image, n, dropout, skip_unused_last_run)
         return self._forward_eager(image, n, dropout, skip_unused_last_run)
 
     def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:

@@ -179,7 +179,7 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     with torch.cuda.device(src.device):
         hip.check(hip.load().pod_wino_conv3x3(hip.ptr(src), hip.ptr(out), hip.ptr(U), hip.ptr(bias), hip.ptr(blocks), int(blocks.shape[0]), C, Kpad,
                                               int(K) if planes else 0, 1 if relu else 0, float(dropout_p), int(seed), int(offset),
-                                              hip.current_stream()), "pod_wino_conv3x3")
+                                              None, hip.current_stream()), "pod_wino_conv3x3")
     return out
 
 

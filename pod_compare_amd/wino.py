@@ -131,16 +131,17 @@ class WinoConv:
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
 
     def __call__(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, relu: bool = False, dropout_p: float = 0.0,
-                 seed: int = 0, offset: int = 0, planes: bool = False) -> torch.Tensor:
+                 seed: int = 0, offset: int = 0, planes: bool = False, epoch: Optional[torch.Tensor] = None) -> torch.Tensor:
         """src: (pixels, C) channels-last.  dst: (pixels, Kpad) channels-last, or with planes=True any contiguous buffer of
-        NCHW images with K (real) planes each, level-major like the table's output side."""
+        NCHW images with K (real) planes each, level-major like the table's output side.  epoch: a device int64 word folded into
+        the dropout masks' Philox key (launches replayed from a HIP graph, include/pod_mi355x.h)."""
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and src.dtype == dst.dtype == torch.float32
         assert planes or dst.shape[-1] == self.Kpad
         assert getattr(table, "pod_channels", 512) >= max(self.C, self.K if planes else self.Kpad), "block_table(channels=...) below this conv's channel count"
         fn = hip.load().pod_wino_conv3x3_split if self.split else hip.load().pod_wino_conv3x3
         hip.check(fn(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
                      table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
-                     seed, offset, hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
+                     seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
         return dst
 
     def splits_for(self, n_blocks: int, cus: int = 256) -> int:

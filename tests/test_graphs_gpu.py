@@ -51,12 +51,36 @@ def test_graph_replay_equals_the_eager_forward_for_every_image_and_stream():
     close(m(other), out)
 
 
-def test_dropout_forwards_are_not_captured():
-    """A replay would repeat the first image's dropout masks (the Philox counter offsets are launch arguments)."""
+def test_mc_dropout_forwards_replay_with_fresh_masks():
+    """A captured MC-dropout forward must not repeat its masks: seed / offset are constants of the captured launches, so the Philox key
+    folds in a device word (head._epoch) that the graph itself bumps at the start of every replay.  Same epoch -> same bits; next
+    epoch -> other masks; and the masks are real dropout (a fifth of the first activation's copies zeroed)."""
     m = build(dropout_rate=0.2).enable_graphs()
     f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda")
-    a = m(f, num_mc_dropout_runs=3)
-    b = m(f, num_mc_dropout_runs=3)
-    assert not m._graphs and not torch.equal(a.cls[0], b.cls[0])
-    m(f)                                                   # dropout off: captured
+    a = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
     assert len(m._graphs) == 1
+    e1 = int(m.head._epoch.item())
+    b = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
+    assert int(m.head._epoch.item()) == e1 + 1 and len(m._graphs) == 1
+    assert not torch.equal(a[0], b[0])                                 # fresh masks
+    assert not torch.equal(b[0][0], b[0][1])                           # and independent ones per run
+    m.head._epoch.fill_(e1 - 1)                                        # the replay bumps it to e1 again
+    c = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
+    # (MIOpen's backbone kernels accumulate with atomics: to rounding, not bit for bit)
+    for x, y in zip(a, c):
+        assert float((x - y).abs().max()) <= 2e-4 * max(1.0, float(y.abs().max()))
+    assert float((a[0] - b[0]).abs().max()) > 1e-3                      # while another epoch moves the outputs visibly
+    m(f)                                                               # the dropout-free forward of the same model: its own graph
+    assert len(m._graphs) == 2
+
+
+def test_parity_mode_and_the_miopen_head_path_are_not_captured():
+    m = build(dropout_rate=0.2).enable_graphs()
+    f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda")
+    old = modeling.WINO_HEAD
+    modeling.WINO_HEAD = False
+    try:
+        m(f, num_mc_dropout_runs=3)                                    # MIOpen head path: its masks' offsets are launch arguments only
+        assert not m._graphs
+    finally:
+        modeling.WINO_HEAD = old

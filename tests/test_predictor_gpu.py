@@ -426,7 +426,7 @@ def test_expand_dropout_statistics_and_independent_copies():
     src = torch.rand(1, 64, 24, 40, device="cuda") + 0.5
     copies, p = 7, 0.2
     dst = torch.empty((copies,) + tuple(src.shape[1:]), device="cuda")
-    hip.check(lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), src.numel(), copies, p, 5, 3 << 34, hip.current_stream()), "expand")
+    hip.check(lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), src.numel(), copies, p, 5, 3 << 34, None, hip.current_stream()), "expand")
     kept = dst != 0
     assert abs(float(kept.float().mean()) - (1 - p)) < 5e-3
     assert torch.allclose(dst[kept], src.expand_as(dst)[kept] / (1 - p), rtol=1e-6, atol=0)
@@ -434,9 +434,9 @@ def test_expand_dropout_statistics_and_independent_copies():
     c = torch.corrcoef(masks)
     assert float((c - torch.eye(copies, device="cuda")).abs().max()) < 0.02          # every copy has its own mask
     again = torch.empty_like(dst)
-    hip.check(lib.pod_expand_dropout(src.data_ptr(), again.data_ptr(), src.numel(), copies, p, 5, 3 << 34, hip.current_stream()), "expand")
+    hip.check(lib.pod_expand_dropout(src.data_ptr(), again.data_ptr(), src.numel(), copies, p, 5, 3 << 34, None, hip.current_stream()), "expand")
     assert torch.equal(dst, again)
-    assert lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), 6, 1, p, 0, 0, hip.current_stream()) == -1   # n % 4 != 0
+    assert lib.pod_expand_dropout(src.data_ptr(), dst.data_ptr(), 6, 1, p, 0, 0, None, hip.current_stream()) == -1   # n % 4 != 0
 
 
 def test_channels_last_trunk_matches_the_nchw_trunk():

@@ -252,15 +252,15 @@ def test_invalid_arguments_are_rejected():
     u = torch.zeros(24 * 64 * 8, device="cuda")
     t = block_table([(16, 16)], 1, "cuda")
     s = hip.current_stream()
-    ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)
+    ok = lib.pod_wino_conv3x3(x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s)
     assert ok == 0
-    for args in ((x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 12, 64, 0, 0, 0.0, 0, 0, s),      # C % 8
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 96, 0, 0, 0.0, 0, 0, s),       # K % 64
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 192, 0, 0, 0.0, 0, 0, s),      # K / 64 not in 1,2,4,8
-                 (x.data_ptr(), x.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s),       # in place
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 63, 0, 0.5, 0, 0, s),      # planes + dropout
-                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 1.0, 0, 0, s),       # p = 1
-                 (x.data_ptr(), y.data_ptr(), None, None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, s)):
+    for args in ((x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 12, 64, 0, 0, 0.0, 0, 0, None, s),      # C % 8
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 96, 0, 0, 0.0, 0, 0, None, s),       # K % 64
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 192, 0, 0, 0.0, 0, 0, None, s),      # K / 64 not in 1,2,4,8
+                 (x.data_ptr(), x.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s),       # in place
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 63, 0, 0.5, 0, 0, None, s),      # planes + dropout
+                 (x.data_ptr(), y.data_ptr(), u.data_ptr(), None, t.data_ptr(), 1, 8, 64, 0, 0, 1.0, 0, 0, None, s),       # p = 1
+                 (x.data_ptr(), y.data_ptr(), None, None, t.data_ptr(), 1, 8, 64, 0, 0, 0.0, 0, 0, None, s)):
         assert lib.pod_wino_conv3x3(*args) == -1
     assert lib.pod_wino_filter_transform(u.data_ptr(), u.data_ptr(), 64, 12, s) == -1
 
