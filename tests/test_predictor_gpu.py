@@ -177,7 +177,7 @@ class Fp64Conv:
         self.K, self.C = int(conv.weight.shape[0]), int(conv.weight.shape[1])
         self.Kpad = (self.K + 63) // 64 * 64
 
-    def __call__(self, src, dst, table, relu=False, dropout_p=0.0, seed=0, offset=0, planes=False):
+    def __call__(self, src, dst, table, relu=False, dropout_p=0.0, seed=0, offset=0, planes=False, epoch=None):   # (epoch: 0 in an eager forward, i.e. the plain seed: the masks pod_bias_act draws below)
         import torch.nn.functional as F
         from pod_compare_amd import hip
         rec = table.cpu().long()
