@@ -35,6 +35,9 @@
 #ifndef POD_K1F_BATCH
 #define POD_K1F_BATCH 2      // runs whose loads are in flight together (CPL < 4): 2 x 2K loads per lane
 #endif
+#ifndef POD_K1F_NT
+#define POD_K1F_NT 1         // non-temporal loads (the runs are read exactly once)
+#endif
 #ifndef POD_K1F_CELLS
 #define POD_K1F_CELLS 1      // consecutive cells of a plane per lane (1, 2 or 4: 4-, 8- or 16-byte loads)
 #endif
@@ -79,7 +82,7 @@ __device__ __forceinline__ K1fVals<CPL> k1f_ld(const float* p, int64_t i, int hw
 #pragma unroll
         for (int j = 0; j < CPL; ++j) r.v[j] = v[j];
     } else if (VEC) {
-        r.v[0] = __builtin_nontemporal_load(p + i);
+        r.v[0] = POD_K1F_NT ? __builtin_nontemporal_load(p + i) : p[i];
     } else {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) r.v[j] = hw0 + j < HW ? p[i + j] : 0.0f;
