@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 7
+#define POD_ABI_VERSION 8
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -394,6 +394,21 @@ int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids,
 /* test support for pod_wino_conv3x3_split's arithmetic contract: the three bf16 terms (bit patterns, terms dev uint16 [3][n]) the kernel
  * forms of each fp32 operand x[i] (dev, n even): x == t0 + t1 + t2 exactly (tests/test_wino_conv_gpu.py). */
 int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t stream);
+
+/* ---- K13 conv1x1_split (round 4): the 1x1 convolutions of the backbone / FPN as a channels-last GEMM ------------------------
+ * Replaces: detectron2 BottleneckBlock.conv1 / conv3 / shortcut (1x1, stride 1 or 2, FrozenBN folded, ReLU, residual add) and
+ * FPN.lateral_convs as `self.backbone(images.tensor)` runs them (probabilistic_retinanet.py:96-100): 39 calls per image that PyTorch-ROCm
+ * executes as fp32 GEMMs + one element-wise pass each.  Same arithmetic contract as pod_wino_conv3x3_split (exact 3 x bf16 splits of
+ * both operands, 6 partial products, fp32 accumulate).
+ *   y[p][k] = act(sum_c x[pin(p)][c] w[k][c] + bias[k] (+ residual[p][k])),  p = oy * W_out + ox,  pin = (stride oy) * W_in + stride ox
+ * x dev (H_in * W_in, Cin), y / residual dev (H_out * W_out, Cout): channels-last.  Cin % 16 == 0, Cout % 64 == 0.
+ * Ws = pod_conv1x1_filter_split(weight (Cout, Cin) fp32): 3 * Cout * Cin bf16 values.
+ * n_splits > 1 (small maps): the input channels cut over workgroup sets, partial sums in `partials` (n_splits * H_out * W_out * Cout
+ * floats), added in a fixed order with bias / residual / ReLU by a second launch. */
+int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
+int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
+                      int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
+                      pod_stream_t stream);
 
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net

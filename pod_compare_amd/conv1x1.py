@@ -1,0 +1,53 @@
+"""Host side of pod_conv1x1_split (csrc/k13_conv1x1_split.hip): the backbone's / FPN's 1x1 convolutions (detectron2 BottleneckBlock conv1 /
+conv3 / shortcut, FPN lateral convs; probabilistic_retinanet.py:96-100 runs them as `self.backbone(images.tensor)`) as a channels-last GEMM
+with every fp32 product formed from exact 3 x bf16 splits on the bf16 matrix cores.  GPU only: there is no CPU path."""
+from typing import Optional
+
+import torch
+
+from . import hip
+
+
+class Conv1x1:
+    """One conv1x1(Cin -> Cout, stride 1 or 2) with its weight split once.  Activations are channels-last (pixels, C) fp32."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1):
+        assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1)
+        self.K, self.C, self.stride = int(weight.shape[0]), int(weight.shape[1]), int(stride)
+        if self.C % 16 or self.K % 64 or self.stride not in (1, 2):
+            raise ValueError("pod_conv1x1_split: Cin %% 16 == 0, Cout %% 64 == 0, stride 1 or 2 required, got Cin=%d Cout=%d stride=%d" % (self.C, self.K, self.stride))
+        self.Ws = torch.empty(3 * self.K * self.C, dtype=torch.int16, device=weight.device)
+        hip.check(hip.load().pod_conv1x1_filter_split(weight.detach().reshape(self.K, self.C).contiguous().data_ptr(), self.Ws.data_ptr(), self.K, self.C,
+                                                      hip.current_stream()), "pod_conv1x1_filter_split")
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().clone()
+
+    @staticmethod
+    def eligible(conv: Optional[torch.nn.Conv2d]) -> bool:
+        return (conv is not None and tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1
+                and tuple(conv.dilation) == (1, 1) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+                and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0)
+
+    def out_hw(self, h: int, w: int):
+        return ((h - 1) // self.stride + 1, (w - 1) // self.stride + 1)
+
+    def splits_for(self, p_out: int, cus: int = 256) -> int:
+        """Cut the input channels over workgroup sets when the map gives the 256-pixel x 128-channel tiling too few workgroups."""
+        wgs = ((p_out + 255) // 256) * (self.K // (128 if self.K % 128 == 0 else 64))
+        nks, s = self.C // 16, 1
+        while s < 8 and wgs * s * 2 <= cus and nks % (s * 2) == 0 and nks // (s * 2) >= 8:
+            s *= 2
+        return s
+
+    def __call__(self, x: torch.Tensor, h: int, w: int, relu: bool = False, residual: Optional[torch.Tensor] = None,
+                 n_splits: Optional[int] = None) -> torch.Tensor:
+        """x: (h * w, Cin) channels-last of ONE image -> (h_out * w_out, Cout) channels-last = act(conv(x) + bias [+ residual])."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
+        ho, wo = self.out_hw(h, w)
+        y = torch.empty((ho * wo, self.K), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            assert residual.is_contiguous() and tuple(residual.shape) == tuple(y.shape) and residual.dtype == torch.float32
+        s = self.splits_for(ho * wo) if n_splits is None else int(n_splits)
+        partials = torch.empty((s, ho * wo, self.K), dtype=torch.float32, device=x.device) if s > 1 else None
+        hip.check(hip.load().pod_conv1x1_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), hip.ptr(residual), ho, wo, h, w, self.stride,
+                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), hip.current_stream()), "pod_conv1x1_split")
+        return y

@@ -1,0 +1,235 @@
+// K13 conv1x1_split -- the 1x1 convolutions of the backbone and the FPN as a channels-last GEMM on the bf16 matrix cores.
+//
+// Replaces (reference: detectron2's ResNet / FPN as probabilistic_retinanet.py:96-100 runs them, `features = self.backbone(images.tensor)`):
+// BottleneckBlock.conv1 / conv3 / shortcut (1x1, stride 1 or 2, FrozenBN folded into weight + bias, ReLU, residual add) and
+// FPN.lateral_convs -- 39 calls per image, 85 GFLOP, which MIOpen runs as fp32 Tensile GEMMs at ~68 TFLOP/s plus one element-wise pass
+// each for bias / residual / ReLU (1.5 ms of a 10.3-ms step once the 3x3 convolutions were off MIOpen).
+//
+//   y[p][k] = act( sum_c x[pin(p)][c] w[k][c] + bias[k] (+ residual[p][k]) ),   x, y, residual channels-last ([pixel][channel])
+//
+// Same arithmetic contract as pod_wino_conv3x3_split (k12): every fp32 product is formed from the EXACT 3-way bf16 splits of both
+// operands (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the weights split once (pod_conv1x1_filter_split),
+// the activations in the loop with the very functions k12 uses (pod_wino.h: wino_bf16_pair / wino_bf16_residual).
+//
+// Mapping.  Workgroup = 4 wavefronts = 256 output pixels x (32 NCB) output channels (NCB = 4, or 2 when Cout % 128 != 0); every
+// wavefront owns 64 pixels x all the workgroup's channels: 2 NCB accumulator blocks of 32 x 32.  The filter is the ROW operand
+// of the MFMAs (a lane's accumulator quad is 4 consecutive output channels of one pixel: 16-byte stores into the channels-last output).
+// No LDS: with both operands K-contiguous a lane's MFMA fragment IS a contiguous piece of memory -- 32 B of one pixel's channels, 16 B
+// of one filter row's pre-split terms -- so fragments are loaded straight into registers, one k-step (16 channels) ahead; the four
+// wavefronts' identical filter loads meet in the CU's L1.  A pixel tile's workgroups (one per channel tile) run on ONE XCD back to back,
+// so the activations come out of that XCD's L2 after the first.  Small maps (res5: 1008 pixels = 4 pixel tiles) cut the input channels
+// over grid.y (partial sums, finished by pod_conv1x1_reduce in a fixed order).
+#include "pod_wino.h"
+
+namespace pod {
+
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+
+struct C1Params {
+    const float* x;
+    float* y;                 // output, or the partial sums of split 0 (split z at + z * split_stride)
+    const uint16_t* Ws;       // pre-split filter: [cout block 32][k-step 16][term 3][h 2][i32 32][8 bf16]
+    const float* bias;
+    const float* residual;
+    int32_t P_out, W_out, W_in, stride, Cin, Cout, relu;
+    int32_t n_pt, n_ct;       // pixel tiles (256), channel tiles (32 NCB)
+    int32_t ks_per_split;     // k-steps (16 channels) a workgroup set accumulates; grid.y sets
+    int64_t split_stride;     // floats between partial outputs; 0: no split (bias / residual / ReLU applied here)
+};
+
+// weight (Cout, Cin) fp32 -> Ws: three nearest-even bf16 terms per value (w = w0 + w1 + w2 exactly), in the order a lane loads them
+__global__ void __launch_bounds__(256) k_conv1x1_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Ws, int32_t Cout, int32_t Cin) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (cout, pair of cins)
+    if (t >= (int64_t)Cout * (Cin / 2)) return;
+    const int k = (int)(t / (Cin / 2)), c = 2 * (int)(t % (Cin / 2));
+    uint32_t terms[3];
+    const WinoSplitSel sel;
+    wino_bf16_split3(w[(int64_t)k * Cin + c], w[(int64_t)k * Cin + c + 1], terms, sel);
+    const int nks = Cin >> 4, cb = k >> 5, i32 = k & 31, ks = c >> 4, h = (c >> 3) & 1, e = c & 7;
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+        uint16_t* d = Ws + ((((int64_t)cb * nks + ks) * 3 + term) * 2 + h) * 256 + i32 * 8 + e;
+        d[0] = (uint16_t)(terms[term] & 0xFFFFu);
+        d[1] = (uint16_t)(terms[term] >> 16);
+    }
+}
+
+template <int NCB>
+__global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i32 = lane & 31, h = lane >> 5;
+    // blockIdx & 7 is the XCD (round-robin dispatch): an XCD takes pixel tiles xcd, xcd + 8, ... and runs all channel tiles of one back to back
+    const int xcd = blockIdx.x & 7, wi = (int)(blockIdx.x >> 3);
+    const int tp = (wi / P.n_ct) * 8 + xcd, tc = wi % P.n_ct;
+    if (tp >= P.n_pt) return;
+    const int nks_all = P.Cin >> 4, ks0 = (int)blockIdx.y * P.ks_per_split, nks = P.ks_per_split;
+    // this lane's two pixels (pb = 0, 1) and where they live in the input (stride-2 convolutions read every second row / column)
+    int pout[2], pin[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int p = tp * 256 + wave * 64 + pb * 32 + i32;
+        pout[pb] = p < P.P_out ? p : -1;
+        const int q = p < P.P_out ? p : 0;
+        if (P.stride == 1) {
+            pin[pb] = q;
+        } else {
+            const int oy = q / P.W_out, ox = q - oy * P.W_out;
+            pin[pb] = (P.stride * oy) * P.W_in + P.stride * ox;
+        }
+    }
+    const float* xa[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) xa[pb] = P.x + (int64_t)pin[pb] * P.Cin + ks0 * 16 + 8 * h;
+    const uint16_t* wa = P.Ws + (((int64_t)(tc * NCB) * nks_all + ks0) * 3 * 2) * 256 + (h * 32 + i32) * 8;     // + cb * nks_all * 1536 + ks * 1536 + term * 512
+    const int64_t w_cb = (int64_t)nks_all * 1536;
+
+    f32x16 acc[NCB][2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 araw[2][2][2];              // [buffer][pb][4-channel half of the lane's 8]
+    c1_u32x4 wf[2][NCB][3];           // [buffer][cb][term]
+    auto load = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            araw[buf][pb][0] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16);
+            araw[buf][pb][1] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16 + 4);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
+    };
+    const WinoSplitSel sel;
+    auto step = [&](auto buf_t, auto first_t) __attribute__((always_inline)) {
+        constexpr int buf = decltype(buf_t)::value;
+        constexpr bool first = decltype(first_t)::value;
+        c1_u32x4 at[2][3];            // the lane's 8 channels of its two pixels as three bf16 terms
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {       // pair i: channels 2 i, 2 i + 1
+                float lo = araw[buf][pb][i >> 1][2 * (i & 1)], hi = araw[buf][pb][i >> 1][2 * (i & 1) + 1];
+                const uint32_t t0 = wino_bf16_pair(lo, hi);
+                wino_bf16_residual(t0, lo, hi, sel);
+                const uint32_t t1 = wino_bf16_pair(lo, hi);
+                wino_bf16_residual(t1, lo, hi, sel);
+                at[pb][0][i] = t0;
+                at[pb][1][i] = t1;
+                at[pb][2][i] = wino_bf16_pair(lo, hi);
+            }
+        // the 6 partial products that matter, small ones first (as k12): w1 x1, w2 x0, w0 x2, w1 x0, w0 x1, w0 x0
+#pragma unroll
+        for (int prod = 0; prod < 6; ++prod) {
+            const int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;
+            const int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    if (first && prod == 0)
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), zero16, 0, 0, 0);
+                    else
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
+                }
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    load(0, 0);
+    if (nks > 1) load(1, 1);
+    step(B0{}, std::true_type{});
+    for (int ks = 1; ks < nks; ks += 2) {       // two k-steps per trip: the buffers alternate at compile time, loads run one k-step ahead
+        if (ks + 1 < nks) load(0, ks + 1);
+        step(B1{}, std::false_type{});
+        if (ks + 1 >= nks) break;
+        if (ks + 2 < nks) load(1, ks + 2);
+        step(B0{}, std::false_type{});
+    }
+
+    // ---- epilogue: a lane's accumulator register r of block (cb, pb) is channel 32 cb + (r & 3) + 8 (r >> 2) + 4 h of pixel 32 pb + i32
+    float* yo = P.y + (int64_t)blockIdx.y * P.split_stride;
+    const bool final_pass = P.split_stride == 0;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        if (pout[pb] < 0) continue;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = (tc * NCB + cb) * 32 + 8 * q + 4 * h;
+                if (k >= P.Cout) continue;
+                f32x4 v = f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
+                const int64_t e = (int64_t)pout[pb] * P.Cout + k;
+                if (final_pass) {
+                    if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + k);
+                    if (P.residual) v += *reinterpret_cast<const f32x4*>(P.residual + e);
+                    if (P.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(yo + e) = v;
+            }
+        }
+    }
+}
+
+// y = act(sum of the partial outputs in order + bias + residual), channels-last, 16 B per lane
+__global__ void __launch_bounds__(256) k_conv1x1_reduce(const float* __restrict__ partials, int32_t n_splits, int64_t split_stride, const float* __restrict__ bias,
+                                                        const float* __restrict__ residual, float* __restrict__ y, int64_t n4, int32_t Cout, int32_t relu) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(partials + 4 * i);
+        for (int s = 1; s < n_splits; ++s) v += *reinterpret_cast<const f32x4*>(partials + (int64_t)s * split_stride + 4 * i);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)((4 * i) % Cout));
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + 4 * i);
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + 4 * i) = v;
+    }
+}
+
+}  // namespace pod
+
+extern "C" int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream) {
+    if (!weight || !Ws || Cout < 32 || (Cout & 31) != 0 || Cin < 16 || (Cin & 15) != 0) return POD_E_INVALID;
+    const int64_t n = (int64_t)Cout * (Cin / 2);
+    hipLaunchKernelGGL(pod::k_conv1x1_filter_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<uint16_t*>(Ws), Cout,
+                       Cin);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out, int32_t H_in,
+                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, pod_stream_t stream) {
+    if (!x || !y || !Ws || x == y || H_out < 1 || W_out < 1 || (stride != 1 && stride != 2) || Cin < 16 || (Cin & 15) != 0 || Cout < 64 || (Cout & 63) != 0)
+        return POD_E_INVALID;
+    if (H_in < (H_out - 1) * stride + 1 || W_in < (W_out - 1) * stride + 1 || (stride == 1 && (H_in != H_out || W_in != W_out))) return POD_E_INVALID;
+    const int64_t P_out = (int64_t)H_out * W_out;
+    if (P_out * (Cout > Cin ? Cout : Cin) >= ((int64_t)1 << 31) || (int64_t)H_in * W_in * Cin >= ((int64_t)1 << 31)) return POD_E_INVALID;
+    const int nks = Cin / 16;
+    if (n_splits < 1 || n_splits > 16 || nks % n_splits != 0 || (n_splits > 1 && !partials)) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias) |
+          reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(partials)) & 15u) != 0)
+        return POD_E_INVALID;
+    pod::C1Params P;
+    P.x = x; P.y = n_splits > 1 ? partials : y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.residual = residual;
+    P.P_out = (int32_t)P_out; P.W_out = W_out; P.W_in = W_in; P.stride = stride; P.Cin = Cin; P.Cout = Cout; P.relu = relu;
+    const int ncb = (Cout % 128 == 0) ? 4 : 2;
+    P.n_pt = (int32_t)((P_out + 255) / 256); P.n_ct = Cout / (32 * ncb);
+    P.ks_per_split = nks / n_splits;
+    P.split_stride = n_splits > 1 ? P_out * Cout : 0;
+    const int64_t grid = 8LL * ((P.n_pt + 7) / 8) * P.n_ct;
+    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    if (ncb == 4) hipLaunchKernelGGL(pod::k_conv1x1_split<4>, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k_conv1x1_split<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    if (n_splits > 1) {
+        const int64_t n4 = P_out * Cout / 4;
+        int64_t blocks = (n4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pod::k_conv1x1_reduce, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, P_out * Cout, bias, residual, y, n4,
+                           Cout, relu);
+        POD_CHECK_LAUNCH();
+    }
+    return POD_OK;
+}

@@ -1,0 +1,80 @@
+"""pod_conv1x1_split (csrc/k13_conv1x1_split.hip): the backbone's / FPN's 1x1 convolutions as a channels-last GEMM with exact 3 x bf16
+split products.  Referees: torch's conv2d on the same tensors, and an fp64 convolution with the per-element bound of the 3x3 kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pod_compare_amd import hip
+from pod_compare_amd.conv1x1 import Conv1x1
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, Cout, H_in, W_in, stride): the shapes of a ResNet-50-FPN on a small frame, ragged pixel counts, both channel tilings
+SHAPES = [(64, 64, 48, 84, 1), (64, 256, 48, 84, 1), (256, 64, 48, 84, 1), (256, 128, 48, 84, 2), (256, 512, 47, 83, 2), (512, 128, 24, 42, 1),
+          (128, 512, 24, 42, 1), (1024, 256, 12, 21, 1), (256, 1024, 12, 21, 1), (2048, 512, 6, 11, 1), (512, 2048, 6, 11, 1), (1024, 2048, 12, 21, 2),
+          (2048, 256, 6, 11, 1), (16, 64, 5, 7, 1), (32, 192, 9, 9, 2)]
+
+
+def make(cin, cout, h, w, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    wt = torch.randn(cout, cin, 1, 1, device="cuda", generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, device="cuda", generator=g)
+    x = torch.randn(1, cin, h, w, device="cuda", generator=g).relu()
+    return wt, b, x
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", SHAPES)
+@pytest.mark.parametrize("residual", [False, True])
+def test_equals_conv2d_and_stays_inside_the_fp32_class(cin, cout, h, w, stride, residual):
+    wt, b, x = make(cin, cout, h, w, cin + cout)
+    conv = Conv1x1(wt, b, stride)
+    ho, wo = conv.out_hw(h, w)
+    xcl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+    res = torch.randn(ho * wo, cout, device="cuda") if residual else None
+    y = conv(xcl, h, w, relu=True, residual=res)
+    pre = F.conv2d(x.double(), wt.double(), b.double(), stride=stride)
+    if residual:
+        pre = pre + res.double().view(1, ho, wo, cout).permute(0, 3, 1, 2)
+    want = pre.relu()
+    got = y.view(1, ho, wo, cout).permute(0, 3, 1, 2).double()
+    assert got.shape == want.shape and bool(torch.isfinite(got).all())
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), stride=stride)
+    if residual:
+        bound = bound + res.double().abs().view(1, ho, wo, cout).permute(0, 3, 1, 2)
+    c = float(((got - want).abs() / (2.0 ** -24 * bound)).max())
+    ref32 = F.conv2d(x, wt, b, stride=stride)
+    if residual:
+        ref32 = ref32 + res.view(1, ho, wo, cout).permute(0, 3, 1, 2)
+    c32 = float(((ref32.relu().double() - want).abs() / (2.0 ** -24 * bound)).max())
+    print("c(pod_conv1x1_split) = %.2f   c(torch conv2d fp32) = %.2f" % (c, c32))
+    assert c <= 8.0                      # a length-Cin fp32 dot product guarantees c <= Cin; MIOpen's fp32 GEMM measures 1.5 - 4
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,splits", [(2048, 512, 24, 42, 1, 4), (1024, 256, 12, 21, 1, 8), (512, 2048, 24, 42, 1, 2), (256, 64, 9, 9, 1, 2)])
+def test_split_over_the_input_channels_is_reproducible_and_equal_to_rounding(cin, cout, h, w, stride, splits):
+    wt, b, x = make(cin, cout, h, w, 7)
+    conv = Conv1x1(wt, b, stride)
+    xcl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+    res = torch.randn(h * w, cout, device="cuda")
+    one = conv(xcl, h, w, relu=True, residual=res, n_splits=1)
+    a = conv(xcl, h, w, relu=True, residual=res, n_splits=splits)
+    b2 = conv(xcl, h, w, relu=True, residual=res, n_splits=splits)
+    assert torch.equal(a, b2)
+    assert float((a - one).abs().max()) <= 4e-6 * max(1.0, float(one.abs().max()))
+    assert conv.splits_for(h * w) >= 1
+
+
+def test_invalid_arguments_are_rejected():
+    lib = hip.load()
+    x = torch.zeros(64, 32, device="cuda")
+    y = torch.zeros(64, 64, device="cuda")
+    ws = torch.zeros(3 * 64 * 32, dtype=torch.int16, device="cuda")
+    s = hip.current_stream()
+    ok = lambda *a: lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, *a, None, s)
+    assert ok(8, 8, 8, 8, 1, 32, 64, 0, 1) == 0
+    assert ok(8, 8, 8, 8, 1, 24, 64, 0, 1) == -1        # Cin % 16
+    assert ok(8, 8, 8, 8, 1, 32, 96, 0, 1) == -1        # Cout % 64
+    assert ok(8, 8, 8, 8, 3, 32, 64, 0, 1) == -1        # stride
+    assert ok(8, 8, 4, 8, 1, 32, 64, 0, 1) == -1        # input smaller than the output needs
+    assert ok(8, 8, 8, 8, 1, 32, 64, 0, 2) == -1        # split without a partials buffer
+    assert lib.pod_conv1x1_filter_split(x.data_ptr(), ws.data_ptr(), 48, 32, s) == -1
