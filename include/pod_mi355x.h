@@ -406,6 +406,8 @@ int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t s
  * n_splits > 1 (small maps): the input channels cut over workgroup sets, partial sums in `partials` (n_splits * H_out * W_out * Cout
  * floats), added in a fixed order with bias / residual / ReLU by a second launch. */
 int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
+int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y,
+                        int64_t n, int32_t Cout, int32_t relu, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
 int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
                       int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
                       pod_stream_t stream);

@@ -30,11 +30,12 @@ class Conv1x1:
     def out_hw(self, h: int, w: int):
         return ((h - 1) // self.stride + 1, (w - 1) // self.stride + 1)
 
-    def splits_for(self, p_out: int, cus: int = 256) -> int:
-        """Cut the input channels over workgroup sets when the map gives the 256-pixel x 128-channel tiling too few workgroups."""
-        wgs = ((p_out + 255) // 256) * (self.K // (128 if self.K % 128 == 0 else 64))
+    def splits_for(self, p_out: int, simds: int = 1024) -> int:
+        """Cut the input channels over workgroup sets when the map gives the 64-pixel x 64-channel tiling (one wavefront each) too few
+        tiles for the chip."""
+        tiles = ((p_out + 63) // 64) * (self.K // 64)
         nks, s = self.C // 16, 1
-        while s < 8 and wgs * s * 2 <= cus and nks % (s * 2) == 0 and nks // (s * 2) >= 8:
+        while s < 8 and tiles * s * 2 <= simds // 2 and nks % (s * 2) == 0 and nks // (s * 2) >= 8:
             s *= 2
         return s
 

@@ -11,15 +11,20 @@
 // operands (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the weights split once (pod_conv1x1_filter_split),
 // the activations in the loop with the very functions k12 uses (pod_wino.h: wino_bf16_pair / wino_bf16_residual).
 //
-// Mapping.  Workgroup = 4 wavefronts = 256 output pixels x (32 NCB) output channels (NCB = 4, or 2 when Cout % 128 != 0); every
-// wavefront owns 64 pixels x all the workgroup's channels: 2 NCB accumulator blocks of 32 x 32.  The filter is the ROW operand
-// of the MFMAs (a lane's accumulator quad is 4 consecutive output channels of one pixel: 16-byte stores into the channels-last output).
-// No LDS: with both operands K-contiguous a lane's MFMA fragment IS a contiguous piece of memory -- 32 B of one pixel's channels, 16 B
-// of one filter row's pre-split terms -- so fragments are loaded straight into registers, one k-step (16 channels) ahead; the four
-// wavefronts' identical filter loads meet in the CU's L1.  A pixel tile's workgroups (one per channel tile) run on ONE XCD back to back,
-// so the activations come out of that XCD's L2 after the first.  Small maps (res5: 1008 pixels = 4 pixel tiles) cut the input channels
-// over grid.y (partial sums, finished by pod_conv1x1_reduce in a fixed order).
+// Mapping.  Workgroup = ONE wavefront = 64 output pixels x (32 NCB) output channels (NCB = 4, or 2 when Cout % 128 != 0): 2 NCB
+// accumulator blocks of 32 x 32.  The filter is the ROW operand of the MFMAs (a lane's accumulator quad is 4 consecutive output
+// channels of one pixel: 16-byte stores into the channels-last output).  No LDS: with both operands K-contiguous a lane's MFMA
+// fragment IS a contiguous piece of memory -- 32 B of one pixel's channels, 16 B of one filter row's pre-split terms -- so fragments
+// are loaded straight into registers, TWO k-steps (16 channels each) ahead through three rotating register buffers; wavefronts that
+// share a CU and a channel tile meet in its L1 for the filter terms.  A pixel tile's wavefronts (one per channel tile) run on ONE XCD
+// back to back, so the activations come out of that XCD's L2 after the first.  One-wavefront workgroups because nothing is shared
+// through LDS and small maps need every tile to be its own schedulable unit (res5: 1008 pixels x 2048 channels = 256 tiles); where
+// even that leaves the chip idle the input channels are cut over grid.y (partial sums, finished by pod_conv1x1_reduce in a fixed order).
 #include "pod_wino.h"
+
+#ifndef POD_C1_ELIM
+#define POD_C1_ELIM 0        // experiment builds: 1 no activation loads, 2 no filter loads, 4 no split arithmetic, 8 no stores (time only)
+#endif
 
 namespace pod {
 
@@ -33,7 +38,7 @@ struct C1Params {
     const float* bias;
     const float* residual;
     int32_t P_out, W_out, W_in, stride, Cin, Cout, relu;
-    int32_t n_pt, n_ct;       // pixel tiles (256), channel tiles (32 NCB)
+    int32_t n_pt, n_ct;       // pixel tiles (64), channel tiles (32 NCB)
     int32_t ks_per_split;     // k-steps (16 channels) a workgroup set accumulates; grid.y sets
     int64_t split_stride;     // floats between partial outputs; 0: no split (bias / residual / ReLU applied here)
 };
@@ -56,8 +61,8 @@ __global__ void __launch_bounds__(256) k_conv1x1_filter_split(const float* __res
 }
 
 template <int NCB>
-__global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i32 = lane & 31, h = lane >> 5;
+__global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
+    const int lane = threadIdx.x & 63, i32 = lane & 31, h = lane >> 5;
     // blockIdx & 7 is the XCD (round-robin dispatch): an XCD takes pixel tiles xcd, xcd + 8, ... and runs all channel tiles of one back to back
     const int xcd = blockIdx.x & 7, wi = (int)(blockIdx.x >> 3);
     const int tp = (wi / P.n_ct) * 8 + xcd, tc = wi % P.n_ct;
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
     int pout[2], pin[2];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
-        const int p = tp * 256 + wave * 64 + pb * 32 + i32;
+        const int p = tp * 64 + pb * 32 + i32;
         pout[pb] = p < P.P_out ? p : -1;
         const int q = p < P.P_out ? p : 0;
         if (P.stride == 1) {
@@ -77,26 +82,31 @@ __global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
             pin[pb] = (P.stride * oy) * P.W_in + P.stride * ox;
         }
     }
-    const float* xa[2];
+    const float* __restrict__ xa[2];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) xa[pb] = P.x + (int64_t)pin[pb] * P.Cin + ks0 * 16 + 8 * h;
-    const uint16_t* wa = P.Ws + (((int64_t)(tc * NCB) * nks_all + ks0) * 3 * 2) * 256 + (h * 32 + i32) * 8;     // + cb * nks_all * 1536 + ks * 1536 + term * 512
+    const uint16_t* __restrict__ const wa = P.Ws + (((int64_t)(tc * NCB) * nks_all + ks0) * 3 * 2) * 256 + (h * 32 + i32) * 8;     // + cb * nks_all * 1536 + ks * 1536 + term * 512
     const int64_t w_cb = (int64_t)nks_all * 1536;
 
     f32x16 acc[NCB][2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x4 araw[2][2][2];              // [buffer][pb][4-channel half of the lane's 8]
-    c1_u32x4 wf[2][NCB][3];           // [buffer][cb][term]
-    auto load = [&](int buf, int ks) __attribute__((always_inline)) {
+    f32x4 araw[3][2][2];              // [buffer][pb][4-channel half of the lane's 8]
+    c1_u32x4 wf[3][NCB][3];           // [buffer][cb][term]
+    auto load = [&](auto buf_t, int ks) __attribute__((always_inline)) {
+        constexpr int buf = decltype(buf_t)::value;
+        if (!(POD_C1_ELIM & 1) || ks < 3) {
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            araw[buf][pb][0] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16);
-            araw[buf][pb][1] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16 + 4);
+            for (int pb = 0; pb < 2; ++pb) {
+                araw[buf][pb][0] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16);
+                araw[buf][pb][1] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16 + 4);
+            }
         }
+        if (!(POD_C1_ELIM & 2) || ks < 3) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
+                for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
+        }
     };
     const WinoSplitSel sel;
     auto step = [&](auto buf_t, auto first_t) __attribute__((always_inline)) {
@@ -108,6 +118,10 @@ __global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // pair i: channels 2 i, 2 i + 1
                 float lo = araw[buf][pb][i >> 1][2 * (i & 1)], hi = araw[buf][pb][i >> 1][2 * (i & 1) + 1];
+                if (POD_C1_ELIM & 4) {
+                    at[pb][0][i] = at[pb][1][i] = at[pb][2][i] = __builtin_bit_cast(uint32_t, lo);
+                    continue;
+                }
                 const uint32_t t0 = wino_bf16_pair(lo, hi);
                 wino_bf16_residual(t0, lo, hi, sel);
                 const uint32_t t1 = wino_bf16_pair(lo, hi);
@@ -134,39 +148,59 @@ __global__ void __launch_bounds__(256, 1) k_conv1x1_split(const C1Params P) {
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
-    load(0, 0);
-    if (nks > 1) load(1, 1);
+    using B2 = std::integral_constant<int, 2>;
+    // loads run two k-steps ahead; the three buffers rotate at compile time (three k-steps per trip)
+    load(B0{}, 0);
+    if (nks > 1) load(B1{}, 1);
+    if (nks > 2) load(B2{}, 2);
     step(B0{}, std::true_type{});
-    for (int ks = 1; ks < nks; ks += 2) {       // two k-steps per trip: the buffers alternate at compile time, loads run one k-step ahead
-        if (ks + 1 < nks) load(0, ks + 1);
+    for (int ks = 1; ks < nks; ks += 3) {
+        if (ks + 2 < nks) load(B0{}, ks + 2);
         step(B1{}, std::false_type{});
         if (ks + 1 >= nks) break;
-        if (ks + 2 < nks) load(1, ks + 2);
+        if (ks + 3 < nks) load(B1{}, ks + 3);
+        step(B2{}, std::false_type{});
+        if (ks + 2 >= nks) break;
+        if (ks + 4 < nks) load(B2{}, ks + 4);
         step(B0{}, std::false_type{});
     }
 
-    // ---- epilogue: a lane's accumulator register r of block (cb, pb) is channel 32 cb + (r & 3) + 8 (r >> 2) + 4 h of pixel 32 pb + i32
-    float* yo = P.y + (int64_t)blockIdx.y * P.split_stride;
+    // ---- epilogue: a lane's accumulator register r of block (cb, pb) is channel 32 cb + (r & 3) + 8 (r >> 2) + 4 h of pixel 32 pb + i32.
+    // One wavefront per SIMD: nobody else hides this wavefront's latencies, so the residual quads of a pixel (4 NCB independent 16-byte
+    // loads) are all requested before the first is used, and nothing may alias (`__restrict__`: a store to y would otherwise fence the
+    // residual loads behind it and turn the epilogue into 32 serial round trips -- measured: 25 of res4-conv3's 37 us).
+    float* __restrict__ const yo = P.y + (int64_t)blockIdx.y * P.split_stride;
+    const float* __restrict__ const res = P.residual;
+    const float* __restrict__ const bias = P.bias;
     const bool final_pass = P.split_stride == 0;
+    const int k0 = tc * NCB * 32 + 4 * h;                       // + 32 cb + 8 q
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         if (pout[pb] < 0) continue;
+        const int64_t e0 = (int64_t)pout[pb] * P.Cout + k0;
+        f32x4 r[NCB][4];
+        if (final_pass && res) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r[cb][q] = (k0 + 32 * cb + 8 * q < P.Cout) ? *reinterpret_cast<const f32x4*>(res + e0 + 32 * cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int k = (tc * NCB + cb) * 32 + 8 * q + 4 * h;
+                const int k = k0 + 32 * cb + 8 * q;
                 if (k >= P.Cout) continue;
                 f32x4 v = f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
-                const int64_t e = (int64_t)pout[pb] * P.Cout + k;
                 if (final_pass) {
-                    if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + k);
-                    if (P.residual) v += *reinterpret_cast<const f32x4*>(P.residual + e);
+                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + k);
+                    if (res) v += r[cb][q];
                     if (P.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                *reinterpret_cast<f32x4*>(yo + e) = v;
+                if (!(POD_C1_ELIM & 8) || v.x == 12345.678f) *reinterpret_cast<f32x4*>(yo + e0 + 32 * cb + 8 * q) = v;
             }
         }
     }
@@ -214,14 +248,18 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     pod::C1Params P;
     P.x = x; P.y = n_splits > 1 ? partials : y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.residual = residual;
     P.P_out = (int32_t)P_out; P.W_out = W_out; P.W_in = W_in; P.stride = stride; P.Cin = Cin; P.Cout = Cout; P.relu = relu;
-    const int ncb = (Cout % 128 == 0) ? 4 : 2;
-    P.n_pt = (int32_t)((P_out + 255) / 256); P.n_ct = Cout / (32 * ncb);
+#ifdef POD_C1_NCB
+    const int ncb = POD_C1_NCB;
+#else
+    const int ncb = 2;      // 64-channel tiles: 186 registers = two wavefronts per SIMD, one's epilogue under the other's MFMAs (measured: 1.17 ms per image against 1.29 with 128-channel tiles)
+#endif
+    P.n_pt = (int32_t)((P_out + 63) / 64); P.n_ct = Cout / (32 * ncb);
     P.ks_per_split = nks / n_splits;
     P.split_stride = n_splits > 1 ? P_out * Cout : 0;
     const int64_t grid = 8LL * ((P.n_pt + 7) / 8) * P.n_ct;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    if (ncb == 4) hipLaunchKernelGGL(pod::k_conv1x1_split<4>, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(pod::k_conv1x1_split<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
+    if (ncb == 4) hipLaunchKernelGGL(pod::k_conv1x1_split<4>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(pod::k_conv1x1_split<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     if (n_splits > 1) {
         const int64_t n4 = P_out * Cout / 4;
@@ -233,3 +271,21 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     }
     return POD_OK;
 }
+
+// The fixed-order sum of channels-last partial outputs as its own entry point (pod_wino_conv3x3_split_partial's partials when the
+// consumer wants channels-last, not planes): y = act(sum_s partials[s] + bias + residual), n = pixels * Cout floats.
+extern "C" int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y, int64_t n,
+                                   int32_t Cout, int32_t relu, pod_stream_t stream) {
+    if (!partials || !y || n_splits < 1 || n_splits > 16 || n < 0 || (n & 3) != 0 || Cout < 4 || (Cout & 3) != 0 || n % Cout != 0) return POD_E_INVALID;
+    if (n_splits > 1 && (split_stride < n || (split_stride & 3) != 0)) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15u) != 0)
+        return POD_E_INVALID;
+    if (n == 0) return POD_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pod::k_conv1x1_reduce, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, split_stride, bias, residual, y, n / 4,
+                       Cout, relu);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+

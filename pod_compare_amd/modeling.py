@@ -236,6 +236,53 @@ def branches(fns, kind=""):
     return outs
 
 
+# ---- channels-last backbone (round 4) ---------------------------------------------------------------------------------------
+# With the 3x3 convolutions on pod_wino_conv3x3[_split] (channels-last in and out) the 1x1 convolutions were what kept the backbone in
+# NCHW: MIOpen GEMM + one element-wise pass each for bias / residual / ReLU, plus a layout pass in front of every 3x3.  On
+# pod_conv1x1_split (csrc/k13_conv1x1_split.hip: channels-last GEMM, bias + residual + ReLU in the store, same exact-split products as
+# the 3x3 kernel) a bottleneck is three launches on (pixels, C) buffers and the whole trunk stays channels-last from the max-pool on.
+CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
+
+
+def c1_of(conv: nn.Conv2d):
+    """The conv's pod_conv1x1_split form (weight split once), refreshed when the parameters change."""
+    from .conv1x1 import Conv1x1
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+    cached = getattr(conv, "_pod_c1", None)
+    if cached is None or cached[0] != key:
+        cached = (key, Conv1x1(conv.weight, conv.bias, conv.stride[0]))
+        torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
+        conv._pod_c1 = cached
+    return cached[1]
+
+
+def _c1_ok(conv: Optional[nn.Conv2d]) -> bool:
+    from .conv1x1 import Conv1x1
+    return conv is not None and conv.bias is not None and Conv1x1.eligible(conv)
+
+
+def _w3_ok(conv: Optional[nn.Conv2d]) -> bool:
+    return (conv is not None and conv.bias is not None and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (1, 1) and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and conv.in_channels % 16 == 0
+            and conv.out_channels in (64, 128, 256, 512))
+
+
+def wino_cl(conv: nn.Conv2d, x: torch.Tensor, h: int, w: int, relu: bool) -> torch.Tensor:
+    """act(conv3x3(x) + bias) of one channels-last image (h * w, C) -> (h * w, K)."""
+    from .wino import block_table
+    return wino_of(conv).channels_last_of_one_image(x, block_table([(h, w)], 1, x.device, channels=max(conv.in_channels, conv.out_channels)), relu=relu)
+
+
+def cl_as_nchw(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """(h * w, C) channels-last buffer as a (1, C, h, w) tensor (channels_last strides: a view)."""
+    return x.view(1, h, w, x.shape[1]).permute(0, 3, 1, 2)
+
+
+def nchw_as_cl(x: torch.Tensor) -> torch.Tensor:
+    """(1, C, h, w) tensor of either memory format as an (h * w, C) channels-last buffer (a view when it already is channels-last)."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
 def _conv_bn(cin, cout, k, stride=1, padding=0):
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill
@@ -268,6 +315,22 @@ class Bottleneck(nn.Module):
         return conv_bias_act(self.conv3, out, relu=True, residual_module=self.shortcut, residual_input=x, residual_raw=raw)
 
 
+    def cl_eligible(self) -> bool:
+        convs = (_plain_conv(self.conv1), _plain_conv(self.conv2), _plain_conv(self.conv3))
+        sc = None if self.shortcut is None else _plain_conv(self.shortcut)
+        return _c1_ok(convs[0]) and _w3_ok(convs[1]) and _c1_ok(convs[2]) and (self.shortcut is None or _c1_ok(sc))
+
+    def forward_cl(self, x: torch.Tensor, h: int, w: int):
+        """The block on a channels-last buffer x (h * w, Cin): conv1 (1x1, stride) -> conv2 (3x3) -> conv3 (1x1) + shortcut + ReLU, three
+        (four) launches, every bias / ReLU / residual in the producing kernel's store.  Returns (y, h_out, w_out)."""
+        c1, c2, c3 = c1_of(_plain_conv(self.conv1)), _plain_conv(self.conv2), c1_of(_plain_conv(self.conv3))
+        h1, w1 = c1.out_hw(h, w)
+        a = c1(x, h, w, relu=True)
+        b = wino_cl(c2, a, h1, w1, relu=True)
+        r = x if self.shortcut is None else c1_of(_plain_conv(self.shortcut))(x, h, w, relu=False)
+        return c3(b, h1, w1, relu=True, residual=r), h1, w1
+
+
 class ResNet50(nn.Module):
     """res2..res5 of ResNet-50; returns res3, res4, res5 (strides 8, 16, 32)."""
 
@@ -292,6 +355,22 @@ class ResNet50(nn.Module):
         c4 = self.res4(c3)
         c5 = self.res5(c4)
         return c3, c4, c5
+
+    def cl_eligible(self) -> bool:
+        return all(b.cl_eligible() for stage in (self.res2, self.res3, self.res4, self.res5) for b in stage)
+
+    def forward_cl(self, x):
+        """Channels-last from the max-pool on: returns [(c3, h, w), (c4, h, w), (c5, h, w)] with c* (h * w, C) buffers."""
+        x = conv_bias_act(self.stem, x, relu=True)                       # 7x7 / stride 2: MIOpen, NCHW
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        h, w = int(x.shape[2]), int(x.shape[3])
+        t = nchw_as_cl(x)
+        outs = []
+        for stage in (self.res2, self.res3, self.res4, self.res5):
+            for block in stage:
+                t, h, w = block.forward_cl(t, h, w)
+            outs.append((t, h, w))
+        return outs[1:]
 
 
 class FPN(nn.Module):
@@ -318,6 +397,25 @@ class FPN(nn.Module):
             p6 = self.p6(c5)
             return p6, self.p7(F.relu(p6))
         p3, p4, p5, (p6, p7) = branches([out(self.output[0], l3), out(self.output[1], l4), out(self.output[2], l5), top], "fpn")
+        return [p3, p4, p5, p6, p7]
+
+    def cl_eligible(self) -> bool:
+        return all(_c1_ok(m) for m in self.lateral) and all(_w3_ok(m) for m in self.output)
+
+    def forward_cl(self, feats):
+        """feats: [(c3, h, w), (c4, h, w), (c5, h, w)] channels-last buffers.  Lateral 1x1 convs on pod_conv1x1_split, top-down sums on
+        channels-last views, output 3x3 convs on pod_wino_conv3x3[_split]; p6 / p7 (stride-2 3x3: MIOpen) read channels_last views.
+        Returns (1, 256, h, w) tensors with channels_last strides: the head lays them out channels-last anyway."""
+        (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = feats
+        l5 = c1_of(self.lateral[2])(c5, h5, w5)
+        up = lambda t, h, w, size: nchw_as_cl(F.interpolate(cl_as_nchw(t, h, w), size=size, mode="nearest"))
+        l4 = c1_of(self.lateral[1])(c4, h4, w4, residual=up(l5, h5, w5, (h4, w4)))       # lateral + upsampled top-down map in one store
+        l3 = c1_of(self.lateral[0])(c3, h3, w3, residual=up(l4, h4, w4, (h3, w3)))
+        p3 = cl_as_nchw(wino_cl(self.output[0], l3, h3, w3, relu=False), h3, w3)
+        p4 = cl_as_nchw(wino_cl(self.output[1], l4, h4, w4, relu=False), h4, w4)
+        p5 = cl_as_nchw(wino_cl(self.output[2], l5, h5, w5, relu=False), h5, w5)
+        p6 = self.p6(cl_as_nchw(c5, h5, w5))
+        p7 = self.p7(F.relu(p6))
         return [p3, p4, p5, p6, p7]
 
 
@@ -663,9 +761,22 @@ class ProbabilisticRetinaNet(nn.Module):
             return self._forward_graphed(image, n, dropout, skip_unused_last_run)
         return self._forward_eager(image, n, dropout, skip_unused_last_run)
 
+    def _cl_backbone(self, x: torch.Tensor) -> bool:
+        """The trunk runs channels-last on pod_conv1x1_split + pod_wino_conv3x3_split: GPU, fp32, FrozenBN folded, the split kernels
+        selected (POD_WINO_SPLIT=0 -- the fp32-MFMA reference leg -- keeps the 1x1 convolutions on MIOpen as in round 3)."""
+        from . import wino
+        if not (CL_BACKBONE and FUSE_CONV_TAIL and WINO_BACKBONE and wino.SPLIT_BF16 and x.is_cuda and x.dtype == torch.float32):
+            return False
+        if not getattr(self, "_cl_ok", False):
+            self._cl_ok = self.bottom_up.cl_eligible() and self.fpn.cl_eligible()       # (cached once true: folding is one-way)
+        return self._cl_ok
+
     def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
         x = self.preprocess_image(image)
-        feats = self.fpn(self.bottom_up(x))
+        if self._cl_backbone(x):
+            feats = self.fpn.forward_cl(self.bottom_up.forward_cl(x))      # channels-last trunk on pod_conv1x1_split + pod_wino_conv3x3[_split]
+        else:
+            feats = self.fpn(self.bottom_up(x))
         cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
                                                  skip_unused_last_run=skip_unused_last_run)
         padded = tuple(x.shape[-2:])

@@ -170,3 +170,20 @@ class WinoConv:
                                       hip.current_stream()), "pod_wino_reduce")
         return dst
 
+    def channels_last_of_one_image(self, src: torch.Tensor, table: torch.Tensor, relu: bool = False, n_splits: Optional[int] = None) -> torch.Tensor:
+        """conv + bias (+ ReLU) of ONE image, channels-last in and out ((H*W, C) -> (H*W, K); K % 64 == 0): the form a channels-last
+        backbone chains (conv1x1.Conv1x1 before and after); small maps are cut over their input channels like `planes_of_one_image`."""
+        assert self.K == self.Kpad, "channels-last output needs K % 64 == 0"
+        hw = int(src.shape[0])
+        dst = torch.empty((hw, self.Kpad), dtype=torch.float32, device=src.device)
+        s = self.splits_for(int(table.shape[0])) if n_splits is None else int(n_splits)
+        if s <= 1:
+            return self(src, dst, table, relu=relu)
+        partials = torch.empty((s, hw, self.Kpad), dtype=torch.float32, device=src.device)
+        lib = hip.load()
+        hip.check(lib.pod_wino_conv3x3_split_partial(src.data_ptr(), partials.data_ptr(), self.U.data_ptr(), table.data_ptr(), table.shape[0], self.C, self.Kpad,
+                                                     s, hw * self.Kpad, hip.current_stream()), "pod_wino_conv3x3_split_partial")
+        hip.check(lib.pod_reduce_partials(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), None, dst.data_ptr(), hw * self.Kpad, self.Kpad,
+                                          1 if relu else 0, hip.current_stream()), "pod_reduce_partials")
+        return dst
+

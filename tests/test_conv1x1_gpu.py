@@ -78,3 +78,32 @@ def test_invalid_arguments_are_rejected():
     assert ok(8, 8, 4, 8, 1, 32, 64, 0, 1) == -1        # input smaller than the output needs
     assert ok(8, 8, 8, 8, 1, 32, 64, 0, 2) == -1        # split without a partials buffer
     assert lib.pod_conv1x1_filter_split(x.data_ptr(), ws.data_ptr(), 48, 32, s) == -1
+
+
+def test_channels_last_backbone_equals_the_nchw_backbone():
+    """ResNet-50-FPN with every 1x1 convolution on pod_conv1x1_split and the trunk channels-last from the max-pool on (modeling.forward_cl)
+    against the round-3 form (MIOpen 1x1 convolutions + element-wise passes, NCHW): the same five feature maps to fp32 rounding through
+    ~50 layers, for frames whose maps are ragged (odd sizes, stride-2 convolutions on odd inputs)."""
+    from pod_compare_amd import modeling
+    torch.manual_seed(0)
+    m = modeling.ProbabilisticRetinaNet(cls_var_loss="loss_attenuation", bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    for mod in m.modules():                                   # non-trivial FrozenBN statistics: the fold must carry them into the biases
+        if isinstance(mod, modeling.FrozenBatchNorm2d):
+            mod.weight.copy_(0.5 + torch.rand(mod.weight.shape, generator=g))
+            mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+            mod.running_mean.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.bias.shape, generator=g))
+    modeling.fold_frozen_bn(m)
+    assert m.bottom_up.cl_eligible() and m.fpn.cl_eligible()
+    for hw in ((224, 320), (200, 333), (97, 131)):
+        frame = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, device="cuda")
+        x = m.preprocess_image(frame)
+        assert m._cl_backbone(x)
+        with torch.no_grad():
+            cl = m.fpn.forward_cl(m.bottom_up.forward_cl(x))
+            ref = m.fpn(m.bottom_up(x))
+        for a, b in zip(cl, ref):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), (hw, tuple(a.shape))
+
