@@ -170,10 +170,37 @@ def conv_census(model, img, N, quirk, dev):
         calls.append((cat, 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))   # direct-convolution FLOPs
         return y
 
+    real_cl = wino.WinoConv.channels_last_of_one_image
+
+    def probe_cl(self, src, table, **kw):               # the same convolutions in the channels-last backbone
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        inside[0] = True
+        try:
+            y = real_cl(self, src, table, **kw)
+        finally:
+            inside[0] = False
+        e1.record()
+        calls.append(("3x3_backbone_fpn_winograd_hip", 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))
+        return y
+
+    from pod_compare_amd import conv1x1
+    real_c1 = conv1x1.Conv1x1.__call__
+
+    def probe_c1(self, x, h, w, **kw):                   # pod_conv1x1_split (+ its reduce launch on small maps)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_c1(self, x, h, w, **kw)
+        e1.record()
+        calls.append(("1x1_hip", 2.0 * y.shape[0] * self.C * self.K, e0, e1))
+        return y
+
     reps = 3
     F.conv2d = probe
     wino.WinoConv.__call__ = probe_wino
     wino.WinoConv.planes_of_one_image = probe_planes
+    wino.WinoConv.channels_last_of_one_image = probe_cl
+    conv1x1.Conv1x1.__call__ = probe_c1
     try:
         with torch.no_grad():
             for _ in range(reps):
@@ -183,6 +210,8 @@ def conv_census(model, img, N, quirk, dev):
         F.conv2d = real
         wino.WinoConv.__call__ = real_wino
         wino.WinoConv.planes_of_one_image = real_planes
+        wino.WinoConv.channels_last_of_one_image = real_cl
+        conv1x1.Conv1x1.__call__ = real_c1
     out = {}
     for cat, flops, e0, e1 in calls:
         d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
@@ -495,6 +524,8 @@ def main():
                                      "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
                                      "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
                    "rng": "in-kernel Philox4x32-10, fresh key per image",
+                   "backbone": ("channels-last on pod_conv1x1_split + pod_wino_conv3x3_split (stem, max-pool, p6 / p7: PyTorch-ROCm)"
+                                if (modeling.CL_BACKBONE and args.split_bf16) else "NCHW: 1x1 / strided convolutions on PyTorch-ROCm, 3x3 / stride-1 on the Winograd kernel"),
                    "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not args.no_cnn) else "eager launches from Python"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
         "host_loop_ms_per_image": host_loop_ms,
