@@ -201,12 +201,15 @@ def conv_census(model, img, N, quirk, dev):
     wino.WinoConv.planes_of_one_image = probe_planes
     wino.WinoConv.channels_last_of_one_image = probe_cl
     conv1x1.Conv1x1.__call__ = probe_c1
+    graphs = getattr(model, "use_graphs", False)
+    model.use_graphs = False                              # a replayed graph calls none of the probes: the census is of the eager forward
     try:
         with torch.no_grad():
             for _ in range(reps):
                 model(img, num_mc_dropout_runs=N, skip_unused_last_run=quirk)
         torch.cuda.synchronize()
     finally:
+        model.use_graphs = graphs
         F.conv2d = real
         wino.WinoConv.__call__ = real_wino
         wino.WinoConv.planes_of_one_image = real_planes
@@ -724,6 +727,15 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                         "traffic": None,
                                         "note": "HIP events around each launch on one stream (launch gaps included); MIOpen's Winograd on the same "
                                                 "convolutions ran at 82 TFLOP/s direct-equivalent in round 2"}
+
+        c1 = census.get("1x1_hip")
+        if c1:      # the bottlenecks' 1x1 convolutions, shortcuts and FPN laterals on pod_conv1x1_split (channels-last GEMM, 6 bf16 partial products)
+            out["roofline_conv1x1"] = {"kernel": "pod_conv1x1_split on the backbone's 1x1 convolutions and the FPN laterals (%d calls per image, batch 1; "
+                                                 "small maps cut over their input channels: + pod_reduce_partials)" % c1["calls"],
+                                       "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF, "achieved": c1["tflops"] * 6.0,
+                                       "frac": c1["tflops"] * 6.0 / BF16_MFMA_PEAK_TF, "fp32_products_vs_fp32_mfma_peak": c1["tflops"] / FP32_MFMA_PEAK_TF,
+                                       "gflop": c1["gflop"], "ms_per_image": c1["ms"], "traffic": None,
+                                       "note": "HIP events around each call on one stream (launch gaps and reduce launches included); the res2 calls are HBM-bound"}
 
     # ---- NLL of the detections against the planted ground truth (the "NLL parity" half of the metric) ---------
     if spec["reg_var"] or N > 1:

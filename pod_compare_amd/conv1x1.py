@@ -32,12 +32,20 @@ class Conv1x1:
 
     def splits_for(self, p_out: int, simds: int = 1024) -> int:
         """Cut the input channels over workgroup sets when the map gives the 64-pixel x 64-channel tiling (one wavefront each) too few
-        tiles for the chip."""
+        tiles for the chip.  Read off tools/conv1x1_splits.py: alone on its SIMD a wavefront takes ~0.68 us per k-step (16 channels), a
+        split costs the reduce launch (~3 us) plus writing s and reading s + 1 copies of the output at ~4 TB/s, and past one wavefront
+        per SIMD nothing is gained."""
         tiles = ((p_out + 63) // 64) * (self.K // 64)
-        nks, s = self.C // 16, 1
-        while s < 8 and tiles * s * 2 <= simds // 2 and nks % (s * 2) == 0 and nks // (s * 2) >= 8:
-            s *= 2
-        return s
+        nks = self.C // 16
+        out_mb = p_out * self.K * 4 / 1e6
+        best, best_t = 1, nks * 0.68
+        for s in (2, 4, 8, 16):
+            if nks % s or nks // s < 4 or tiles * s > simds:
+                continue
+            t = (nks // s) * 0.68 + 3.0 + (s + 1) * out_mb / 4.0
+            if t < best_t:
+                best, best_t = s, t
+        return best
 
     def __call__(self, x: torch.Tensor, h: int, w: int, relu: bool = False, residual: Optional[torch.Tensor] = None,
                  n_splits: Optional[int] = None) -> torch.Tensor:

@@ -26,6 +26,21 @@
 #define POD_C1_ELIM 0        // experiment builds: 1 no activation loads, 2 no filter loads, 4 no split arithmetic, 8 no stores (time only)
 #endif
 
+#ifdef POD_C1_TRACE       // experiment builds: 10-ns time stamps of every wavefront (start | first k-step done | loop done | end), pod_c1_trace_dump()
+static __device__ long long g_c1_trace[8192 * 4];
+static __device__ long long g_c1_cycles[8192 * 4];      // s_memtime beside the constant 100-MHz clock: the shader clock the wavefront ran at
+#define C1_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                     \
+        if (threadIdx.x == 0 && wg_ < 8192) {                                                         \
+            g_c1_trace[wg_ * 4 + (k)] = wall_clock64();                                               \
+            g_c1_cycles[wg_ * 4 + (k)] = clock64();                                                   \
+        }                                                                                             \
+    } while (0)
+#else
+#define C1_STAMP(k)
+#endif
+
 namespace pod {
 
 typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
@@ -60,13 +75,22 @@ __global__ void __launch_bounds__(256) k_conv1x1_filter_split(const float* __res
     }
 }
 
-template <int NCB>
+template <int I>
+using c1_ic = std::integral_constant<int, I>;
+
+// RING: register buffers of one k-step each; loads run RING - 1 k-steps ahead.  3 leaves room for two wavefronts per SIMD.  Deeper rings
+// were measured on the launches that have at most one wavefront per SIMD anyway (res4 / res5, the laterals: 1600 cycles per k-step
+// against the 768 of its MFMAs) and change nothing (ring 4 / 5 / 6: 1.17 / 1.15 / 1.20 ms per image against 1.18): what those
+// wavefronts wait for is not the distance of the loads but the L1's time for the activation fragments -- 32 cache lines per
+// instruction (profiles/r04_experiments.md, K13).
+template <int NCB, int RING>
 __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
     const int lane = threadIdx.x & 63, i32 = lane & 31, h = lane >> 5;
     // blockIdx & 7 is the XCD (round-robin dispatch): an XCD takes pixel tiles xcd, xcd + 8, ... and runs all channel tiles of one back to back
     const int xcd = blockIdx.x & 7, wi = (int)(blockIdx.x >> 3);
     const int tp = (wi / P.n_ct) * 8 + xcd, tc = wi % P.n_ct;
     if (tp >= P.n_pt) return;
+    C1_STAMP(0);
     const int nks_all = P.Cin >> 4, ks0 = (int)blockIdx.y * P.ks_per_split, nks = P.ks_per_split;
     // this lane's two pixels (pb = 0, 1) and where they live in the input (stride-2 convolutions read every second row / column)
     int pout[2], pin[2];
@@ -90,18 +114,18 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
 
     f32x16 acc[NCB][2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x4 araw[3][2][2];              // [buffer][pb][4-channel half of the lane's 8]
-    c1_u32x4 wf[3][NCB][3];           // [buffer][cb][term]
+    f32x4 araw[RING][2][2];           // [buffer][pb][4-channel half of the lane's 8]
+    c1_u32x4 wf[RING][NCB][3];        // [buffer][cb][term]
     auto load = [&](auto buf_t, int ks) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_t)::value;
-        if (!(POD_C1_ELIM & 1) || ks < 3) {
+        if (!(POD_C1_ELIM & 1) || ks < RING) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
                 araw[buf][pb][0] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16);
                 araw[buf][pb][1] = *reinterpret_cast<const f32x4*>(xa[pb] + ks * 16 + 4);
             }
         }
-        if (!(POD_C1_ELIM & 2) || ks < 3) {
+        if (!(POD_C1_ELIM & 2) || ks < RING) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -146,25 +170,32 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
                 }
         }
     };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    using B2 = std::integral_constant<int, 2>;
-    // loads run two k-steps ahead; the three buffers rotate at compile time (three k-steps per trip)
-    load(B0{}, 0);
-    if (nks > 1) load(B1{}, 1);
-    if (nks > 2) load(B2{}, 2);
-    step(B0{}, std::true_type{});
-    for (int ks = 1; ks < nks; ks += 3) {
-        if (ks + 2 < nks) load(B0{}, ks + 2);
-        step(B1{}, std::false_type{});
-        if (ks + 1 >= nks) break;
-        if (ks + 3 < nks) load(B1{}, ks + 3);
-        step(B2{}, std::false_type{});
-        if (ks + 2 >= nks) break;
-        if (ks + 4 < nks) load(B2{}, ks + 4);
-        step(B0{}, std::false_type{});
-    }
+    // k-step j computes from buffer j % RING and, before that, refills the buffer k-step j - 1 just left with k-step j + RING - 1;
+    // the buffers rotate at compile time (RING k-steps per trip of the loop)
+    auto prologue = [&](auto self, auto r_t) __attribute__((always_inline)) -> void {
+        constexpr int R = decltype(r_t)::value;
+        if constexpr (R < RING - 1) {
+            if (R < nks) load(c1_ic<R>{}, R);
+            self(self, c1_ic<R + 1>{});
+        }
+    };
+    prologue(prologue, c1_ic<0>{});
+    if (RING - 1 < nks) load(c1_ic<RING - 1>{}, RING - 1);
+    step(c1_ic<0>{}, std::true_type{});
+    C1_STAMP(1);
+    auto trip = [&](auto self, auto r_t, int ks) __attribute__((always_inline)) -> void {        // k-steps ks + R, R = 0 .. RING - 1, ks % RING == 1
+        constexpr int R = decltype(r_t)::value;
+        if constexpr (R < RING) {
+            if (ks + R < nks) {
+                if (ks + R + RING - 1 < nks) load(c1_ic<R % RING>{}, ks + R + RING - 1);
+                step(c1_ic<(R + 1) % RING>{}, std::false_type{});
+                self(self, c1_ic<R + 1>{}, ks);
+            }
+        }
+    };
+    for (int ks = 1; ks < nks; ks += RING) trip(trip, c1_ic<0>{}, ks);
 
+    C1_STAMP(2);
     // ---- epilogue: a lane's accumulator register r of block (cb, pb) is channel 32 cb + (r & 3) + 8 (r >> 2) + 4 h of pixel 32 pb + i32.
     // One wavefront per SIMD: nobody else hides this wavefront's latencies, so the residual quads of a pixel (4 NCB independent 16-byte
     // loads) are all requested before the first is used, and nothing may alias (`__restrict__`: a store to y would otherwise fence the
@@ -204,6 +235,10 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
             }
         }
     }
+#ifdef POD_C1_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    C1_STAMP(3);
+#endif
 }
 
 // y = act(sum of the partial outputs in order + bias + residual), channels-last, 16 B per lane
@@ -258,8 +293,16 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     P.split_stride = n_splits > 1 ? P_out * Cout : 0;
     const int64_t grid = 8LL * ((P.n_pt + 7) / 8) * P.n_ct;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    if (ncb == 4) hipLaunchKernelGGL(pod::k_conv1x1_split<4>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(pod::k_conv1x1_split<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
+#ifdef POD_C1_LDSPAD
+    const unsigned pad = (grid * n_splits <= POD_C1_LDSPAD_MAXGRID) ? POD_C1_LDSPAD : 0;
+#else
+    const unsigned pad = 0;
+#endif
+#ifndef POD_C1_RING
+#define POD_C1_RING 3
+#endif
+    if (ncb == 4) hipLaunchKernelGGL((pod::k_conv1x1_split<4, 3>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     if (n_splits > 1) {
         const int64_t n4 = P_out * Cout / 4;
@@ -289,3 +332,38 @@ extern "C" int pod_reduce_partials(const float* partials, int32_t n_splits, int6
     return POD_OK;
 }
 
+
+#ifdef POD_C1_TRACE
+#include <algorithm>
+#include <stdio.h>
+#include <vector>
+extern "C" int pod_c1_trace_dump(void) {   // experiment builds only (not in include/pod_mi355x.h): the LAST launch's wavefronts
+    static long long host[8192 * 4], cyc[8192 * 4];
+    if (hipDeviceSynchronize() != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c1_trace), sizeof(host)) != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_c1_cycles), sizeof(cyc)) != hipSuccess) return POD_E_LAUNCH;
+    long long t0 = 0, t_end = 0;
+    std::vector<long long> start, first, loop, epi, total, mhz;
+    for (int i = 0; i < 8192; ++i)
+        if (host[i * 4 + 3]) {
+            if (!t0 || host[i * 4] < t0) t0 = host[i * 4];
+            if (host[i * 4 + 3] > t_end) t_end = host[i * 4 + 3];
+        }
+    for (int i = 0; i < 8192; ++i)
+        if (host[i * 4 + 3]) {
+            start.push_back(host[i * 4] - t0);
+            first.push_back(host[i * 4 + 1] - host[i * 4]);
+            loop.push_back(host[i * 4 + 2] - host[i * 4 + 1]);
+            epi.push_back(host[i * 4 + 3] - host[i * 4 + 2]);
+            total.push_back(host[i * 4 + 3] - host[i * 4]);
+            mhz.push_back((cyc[i * 4 + 2] - cyc[i * 4 + 1]) * 100 / std::max(1LL, host[i * 4 + 2] - host[i * 4 + 1]));
+        }
+    auto q = [](std::vector<long long>& v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0LL : v[(size_t)(f * (v.size() - 1))]; };
+    fprintf(stderr, "c1 trace: %zu wavefronts, first start to last end %lld0 ns; 10-ns ticks  min / median / 90%% / max\n", start.size(), t_end - t0);
+    std::vector<long long>* vs[6] = {&start, &first, &loop, &epi, &total, &mhz};
+    const char* names[6] = {"start after the first", "start -> first k-step done", "rest of the k loop", "epilogue (stores landed)", "whole wavefront", "s_memtime MHz in the k loop"};
+    for (int k = 0; k < 6; ++k) fprintf(stderr, "  %-28s %5lld %5lld %5lld %5lld\n", names[k], q(*vs[k], 0.0), q(*vs[k], 0.5), q(*vs[k], 0.9), q(*vs[k], 1.0));
+    static long long zero[8192 * 4];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_c1_trace), zero, sizeof(zero)) == hipSuccess ? POD_OK : POD_E_LAUNCH;
+}
+#endif
