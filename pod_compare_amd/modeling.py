@@ -716,7 +716,9 @@ class ProbabilisticRetinaNet(nn.Module):
 
     def _forward_graphed(self, image: torch.Tensor, n: int, dropout: bool, skip: bool) -> HeadOutputs:
         stream = torch.cuda.current_stream(image.device)
-        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip)
+        from . import wino
+        # (the kernel selection is part of the key: a graph captured with one convolution kernel must not answer for the other)
+        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip, bool(wino.SPLIT_BF16), CL_BACKBONE, WINO_BACKBONE)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = image.clone()
