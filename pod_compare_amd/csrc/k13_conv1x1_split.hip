@@ -304,9 +304,12 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
             for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
     };
     const WinoSplitSel sel;
-    // (Splitting k-step j + 1 beside the MFMAs of k-step j, slot by slot as k12 does, was built and measured: the k loop keeps its 0.73 us
-    // per k-step -- what it waits for is the 10 KB of operands per 24 MFMAs, not the issue order -- and the second term buffer costs the
-    // second wavefront per SIMD that the large maps need: 1.02 ms per image against 0.975.  profiles/r04_experiments.md, K13.)
+    // Built, measured and dropped (profiles/r04_experiments.md, K13): splitting k-step j + 1 beside the MFMAs of k-step j slot by slot as
+    // k12 does (units of 7 VALU instructions in every second MFMA gap: the loop kept its 0.73 us per k-step and the second term buffer
+    // cost the second wavefront per SIMD that the large maps need: 1.02 ms per image against 0.975); a four-wavefront workgroup sharing
+    // the channel tile's filter terms through LDS (half the L1 / L2 traffic per MFMA, one barrier per pair: 1.02 against 0.93, the
+    // small maps 30-40 % slower).  The counters say where a lone wavefront's k-step goes: 768 cycles of MFMA + ~450 of VALU issue
+    // (113 instructions) + ~250 of waits, one after the other -- the VALU block of a k-step does not overlap its own MFMAs.
     auto step = [&](auto buf_t, auto t_t, int b) __attribute__((always_inline)) {       // k-step t of the pair in LDS buffer b
         constexpr int buf = decltype(buf_t)::value;
         constexpr int t = decltype(t_t)::value;
@@ -417,163 +420,6 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
 #endif
 }
 
-// The workgroup form: four wavefronts = four neighbouring 64-pixel tiles of ONE 64-channel tile, sharing its filter terms through LDS.
-// k_conv1x1_split_lds moves 10 KB from L1 / L2 per k-step and wavefront (4 KB activations, 6 KB filter terms) for 24 MFMAs, and that
-// traffic -- not latency, placement or issue order (profiles/r04_experiments.md, K13) -- is what its k loop waits for.  Here a pair's
-// filter terms (12 pieces of 1 KB, already stored in the order a lane reads them) are fetched ONCE per workgroup, three pieces per
-// wavefront, parked in a double-buffered LDS ring and read back by every wavefront: 5.5 KB from L1 / L2 per k-step and wavefront.
-// One barrier per pair.  Activations as in k_conv1x1_split_lds (whole lines, a swizzled transposing buffer per wavefront, here ONE
-// pair deep: LDS operations of a wavefront execute in order, so the next pair may overwrite the buffer once this pair's reads are
-// issued); epilogue through the same 8 KB, 32 pixels at a time.  56 KB of LDS per workgroup: two workgroups per CU.
-// Arithmetic, channel order and accumulation order are those of k_conv1x1_split: the results are bit-identical.
-__global__ void __launch_bounds__(256, 2) k_conv1x1_split_wg(const C1Params P) {
-    constexpr int NCB = 2;
-    __shared__ __attribute__((aligned(16))) float lds_a[4][64 * 32];            // [wavefront][pixel 64][chunk position 8][4 floats]
-    __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][12 * 256];        // [buffer][piece = k-step in pair * 6 + cb * 3 + term][lane][4]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i32 = lane & 31, h = lane >> 5;
-    // blockIdx & 7 is the XCD: an XCD takes 256-pixel groups xcd, xcd + 8, ... and runs all channel tiles of one back to back
-    const int xcd = blockIdx.x & 7, wi = (int)(blockIdx.x >> 3);
-    const int n_pg = (P.n_pt + 3) >> 2;
-    const int pg = (wi / P.n_ct) * 8 + xcd, tc = wi % P.n_ct;
-    if (pg >= n_pg) return;                                                     // whole workgroup
-    const int tp = pg * 4 + wave;                                               // this wavefront's pixel tile (may lie past the map: loads clamped, nothing stored)
-    C1_STAMP(0);
-    const int nks_all = P.Cin >> 4, ks0 = (int)blockIdx.y * P.ks_per_split, nks = P.ks_per_split, npairs = nks >> 1;
-    int32_t soff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int pl = 8 * j + (lane >> 3), p = tp * 64 + pl;
-        const int q = p < P.P_out ? p : 0;
-        int pin = q;
-        if (P.stride != 1) {
-            const int oy = q / P.W_out, ox = q - oy * P.W_out;
-            pin = (P.stride * oy) * P.W_in + P.stride * ox;
-        }
-        soff[j] = pin * P.Cin + ks0 * 16 + 4 * ((lane & 7) ^ ((pl >> 1) & 7));
-    }
-    const float* __restrict__ const xg = P.x;
-    const int key = (i32 >> 1) & 7;
-    float* const my_a = &lds_a[wave][0];
-    // this wavefront's three filter pieces of a pair: piece q = 3 wave + i
-    const uint16_t* wsrc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = 3 * wave + i, t = q / 6, cb = (q % 6) / 3, term = q % 3;
-        wsrc[i] = P.Ws + (((int64_t)(tc * NCB + cb) * nks_all + ks0 + t) * 3 + term) * 512 + lane * 8;       // + pair * 2 * 1536
-    }
-    f32x16 acc[NCB][2];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
-    f32x4 stg[8];
-    c1_u32x4 wstg[3];
-    auto stage_load = [&](int pair) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stg[j] = *reinterpret_cast<const f32x4*>(xg + soff[j] + pair * 32);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) wstg[i] = *reinterpret_cast<const c1_u32x4*>(wsrc[i] + (int64_t)pair * 3072);
-    };
-    auto stage_write = [&](int b) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(my_a + j * 256 + lane * 4) = stg[j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<c1_u32x4*>(&lds_w[b][(3 * wave + i) * 256 + lane * 4]) = wstg[i];
-    };
-    const WinoSplitSel sel;
-    auto step = [&](auto t_t, int b) __attribute__((always_inline)) {           // k-step t of the pair whose filter terms are in ring buffer b
-        constexpr int t = decltype(t_t)::value;
-        c1_u32x4 wf[NCB][3], at[2][3];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int term = 0; term < 3; ++term) wf[cb][term] = *reinterpret_cast<const c1_u32x4*>(&lds_w[b][(t * 6 + cb * 3 + term) * 256 + lane * 4]);
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const float* row = my_a + (pb * 32 + i32) * 32;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(row + 4 * ((4 * t + 2 * h) ^ key));
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(row + 4 * ((4 * t + 2 * h + 1) ^ key));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float lo = i < 2 ? a0[2 * (i & 1)] : a1[2 * (i & 1)], hi = i < 2 ? a0[2 * (i & 1) + 1] : a1[2 * (i & 1) + 1];
-                const uint32_t t0 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t0, lo, hi, sel);
-                const uint32_t t1 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t1, lo, hi, sel);
-                at[pb][0][i] = t0;
-                at[pb][1][i] = t1;
-                at[pb][2][i] = wino_bf16_pair(lo, hi);
-            }
-        }
-#pragma unroll
-        for (int prod = 0; prod < 6; ++prod) {
-            const int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;
-            const int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
-        }
-    };
-    stage_load(0);
-    stage_write(0);
-    C1_STAMP(1);
-    for (int pair = 0; pair < npairs; ++pair) {
-        __syncthreads();                    // this pair's filter terms are in the ring (every wavefront's three pieces); the other buffer is free
-        if (pair + 1 < npairs) stage_load(pair + 1);
-        step(c1_ic<0>{}, pair & 1);
-        step(c1_ic<1>{}, pair & 1);
-        if (pair + 1 < npairs) stage_write((pair + 1) & 1);
-    }
-    C1_STAMP(2);
-
-    // ---- epilogue in whole lines through this wavefront's 8 KB, 32 pixels (one accumulator column) at a time
-    float* __restrict__ const yo = P.y + (int64_t)blockIdx.y * P.split_stride;
-    const float* __restrict__ const res = P.residual;
-    const bool final_pass = P.split_stride == 0;
-    const int oc = lane & 15, op = lane >> 4;                       // read side: chunk oc (channels 4 oc ..) of pixel 4 j + op
-    const int gp0 = tp * 64 + op;
-    const int64_t e0 = (int64_t)gp0 * P.Cout + tc * 64 + 4 * oc;    // + 4 j Cout
-    f32x4 r[16];
-    if (final_pass && res) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = (gp0 + 4 * j < P.P_out) ? *reinterpret_cast<const f32x4*>(res + e0 + (int64_t)(4 * j) * P.Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (final_pass && P.bias) b4 = *reinterpret_cast<const f32x4*>(P.bias + tc * 64 + 4 * oc);
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = 8 * cb + 2 * q + h;
-                *reinterpret_cast<f32x4*>(my_a + i32 * 64 + 4 * (c ^ (i32 & 15))) =
-                    f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
-            }
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int pix = 4 * jj + op, j = 8 * pb + jj;
-            f32x4 v = *reinterpret_cast<const f32x4*>(my_a + pix * 64 + 4 * (oc ^ (pix & 15)));
-            if (final_pass) {
-                v += b4;
-                if (res) v += r[j];
-                if (P.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            if (gp0 + 4 * j < P.P_out) *reinterpret_cast<f32x4*>(yo + e0 + (int64_t)(4 * j) * P.Cout) = v;
-        }
-    }
-#ifdef POD_C1_TRACE
-    __builtin_amdgcn_s_waitcnt(0);
-    C1_STAMP(3);
-#endif
-}
-
 // y = act(sum of the partial outputs in order + bias + residual), channels-last, 16 B per lane
 __global__ void __launch_bounds__(256) k_conv1x1_reduce(const float* __restrict__ partials, int32_t n_splits, int64_t split_stride, const float* __restrict__ bias,
                                                         const float* __restrict__ residual, float* __restrict__ y, int64_t n4, int32_t Cout, int32_t relu) {
@@ -636,12 +482,6 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
 #endif
     if (ncb == 4) hipLaunchKernelGGL((pod::k_conv1x1_split<4, 3>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
 #ifndef POD_C1_DIRECT
-#ifndef POD_C1_NO_WG
-    else if ((P.ks_per_split & 1) == 0) {
-        const int64_t grid4 = 8LL * ((((P.n_pt + 3) >> 2) + 7) / 8) * P.n_ct;
-        hipLaunchKernelGGL(pod::k_conv1x1_split_wg, dim3((unsigned)grid4, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
-    }
-#endif
     else if ((P.ks_per_split & 1) == 0) hipLaunchKernelGGL(pod::k_conv1x1_split_lds<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
 #endif
     else hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
