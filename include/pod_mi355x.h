@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 8
+#define POD_ABI_VERSION 9
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -353,6 +353,15 @@ int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, in
 int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                            int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                            const uint64_t* epoch, pod_stream_t stream);
+/* The first conv of an MC-dropout subnet and the replication behind it in ONE launch (round 4; ABI 9).  Replaces PR:403-427's first
+ * Conv2d + ReLU + Dropout under PR:95-108's run loop: every MC run sees the same features, so the conv is evaluated once and its store
+ * pass writes the runs' `replicas` (<= 127) dropout-masked copies -- replica r = image r of the record's output canvas (the table:
+ * one input image per record, `replicas` output images; pod_compare_amd/wino.py block_table(levels, 1, out_copies = replicas)).
+ * Channels-last in and out.  Bit for bit pod_wino_conv3x3_split with p = 0, followed per level by pod_expand_dropout(copies = replicas,
+ * p, seed, offset + (index of the level's first output float) / 8, epoch): the separate pass (0.17 ms of a 10-ms image) is gone. */
+int pod_wino_conv3x3_split_replicas(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
+                                    int32_t C, int32_t K, int32_t relu, int32_t replicas, float p, uint64_t seed, uint64_t offset,
+                                    const uint64_t* epoch, pod_stream_t stream);
 /* Small maps (round 4): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  pod_wino_conv3x3_split_partial
  * cuts the INPUT channels into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): `partials` receives
  * n_splits channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart (K = round_up(real K, 64));

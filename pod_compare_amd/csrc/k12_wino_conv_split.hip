@@ -595,7 +595,31 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                 v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
-            const int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
+            int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
+            if (P.replicas > 1) {
+                // The first conv of an MC-dropout subnet: its output is the same for every run, so the store pass writes the runs'
+                // masked replicas itself (replica r = image r of the output canvas) -- the separate expand pass read this tensor back
+                // and wrote them in a launch of its own.  Mask of replica r = pod_expand_dropout's: counter word 2, 16 bits per element.
+                for (int rep = 0; rep < P.replicas; ++rep, e += (int64_t)HWi * P.out_stride) {
+                    f32x4 w0 = v0, w1 = v1;
+                    if (P.thresh) {
+                        const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
+                        const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
+                                                       (uint32_t)(drop_key >> 32));
+                        w0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
+                        w0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
+                        w0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
+                        w0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
+                        w1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
+                        w1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
+                        w1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
+                        w1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(out_base + e) = w0;
+                    *reinterpret_cast<f32x4*>(out_base + e + 4) = w1;
+                }
+                continue;
+            }
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
                 const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
@@ -679,7 +703,38 @@ extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* U
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch;
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 1;
+    const int64_t grid = pod::wino_grid(KS, n_blocks);
+    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+// conv + bias + ReLU of ONE image per record, stored `replicas` times (image r of the record's output canvas = replica r), each replica
+// under its own dropout mask: the first conv of an MC-dropout subnet and the expand pass behind it (PR:403-427 under PR:95-108: every
+// run sees the same input, so the conv is evaluated once) in one launch.  Output equals pod_wino_conv3x3_split (p = 0) followed, per
+// record canvas, by pod_expand_dropout(.., copies = replicas, p, seed, offset + (first output float of the canvas) / 8, epoch) bit for bit.
+extern "C" int pod_wino_conv3x3_split_replicas(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
+                                               int32_t C, int32_t K, int32_t relu, int32_t replicas, float p, uint64_t seed, uint64_t offset,
+                                               const uint64_t* epoch, pod_stream_t stream) {
+    if (!in || !out || in == out || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0 || !(p >= 0.0f && p < 1.0f) ||
+        replicas < 1 || replicas > 127)
+        return POD_E_INVALID;
+    const int32_t KS = K / 64;
+    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Us) |
+          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
+        return POD_E_INVALID;
+    if (n_blocks == 0) return POD_OK;
+    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
+    pod::WinoParams P;
+    P.in = in; P.out = out; P.U = reinterpret_cast<const float*>(Us); P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
+    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = 0;
+    P.thresh = POD_DROPOUT_THRESH16(p);
+    P.scale = 1.0f / (1.0f - p);
+    P.seed = seed; P.offset = offset;
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = replicas;
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
@@ -704,7 +759,7 @@ extern "C" int pod_wino_conv3x3_split_partial(const float* in, float* partials, 
     P.in = in; P.out = partials; P.U = reinterpret_cast<const float*>(Us); P.bias = nullptr; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = 0; P.k_planes = 0;
     P.thresh = 0; P.scale = 1.0f; P.seed = 0; P.offset = 0;
-    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride; P.epoch = nullptr;
+    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride; P.epoch = nullptr; P.replicas = 1;
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);

@@ -241,6 +241,7 @@ def branches(fns, kind=""):
 # NCHW: MIOpen GEMM + one element-wise pass each for bias / residual / ReLU, plus a layout pass in front of every 3x3.  On
 # pod_conv1x1_split (csrc/k13_conv1x1_split.hip: channels-last GEMM, bias + residual + ReLU in the store, same exact-split products as
 # the 3x3 kernel) a bottleneck is three launches on (pixels, C) buffers and the whole trunk stays channels-last from the max-pool on.
+FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0"     # the first conv of an MC-dropout subnet stores its masked replicas itself
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
 
 
@@ -515,8 +516,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
         lib, C = hip.load(), x0.shape[1]
         t1 = block_table(levels, 1, x0.device)
         off1 = level_pixel_offsets(levels, 1)
-        y = self._wino(convs[0])(x0, torch.empty_like(x0), t1, relu=True)          # identical for every copy: computed once
+        first = self._wino(convs[0])
         if not dropout:
+            y = first(x0, torch.empty_like(x0), t1, relu=True)
             for conv in convs[1:]:
                 y = self._wino(conv)(y, torch.empty_like(y), t1, relu=True)
             return y, 1
@@ -524,17 +526,27 @@ class ProbabilisticRetinaNetHead(nn.Module):
         a = torch.empty((offn[-1], C), dtype=x0.dtype, device=x0.device)
         replay = self.dropout_replay is not None
         sid = 0 if convs is self.cls_subnet else 1
+        # The first activation is identical for every copy: computed once, stored `copies` times under the copies' dropout masks.  One
+        # Philox offset for the whole buffer: the mask of an element is keyed by its index in `a`.
+        self._drop_calls += 1
+        p_first = 0.0 if replay else float(self.dropout_rate)
+        if first.split and copies <= 127 and FUSED_REPLICAS:
+            # ... by the conv's own store pass (pod_wino_conv3x3_split_replicas)
+            first.replicas(x0, a, block_table(levels, 1, x0.device, out_copies=copies), copies, relu=True, dropout_p=p_first,
+                           seed=self.dropout_seed, offset=self._drop_calls << 34, epoch=self._epoch)
+        else:
+            # ... or by a pass of its own per level (the fp32-MFMA kernel; the same masks)
+            y = first(x0, torch.empty_like(x0), t1, relu=True)
+            for i, (h, w) in enumerate(levels):
+                hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies, p_first, self.dropout_seed,
+                                                 (self._drop_calls << 34) + offn[i] * C // 8, self._epoch.data_ptr(), hip.current_stream()),
+                          "pod_expand_dropout")
 
         def mask_in_place(buf, layer):              # parity mode: the recorded masks on the channels-last images of the buffer
             for i, (h, w) in enumerate(levels):
                 v = buf[offn[i]:offn[i + 1]].view(copies, h, w, C)
                 v.copy_(self._replayed(v.permute(0, 3, 1, 2), sid, layer, i).permute(0, 2, 3, 1))
 
-        for i, (h, w) in enumerate(levels):                                         # copies x dropout(first activation)
-            self._drop_calls += 1
-            hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), a[offn[i]:].data_ptr(), h * w * C, copies,
-                                             0.0 if replay else float(self.dropout_rate),
-                                             self.dropout_seed, self._drop_calls << 34, self._epoch.data_ptr(), hip.current_stream()), "pod_expand_dropout")
         if replay:
             mask_in_place(a, 0)
         tn = block_table(levels, copies, x0.device)

@@ -144,6 +144,18 @@ class WinoConv:
                      seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
         return dst
 
+    def replicas(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, replicas: int, relu: bool = False, dropout_p: float = 0.0,
+                 seed: int = 0, offset: int = 0, epoch: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """conv + bias (+ ReLU) of ONE image per level, stored `replicas` times with a dropout mask each (pod_wino_conv3x3_split_replicas):
+        table = block_table(levels, 1, out_copies=replicas); dst: the `replicas` images per level, channels-last.  The masks are those
+        of pod_expand_dropout called per level with offset + (first float of the level in dst) / 8 (`expand_offset`)."""
+        assert self.split and self.K == self.Kpad and 1 <= replicas <= 127
+        assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and dst.shape[-1] == self.Kpad and src.dtype == dst.dtype == torch.float32
+        hip.check(hip.load().pod_wino_conv3x3_split_replicas(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
+                                                             table.shape[0], self.C, self.Kpad, 1 if relu else 0, int(replicas), float(dropout_p),
+                                                             seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split_replicas")
+        return dst
+
     def splits_for(self, n_blocks: int, cus: int = 256) -> int:
         """How many ways to cut the input channels of a launch of n_blocks output blocks (pod_wino_conv3x3_split_partial): small maps
         give this tiling too few workgroups for the chip (res5 of a 768 x 1344 frame: 6 blocks x 8 filter slices = 48), each walking all

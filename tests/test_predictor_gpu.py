@@ -176,6 +176,7 @@ class Fp64Conv:
         self.w, self.b = conv.weight.detach().double().cpu(), conv.bias.detach().float()
         self.K, self.C = int(conv.weight.shape[0]), int(conv.weight.shape[1])
         self.Kpad = (self.K + 63) // 64 * 64
+        self.split = False          # (no replicas() here: the head then takes conv + pod_expand_dropout, the same masks as the fused store pass)
 
     def __call__(self, src, dst, table, relu=False, dropout_p=0.0, seed=0, offset=0, planes=False, epoch=None):   # (epoch: 0 in an eager forward, i.e. the plain seed: the masks pod_bias_act draws below)
         import torch.nn.functional as F

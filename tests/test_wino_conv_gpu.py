@@ -216,6 +216,35 @@ def test_dropout_mask_is_the_one_pod_bias_act_draws(split):
     assert 0.5 < dropped < 0.8                                  # ReLU zeroes half, dropout 30 % of the rest
 
 
+@pytest.mark.parametrize("p", [0.25, 0.0])
+@pytest.mark.parametrize("levels,replicas,C,K", [([(20, 28), (5, 7)], 5, 32, 64), ([(96, 168), (12, 21), (6, 11)], 19, 64, 128), ([(17, 33)], 127, 16, 64)])
+def test_replicas_from_the_store_pass_equal_conv_then_expand_dropout(levels, replicas, C, K, p):
+    """pod_wino_conv3x3_split_replicas (the first conv of an MC-dropout subnet writing the runs' masked copies itself) == the conv
+    without dropout followed, level by level, by pod_expand_dropout with offset + (first float of the level) / 8: bit for bit; with
+    p = 0 (parity mode: the recorded masks are applied afterwards) plain copies."""
+    w, b, xs = make(levels, 1, C, K, seed=11)
+    src = flat(xs)
+    conv = WinoConv(w, b, split=True)
+    offn, off1 = level_pixel_offsets(levels, replicas), level_pixel_offsets(levels, 1)
+    fused = torch.full((offn[-1], K), float("nan"), device="cuda")
+    conv.replicas(src, fused, block_table(levels, 1, "cuda", out_copies=replicas), replicas, relu=True, dropout_p=p, seed=77, offset=9 << 34)
+    y = conv(src, torch.empty(src.shape[0], K, device="cuda"), block_table(levels, 1, "cuda"), relu=True)
+    want = torch.full_like(fused, float("nan"))
+    lib = hip.load()
+    for i, (h, wd) in enumerate(levels):
+        hip.check(lib.pod_expand_dropout(y[off1[i]:].data_ptr(), want[offn[i]:].data_ptr(), h * wd * K, replicas, p, 77, (9 << 34) + offn[i] * K // 8, None,
+                                         hip.current_stream()), "pod_expand_dropout")
+    assert torch.equal(fused, want)
+    if p == 0.0:
+        for i, (h, wd) in enumerate(levels):
+            assert torch.equal(fused[offn[i]:offn[i + 1]].view(replicas, h * wd, K), y[off1[i]:off1[i + 1]].expand(replicas, -1, -1))
+    else:
+        first = fused[offn[0]:offn[1]].view(replicas, -1)
+        assert not torch.equal(first[0], first[1])               # every replica its own mask
+    assert lib.pod_wino_conv3x3_split_replicas(src.data_ptr(), fused.data_ptr(), conv.U.data_ptr(), conv.bias.data_ptr(), block_table(levels, 1, "cuda").data_ptr(), 1, C, K, 1,
+                                               128, 0.0, 0, 0, None, hip.current_stream()) == -1        # replicas <= 127
+
+
 @pytest.mark.parametrize("H,W,C,K,splits", [(24, 42, 512, 512, 4), (48, 84, 256, 256, 2), (24, 42, 256, 256, 4), (6, 11, 128, 64, 2), (13, 17, 64, 36, 2)])
 def test_small_maps_split_over_the_input_channels(H, W, C, K, splits):
     """pod_wino_conv3x3_split_partial + pod_wino_reduce (backbone convolutions on small maps: res4 / res5 / p4 / p5): the input channels
