@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 9
+#define POD_ABI_VERSION 10
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -371,6 +371,18 @@ int pod_wino_conv3x3_split_partial(const float* in, float* partials, const void*
                                    int32_t K, int32_t n_splits, int64_t split_stride, pod_stream_t stream);
 int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
                     int32_t K, int32_t k_real, int32_t relu, pod_stream_t stream);
+
+/* ---- the ResNet stem, channels-last (round 4; ABI 10; csrc/k14_stem_conv.hip) -------------------------------------------
+ * Replaces detectron2's BasicStem as probabilistic_retinanet.py:96-100 runs it (`features = self.backbone(images.tensor)`):
+ * conv1 (7x7, stride 2, padding 3, 3 -> 64 channels, FrozenBN folded into weight + bias) + ReLU, then max_pool2d(3, 2, 1).
+ * pod_stem7x7_filter_split: weight (64, 3, 7, 7) fp32 -> Ws, 3 * 64 * 192 bf16 values (the window padded to 8 x 8 with zeros, three exact
+ * bf16 terms per value).  pod_stem7x7_split: x = the normalised, padded image as (3, H, W) fp32 planes -> y ((H-1)/2+1) x ((W-1)/2+1)
+ * pixels x 64 channels, channels-last; every fp32 product from exact 3-way bf16 splits of both operands (pod_conv1x1_split's
+ * arithmetic).  pod_maxpool3x3s2_cl: (H * W, C) channels-last -> ((H-1)/2+1) x ((W-1)/2+1) x C, C % 4 == 0; taps outside the map do not
+ * take part (torch's -inf padding). */
+int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream);
+int pod_stem7x7_split(const float* x, float* y, const void* Ws, const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream);
+int pod_maxpool3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

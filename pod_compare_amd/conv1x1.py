@@ -60,3 +60,38 @@ class Conv1x1:
         hip.check(hip.load().pod_conv1x1_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), hip.ptr(residual), ho, wo, h, w, self.stride,
                                                self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), hip.current_stream()), "pod_conv1x1_split")
         return y
+
+
+class Stem7x7:
+    """The ResNet stem conv (7x7, stride 2, padding 3, 3 -> 64 channels; FrozenBN folded into weight + bias) with its weight split once:
+    (1, 3, H, W) fp32 planes -> ((H-1)//2+1) x ((W-1)//2+1) pixels x 64 channels, channels-last (pod_stem7x7_split)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        assert weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape) == (64, 3, 7, 7)
+        self.Ws = torch.empty(3 * 64 * 192, dtype=torch.int16, device=weight.device)
+        hip.check(hip.load().pod_stem7x7_filter_split(weight.detach().contiguous().data_ptr(), self.Ws.data_ptr(), hip.current_stream()), "pod_stem7x7_filter_split")
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().clone()
+
+    @staticmethod
+    def eligible(conv: Optional[torch.nn.Conv2d]) -> bool:
+        return (conv is not None and tuple(conv.weight.shape) == (64, 3, 7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3)
+                and conv.groups == 1 and tuple(conv.dilation) == (1, 1))
+
+    def __call__(self, x: torch.Tensor, relu: bool = True):
+        """x: (1, 3, H, W) or (3, H, W), contiguous -> (y (Ho * Wo, 64), Ho, Wo)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == 3 * x.shape[-2] * x.shape[-1]
+        h, w = int(x.shape[-2]), int(x.shape[-1])
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((ho * wo, 64), dtype=torch.float32, device=x.device)
+        hip.check(hip.load().pod_stem7x7_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), h, w, 1 if relu else 0, hip.current_stream()),
+                  "pod_stem7x7_split")
+        return y, ho, wo
+
+
+def maxpool3x3s2_cl(x: torch.Tensor, h: int, w: int):
+    """max_pool2d(kernel 3, stride 2, padding 1) of a channels-last map (h * w, C) -> (y (hp * wp, C), hp, wp)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == h * w and x.shape[1] % 4 == 0
+    hp, wp = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((hp * wp, x.shape[1]), dtype=torch.float32, device=x.device)
+    hip.check(hip.load().pod_maxpool3x3s2_cl(x.data_ptr(), y.data_ptr(), h, w, int(x.shape[1]), hip.current_stream()), "pod_maxpool3x3s2_cl")
+    return y, hp, wp

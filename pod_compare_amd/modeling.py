@@ -243,6 +243,7 @@ def branches(fns, kind=""):
 # the 3x3 kernel) a bottleneck is three launches on (pixels, C) buffers and the whole trunk stays channels-last from the max-pool on.
 FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0"     # the first conv of an MC-dropout subnet stores its masked replicas itself
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
+HIP_STEM = __import__("os").environ.get("POD_HIP_STEM", "1") != "0"         # the 7x7 stem + max-pool of the channels-last trunk on pod_stem7x7_split / pod_maxpool3x3s2_cl
 
 
 def c1_of(conv: nn.Conv2d):
@@ -254,6 +255,18 @@ def c1_of(conv: nn.Conv2d):
         cached = (key, Conv1x1(conv.weight, conv.bias, conv.stride[0]))
         torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
         conv._pod_c1 = cached
+    return cached[1]
+
+
+def stem_of(conv: nn.Conv2d):
+    """The stem conv's pod_stem7x7_split form (weight split once), refreshed when the parameters change."""
+    from .conv1x1 import Stem7x7
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+    cached = getattr(conv, "_pod_stem", None)
+    if cached is None or cached[0] != key:
+        cached = (key, Stem7x7(conv.weight, conv.bias))
+        torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
+        conv._pod_stem = cached
     return cached[1]
 
 
@@ -362,10 +375,16 @@ class ResNet50(nn.Module):
 
     def forward_cl(self, x):
         """Channels-last from the max-pool on: returns [(c3, h, w), (c4, h, w), (c5, h, w)] with c* (h * w, C) buffers."""
-        x = conv_bias_act(self.stem, x, relu=True)                       # 7x7 / stride 2: MIOpen, NCHW
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        h, w = int(x.shape[2]), int(x.shape[3])
-        t = nchw_as_cl(x)
+        stem = _plain_conv(self.stem)
+        from .conv1x1 import Stem7x7, maxpool3x3s2_cl
+        if HIP_STEM and stem is not None and stem.bias is not None and Stem7x7.eligible(stem) and x.shape[0] == 1 and x.is_contiguous():
+            t, h, w = stem_of(stem)(x, relu=True)                        # 7x7 / stride 2 on pod_stem7x7_split: channels-last out
+            t, h, w = maxpool3x3s2_cl(t, h, w)
+        else:
+            x = conv_bias_act(self.stem, x, relu=True)                   # MIOpen, NCHW
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+            h, w = int(x.shape[2]), int(x.shape[3])
+            t = nchw_as_cl(x)
         outs = []
         for stage in (self.res2, self.res3, self.res4, self.res5):
             for block in stage:
