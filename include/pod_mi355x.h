@@ -376,12 +376,15 @@ int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_strid
  * Replaces detectron2's BasicStem as probabilistic_retinanet.py:96-100 runs it (`features = self.backbone(images.tensor)`):
  * conv1 (7x7, stride 2, padding 3, 3 -> 64 channels, FrozenBN folded into weight + bias) + ReLU, then max_pool2d(3, 2, 1).
  * pod_stem7x7_filter_split: weight (64, 3, 7, 7) fp32 -> Ws, 3 * 64 * 192 bf16 values (the window padded to 8 x 8 with zeros, three exact
- * bf16 terms per value).  pod_stem7x7_split: x = the normalised, padded image as (3, H, W) fp32 planes -> y ((H-1)/2+1) x ((W-1)/2+1)
- * pixels x 64 channels, channels-last; every fp32 product from exact 3-way bf16 splits of both operands (pod_conv1x1_split's
- * arithmetic).  pod_maxpool3x3s2_cl: (H * W, C) channels-last -> ((H-1)/2+1) x ((W-1)/2+1) x C, C % 4 == 0; taps outside the map do not
- * take part (torch's -inf padding). */
+ * bf16 terms per value).  pod_stem7x7_split: x = the frame as (3, H_img, W_img) planes, fp32 or uint8 (x_is_u8); mean / stddev non-null:
+ * the kernel normalises on load, (x - mean[c]) / stddev[c] in fp32 as PR:96's `self.normalizer` does (null: x is normalised already);
+ * H x W >= H_img x W_img is the padded extent ImageList.from_tensors gives the frame (zeros outside the frame, as its padding and the
+ * conv's own are) -> y ((H-1)/2+1) x ((W-1)/2+1) pixels x 64 channels, channels-last; every fp32 product from exact 3-way bf16 splits of
+ * both operands (pod_conv1x1_split's arithmetic).  pod_maxpool3x3s2_cl: (H * W, C) channels-last -> ((H-1)/2+1) x ((W-1)/2+1) x C,
+ * C % 4 == 0; taps outside the map do not take part (torch's -inf padding). */
 int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream);
-int pod_stem7x7_split(const float* x, float* y, const void* Ws, const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream);
+int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, int32_t W_img, const float* mean, const float* stddev, float* y, const void* Ws,
+                      const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream);
 int pod_maxpool3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------

@@ -77,14 +77,20 @@ class Stem7x7:
         return (conv is not None and tuple(conv.weight.shape) == (64, 3, 7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3)
                 and conv.groups == 1 and tuple(conv.dilation) == (1, 1))
 
-    def __call__(self, x: torch.Tensor, relu: bool = True):
-        """x: (1, 3, H, W) or (3, H, W), contiguous -> (y (Ho * Wo, 64), Ho, Wo)."""
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == 3 * x.shape[-2] * x.shape[-1]
-        h, w = int(x.shape[-2]), int(x.shape[-1])
+    def __call__(self, x: torch.Tensor, relu: bool = True, mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None,
+                 padded_hw: Optional[tuple] = None):
+        """x: (1, 3, H, W) or (3, H, W), contiguous, fp32 or uint8 -> (y (Ho * Wo, 64), Ho, Wo).  mean / std (3 floats each): the frame is
+        normalised on load; padded_hw: the extent the frame is zero-padded to (the output's size follows it)."""
+        assert x.is_cuda and x.dtype in (torch.float32, torch.uint8) and x.is_contiguous() and x.numel() == 3 * x.shape[-2] * x.shape[-1]
+        hi, wi = int(x.shape[-2]), int(x.shape[-1])
+        h, w = (hi, wi) if padded_hw is None else (int(padded_hw[0]), int(padded_hw[1]))
+        assert (mean is None) == (std is None) and h >= hi and w >= wi
+        if mean is not None:
+            assert mean.is_cuda and std.is_cuda and mean.dtype == std.dtype == torch.float32 and mean.numel() == std.numel() == 3 and mean.is_contiguous() and std.is_contiguous()
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty((ho * wo, 64), dtype=torch.float32, device=x.device)
-        hip.check(hip.load().pod_stem7x7_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), h, w, 1 if relu else 0, hip.current_stream()),
-                  "pod_stem7x7_split")
+        hip.check(hip.load().pod_stem7x7_split(x.data_ptr(), 1 if x.dtype == torch.uint8 else 0, hi, wi, hip.ptr(mean), hip.ptr(std), y.data_ptr(), self.Ws.data_ptr(),
+                                               hip.ptr(self.bias), h, w, 1 if relu else 0, hip.current_stream()), "pod_stem7x7_split")
         return y, ho, wo
 
 

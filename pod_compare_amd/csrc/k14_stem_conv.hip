@@ -23,7 +23,10 @@ constexpr int ST_KS = 12;                 // k-steps
 constexpr int ST_PR = 22, ST_PC = 24;     // patch rows (2 * 7 + 7 + 1), columns (2 * 7 + 8, padded to 24)
 
 struct StemParams {
-    const float* x;           // (3, H, W) planes
+    const void* x;            // (3, Hi, Wi) planes: fp32, or uint8 (x_u8) -- the frame as the data loader hands it over
+    const float* mean;        // per-channel pixel mean / std (PR:96 `self.normalizer`): the patch load computes (x - mean) / std, in fp32 as torch
+    const float* std_;        //   does; null: x is already normalised
+    int32_t Hi, Wi, x_u8;     // extent of x; outside it -- the zero padding of the conv AND the frame's padding to a multiple of 32 -- the input is 0
     float* y;                 // (Ho * Wo, 64) channels-last
     const uint16_t* Ws;       // pre-split filter: [cout block 2][k-step 12][term 3][h 2][i32 32][8 bf16]
     const float* bias;
@@ -65,7 +68,13 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
         for (int e = lane; e < 3 * ST_PR * ST_PC; e += 64) {
             const int c = e / (ST_PR * ST_PC), r = (e - c * ST_PR * ST_PC) / ST_PC, col = e - c * ST_PR * ST_PC - r * ST_PC;
             const int iy = iy0 + r, ix = ix0 + col;
-            lds[e] = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? P.x[((int64_t)c * P.H + iy) * P.W + ix] : 0.f;
+            float v = 0.f;
+            if (iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi) {
+                const int64_t at = ((int64_t)c * P.Hi + iy) * P.Wi + ix;
+                v = P.x_u8 ? (float)static_cast<const uint8_t*>(P.x)[at] : static_cast<const float*>(P.x)[at];
+                if (P.mean) v = (v - P.mean[c]) / P.std_[c];
+            }
+            lds[e] = v;
         }
     }
     const uint16_t* __restrict__ const wa = P.Ws + (h * 32 + i32) * 8;          // + cb * 12 * 1536 + ks * 1536 + term * 512
@@ -189,12 +198,17 @@ extern "C" int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_strea
     return POD_OK;
 }
 
-extern "C" int pod_stem7x7_split(const float* x, float* y, const void* Ws, const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream) {
-    if (!x || !y || !Ws || x == y || H < 1 || W < 1 || H > 16384 || W > 16384) return POD_E_INVALID;
-    if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias)) & 15u) != 0 || (reinterpret_cast<uintptr_t>(x) & 3u) != 0)
+extern "C" int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, int32_t W_img, const float* mean, const float* stddev, float* y, const void* Ws,
+                                 const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream) {
+    if (!x || !y || !Ws || x == static_cast<const void*>(y) || H < 1 || W < 1 || H > 16384 || W > 16384 || H_img < 1 || W_img < 1 || H_img > H || W_img > W)
+        return POD_E_INVALID;
+    if ((mean == nullptr) != (stddev == nullptr)) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias)) & 15u) != 0 ||
+        (!x_is_u8 && (reinterpret_cast<uintptr_t>(x) & 3u) != 0))
         return POD_E_INVALID;
     pod::StemParams P;
-    P.x = x; P.y = y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.H = H; P.W = W; P.relu = relu;
+    P.x = x; P.x_u8 = x_is_u8 ? 1 : 0; P.Hi = H_img; P.Wi = W_img; P.mean = mean; P.std_ = stddev;
+    P.y = y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.H = H; P.W = W; P.relu = relu;
     P.Ho = (H - 1) / 2 + 1; P.Wo = (W - 1) / 2 + 1;
     P.tiles_x = (P.Wo + 7) / 8;
     const int64_t grid = (int64_t)P.tiles_x * ((P.Ho + 7) / 8);

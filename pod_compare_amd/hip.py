@@ -119,7 +119,7 @@ def load() -> ctypes.CDLL:
     lib.pod_wino_reduce.argtypes = [P, c_int32, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P]
     lib.pod_reduce_partials.argtypes = [P, c_int32, c_int64, P, P, P, c_int64, c_int32, c_int32, P]
     lib.pod_stem7x7_filter_split.argtypes = [P, P, P]
-    lib.pod_stem7x7_split.argtypes = [P, P, P, P, c_int32, c_int32, c_int32, P]
+    lib.pod_stem7x7_split.argtypes = [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32, c_int32, c_int32, P]
     lib.pod_maxpool3x3s2_cl.argtypes = [P, P, c_int32, c_int32, c_int32, P]
     lib.pod_conv1x1_filter_split.argtypes = [P, P, c_int32, c_int32, P]
     lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, P]

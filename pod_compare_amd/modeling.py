@@ -243,6 +243,7 @@ def branches(fns, kind=""):
 # the 3x3 kernel) a bottleneck is three launches on (pixels, C) buffers and the whole trunk stays channels-last from the max-pool on.
 FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0"     # the first conv of an MC-dropout subnet stores its masked replicas itself
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
+FUSED_PREPROCESS = __import__("os").environ.get("POD_FUSED_PREPROCESS", "1") != "0"   # ... which then also normalises and pads the frame on load
 HIP_STEM = __import__("os").environ.get("POD_HIP_STEM", "1") != "0"         # the 7x7 stem + max-pool of the channels-last trunk on pod_stem7x7_split / pod_maxpool3x3s2_cl
 
 
@@ -373,11 +374,21 @@ class ResNet50(nn.Module):
     def cl_eligible(self) -> bool:
         return all(b.cl_eligible() for stage in (self.res2, self.res3, self.res4, self.res5) for b in stage)
 
-    def forward_cl(self, x):
-        """Channels-last from the max-pool on: returns [(c3, h, w), (c4, h, w), (c5, h, w)] with c* (h * w, C) buffers."""
+    def hip_stem_ok(self) -> bool:
+        from .conv1x1 import Stem7x7
         stem = _plain_conv(self.stem)
-        from .conv1x1 import Stem7x7, maxpool3x3s2_cl
-        if HIP_STEM and stem is not None and stem.bias is not None and Stem7x7.eligible(stem) and x.shape[0] == 1 and x.is_contiguous():
+        return HIP_STEM and stem is not None and stem.bias is not None and Stem7x7.eligible(stem)
+
+    def forward_cl(self, x, frame=None):
+        """Channels-last from the stem on: returns [(c3, h, w), (c4, h, w), (c5, h, w)] with c* (h * w, C) buffers.  frame = (image (3, h, w)
+        uint8 / fp32 on the device, pixel mean, pixel std, padded (h, w)) instead of x: the stem kernel normalises and pads on load."""
+        stem = _plain_conv(self.stem)
+        from .conv1x1 import maxpool3x3s2_cl
+        if frame is not None:
+            img, mean, std, padded = frame
+            t, h, w = stem_of(stem)(img, relu=True, mean=mean, std=std, padded_hw=padded)
+            t, h, w = maxpool3x3s2_cl(t, h, w)
+        elif self.hip_stem_ok() and x.shape[0] == 1 and x.is_contiguous():
             t, h, w = stem_of(stem)(x, relu=True)                        # 7x7 / stride 2 on pod_stem7x7_split: channels-last out
             t, h, w = maxpool3x3s2_cl(t, h, w)
         else:
@@ -805,14 +816,20 @@ class ProbabilisticRetinaNet(nn.Module):
         return self._cl_ok
 
     def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
-        x = self.preprocess_image(image)
-        if self._cl_backbone(x):
-            feats = self.fpn.forward_cl(self.bottom_up.forward_cl(x))      # channels-last trunk on pod_conv1x1_split + pod_wino_conv3x3[_split]
+        if (FUSED_PREPROCESS and image.is_cuda and image.device == self.device and image.dim() == 3 and image.shape[0] == 3 and image.is_contiguous()
+                and image.dtype in (torch.uint8, torch.float32) and self._cl_backbone(self.pixel_mean) and self.bottom_up.hip_stem_ok()):
+            # the frame as the loader hands it over: pod_stem7x7_split normalises ((x - mean) / std, PR:96) and pads on load
+            padded = _anchors.padded_size(int(image.shape[1]), int(image.shape[2]))
+            feats = self.fpn.forward_cl(self.bottom_up.forward_cl(None, frame=(image, self.pixel_mean.reshape(3), self.pixel_std.reshape(3), padded)))
         else:
-            feats = self.fpn(self.bottom_up(x))
+            x = self.preprocess_image(image)
+            if self._cl_backbone(x):
+                feats = self.fpn.forward_cl(self.bottom_up.forward_cl(x))      # channels-last trunk on pod_conv1x1_split + pod_wino_conv3x3[_split]
+            else:
+                feats = self.fpn(self.bottom_up(x))
+            padded = tuple(x.shape[-2:])
         cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
                                                  skip_unused_last_run=skip_unused_last_run)
-        padded = tuple(x.shape[-2:])
         shapes = [tuple(f.shape[-2:]) for f in feats]
         skipped = skip_unused_last_run and n > 1 and bool(mc_dropout) and self.use_dropout
         return HeadOutputs(cls, delta, cls_var, reg_var, self.anchors_for(padded), shapes, self.num_anchors,
