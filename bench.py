@@ -195,7 +195,18 @@ def conv_census(model, img, N, quirk, dev):
         calls.append(("1x1_hip", 2.0 * y.shape[0] * self.C * self.K, e0, e1))
         return y
 
+    real_stem = conv1x1.Stem7x7.__call__
+
+    def probe_stem(self, x, **kw):                       # pod_stem7x7_split (frame normalisation + padding + conv + ReLU)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_stem(self, x, **kw)
+        e1.record()
+        calls.append(("stem_7x7_hip", 2.0 * y[1] * y[2] * 64 * 147, e0, e1))
+        return y
+
     reps = 3
+    conv1x1.Stem7x7.__call__ = probe_stem
     F.conv2d = probe
     wino.WinoConv.__call__ = probe_wino
     wino.WinoConv.planes_of_one_image = probe_planes
@@ -215,6 +226,7 @@ def conv_census(model, img, N, quirk, dev):
         wino.WinoConv.planes_of_one_image = real_planes
         wino.WinoConv.channels_last_of_one_image = real_cl
         conv1x1.Conv1x1.__call__ = real_c1
+        conv1x1.Stem7x7.__call__ = real_stem
     out = {}
     for cat, flops, e0, e1 in calls:
         d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
@@ -527,7 +539,7 @@ def main():
                                      "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
                                      "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
                    "rng": "in-kernel Philox4x32-10, fresh key per image",
-                   "backbone": ("channels-last on pod_conv1x1_split + pod_wino_conv3x3_split (stem, max-pool, p6 / p7: PyTorch-ROCm)"
+                   "backbone": ("channels-last from the frame on: pod_stem7x7_split + pod_maxpool3x3s2_cl, pod_conv1x1_split, pod_wino_conv3x3_split (p6 / p7: PyTorch-ROCm)"
                                 if (modeling.CL_BACKBONE and args.split_bf16) else "NCHW: 1x1 / strided convolutions on PyTorch-ROCm, 3x3 / stride-1 on the Winograd kernel"),
                    "model_forward": "HIP graph replay per (stream, shape)" if (not args.no_graphs and not args.no_cnn) else "eager launches from Python"},
         "per_rank_images_per_s": per_rank, "flush_ms": flush_ms if multi else None, "host_enqueue_ms_per_image": host_enqueue_ms,
