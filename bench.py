@@ -170,6 +170,16 @@ def conv_census(model, img, N, quirk, dev):
         calls.append((cat, 2.0 * table.pod_pixels * self.C * self.K * 9, e0, e1))   # direct-convolution FLOPs
         return y
 
+    real_rep = wino.WinoConv.replicas
+
+    def probe_rep(self, src, dst, table, replicas, **kw):     # the first conv of an MC-dropout subnet: evaluated once, stored `replicas` times
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_rep(self, src, dst, table, replicas, **kw)
+        e1.record()
+        calls.append(("3x3_head_winograd_hip", 2.0 * src.shape[0] * self.C * self.K * 9, e0, e1))
+        return y
+
     real_cl = wino.WinoConv.channels_last_of_one_image
 
     def probe_cl(self, src, table, **kw):               # the same convolutions in the channels-last backbone
@@ -207,6 +217,7 @@ def conv_census(model, img, N, quirk, dev):
 
     reps = 3
     conv1x1.Stem7x7.__call__ = probe_stem
+    wino.WinoConv.replicas = probe_rep
     F.conv2d = probe
     wino.WinoConv.__call__ = probe_wino
     wino.WinoConv.planes_of_one_image = probe_planes
@@ -227,6 +238,7 @@ def conv_census(model, img, N, quirk, dev):
         wino.WinoConv.channels_last_of_one_image = real_cl
         conv1x1.Conv1x1.__call__ = real_c1
         conv1x1.Stem7x7.__call__ = real_stem
+        wino.WinoConv.replicas = real_rep
     out = {}
     for cat, flops, e0, e1 in calls:
         d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
