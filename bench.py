@@ -81,8 +81,10 @@ def parse_args():
     ap.add_argument("--synth", default="planted", choices=["planted", "worst"])
     ap.add_argument("--boxes", type=int, default=24, help="planted objects per image (SURVEY 8d: 24); more objects = more candidates")
     ap.add_argument("--no-cnn", action="store_true", help="time the HIP hot path only (diagnostic; not the headline)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d); 0 = the config's default: 2 for the "
+                         "MC-dropout config (its step is K12's head launches; a third image in flight only adds contention: 101.6 - 102.6 against "
+                         "99.6 - 99.7 images/s, profiles/r04_experiments.md), 3 otherwise")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
     ap.add_argument("--fp32-mfma", action="store_true",
@@ -430,7 +432,7 @@ def main():
     D = 4 if spec["reg_var"] else 0
     # one workspace per stream: images are independent units (PI:86-111), so consecutive images go to different HIP streams
     # and the low-occupancy stretches of one image's backbone overlap the other image's head convs
-    n_streams = max(1, args.streams)
+    n_streams = args.streams if args.streams > 0 else (2 if (N > 1 and spec.get("members", 1) == 1) else 3)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     hps = [hotpath.HotPath(heads[0].shapes, heads[0].anchors, params, n_runs=N, has_cls_var=spec["cls_var"], cov_dims=D, device=dev)
            for _ in range(n_streams)]

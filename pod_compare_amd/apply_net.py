@@ -189,8 +189,9 @@ def main(argv=None):
     ap.add_argument("--random-seed", type=int, default=0)
     ap.add_argument("--output", default="coco_instances_results.json")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of a forward from Python instead of replaying a HIP graph per (stream, frame shape)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams per GPU; consecutive images of a rank go to different streams (batch 1 per stream, AN:35)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams per GPU; consecutive images of a rank go to different streams (batch 1 per stream, AN:35); 0 = 2 with "
+                         "MC dropout (several runs per image), 3 otherwise")
     ap.add_argument("--flush-every", type=int, default=64,
                     help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
@@ -242,7 +243,8 @@ def main(argv=None):
                 m.enable_graphs(not getattr(args, "no_graphs", False))      # one host call per dropout-free forward instead of ~200 launches
     # images are independent units: keep a few in flight on separate HIP streams so one image's low-occupancy backbone
     # stretches overlap another image's head convs (+12 % images/s on one MI355X); the predictor keeps a workspace per stream
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(1, args.streams) - 1)]
+    n_streams = args.streams if args.streams > 0 else (2 if (getattr(predictor, "mc_dropout_enabled", False) and getattr(predictor, "num_mc_dropout_runs", 1) > 1) else 3)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
     width = record_width(K)
     dev = cfg.MODEL.DEVICE
     F = max(1, args.flush_every)
