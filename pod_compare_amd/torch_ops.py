@@ -16,6 +16,9 @@ no second implementation and no CPU kernel (calling them with CPU tensors raises
     wino_filter_transform / wino_conv3x3
                  the head's `Conv2d(C, K, 3, padding=1) [+ ReLU + Dropout]` (PR:403-484) for all MC runs and FPN levels in one
                  launch: channels-last activations in, channels-last (trunk) or NCHW planes (predictors) out
+    conv1x1_filter_split / conv1x1_split, stem7x7_filter_split / stem7x7_split, maxpool3x3s2_cl
+                 the channels-last trunk (round 4): the backbone's / FPN's 1x1 convolutions with bias / residual / ReLU in the store, the
+                 7x7 stem taking the frame as loaded (normalisation + padding on load) and its max-pool
 """
 from typing import List, Tuple
 
@@ -34,6 +37,11 @@ _LIB.define("reg_nll(Tensor means, Tensor covs, Tensor gt) -> Tensor")
 _LIB.define("wino_filter_transform(Tensor weight) -> Tensor")
 _LIB.define("wino_conv3x3(Tensor src, Tensor U, Tensor? bias, Tensor blocks, int K, int out_elements, bool planes=False, bool relu=False, "
             "float dropout_p=0.0, int seed=0, int offset=0) -> Tensor")
+_LIB.define("conv1x1_filter_split(Tensor weight) -> Tensor")
+_LIB.define("conv1x1_split(Tensor x, Tensor Ws, Tensor? bias, Tensor? residual, int h, int w, int stride, int cout, bool relu=False, int n_splits=1) -> Tensor")
+_LIB.define("stem7x7_filter_split(Tensor weight) -> Tensor")
+_LIB.define("stem7x7_split(Tensor frame, Tensor Ws, Tensor? bias, Tensor? mean, Tensor? std, int padded_h, int padded_w, bool relu=True) -> Tensor")
+_LIB.define("maxpool3x3s2_cl(Tensor x, int h, int w) -> Tensor")
 
 _PATHS = {}            # key -> [HotPath, anchor identity, the anchor tensors]; insertion order = LRU order
 _MAX_PATHS = 16
@@ -183,7 +191,82 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     return out
 
 
+def _conv1x1_filter_split(weight) -> torch.Tensor:
+    """pod_conv1x1_filter_split: a (Cout, Cin, 1, 1) / (Cout, Cin) fp32 weight as its three exact bf16 terms per value, in the order the kernel
+    loads them (3 * Cout * Cin int16 words).  Cout % 64 == 0, Cin % 16 == 0."""
+    torch._check(weight.is_cuda and weight.dtype == torch.float32 and weight.dim() in (2, 4) and weight.numel() == weight.shape[0] * weight.shape[1],
+                 lambda: "weight: CUDA fp32 (Cout, Cin) or (Cout, Cin, 1, 1)")
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    torch._check(cout >= 64 and cout % 64 == 0 and cin >= 16 and cin % 16 == 0, lambda: "Cout % 64 == 0 and Cin % 16 == 0 required")
+    ws = torch.empty(3 * cout * cin, dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        hip.check(hip.load().pod_conv1x1_filter_split(hip.ptr(weight.contiguous()), hip.ptr(ws), cout, cin, hip.current_stream()), "pod_conv1x1_filter_split")
+    return ws
+
+
+def _conv1x1_split(x, Ws, bias, residual, h, w, stride, cout, relu=False, n_splits=1) -> torch.Tensor:
+    """pod_conv1x1_split on one channels-last image x (h * w, Cin): act(conv1x1(x, stride) + bias + residual) as (h_out * w_out, cout)."""
+    torch._check(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[0] == h * w, lambda: "x: contiguous CUDA fp32 (h * w, Cin)")
+    cin = int(x.shape[1])
+    torch._check(stride in (1, 2) and cout >= 64 and cout % 64 == 0 and cin >= 16 and cin % 16 == 0, lambda: "stride 1 or 2, cout % 64 == 0, Cin % 16 == 0")
+    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 3 * cout * cin, lambda: "Ws: conv1x1_filter_split of a (cout, Cin) weight")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()), lambda: "bias: cout fp32 values")
+    torch._check(residual is None or (residual.is_cuda and residual.dtype == torch.float32 and residual.is_contiguous() and tuple(residual.shape) == (ho * wo, cout)),
+                 lambda: "residual: contiguous (h_out * w_out, cout) fp32")
+    nks = cin // 16
+    torch._check(1 <= n_splits <= 16 and nks % n_splits == 0, lambda: "n_splits must divide Cin / 16 (1 .. 16)")
+    y = torch.empty((ho * wo, cout), dtype=torch.float32, device=x.device)
+    partials = torch.empty((n_splits, ho * wo, cout), dtype=torch.float32, device=x.device) if n_splits > 1 else None
+    with torch.cuda.device(x.device):
+        hip.check(hip.load().pod_conv1x1_split(hip.ptr(x), hip.ptr(y), hip.ptr(Ws), hip.ptr(bias), hip.ptr(residual), ho, wo, int(h), int(w), int(stride), cin, int(cout),
+                                               1 if relu else 0, int(n_splits), hip.ptr(partials), hip.current_stream()), "pod_conv1x1_split")
+    return y
+
+
+def _stem7x7_filter_split(weight) -> torch.Tensor:
+    torch._check(weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape) == (64, 3, 7, 7), lambda: "weight: CUDA fp32 (64, 3, 7, 7)")
+    ws = torch.empty(3 * 64 * 192, dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        hip.check(hip.load().pod_stem7x7_filter_split(hip.ptr(weight.contiguous()), hip.ptr(ws), hip.current_stream()), "pod_stem7x7_filter_split")
+    return ws
+
+
+def _stem7x7_split(frame, Ws, bias, mean, std, padded_h, padded_w, relu=True) -> torch.Tensor:
+    """pod_stem7x7_split: frame (3, H, W) uint8 / fp32 -> ((padded_h - 1) // 2 + 1) * ((padded_w - 1) // 2 + 1) pixels x 64 channels, channels-last;
+    mean / std (3 values each) given: normalised on load."""
+    torch._check(frame.is_cuda and frame.dtype in (torch.uint8, torch.float32) and frame.dim() == 3 and frame.shape[0] == 3 and frame.is_contiguous(),
+                 lambda: "frame: contiguous CUDA uint8 / fp32 (3, H, W)")
+    hi, wi = int(frame.shape[1]), int(frame.shape[2])
+    torch._check(padded_h >= hi and padded_w >= wi and padded_h <= 16384 and padded_w <= 16384, lambda: "padded extent must contain the frame (<= 16384)")
+    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 3 * 64 * 192, lambda: "Ws: stem7x7_filter_split of the (64, 3, 7, 7) weight")
+    torch._check((mean is None) == (std is None), lambda: "mean and std: both or neither")
+    for t in (mean, std):
+        torch._check(t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == 3 and t.is_contiguous()), lambda: "mean / std: 3 contiguous CUDA fp32 values")
+    torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == 64 and bias.is_contiguous()), lambda: "bias: 64 fp32 values")
+    ho, wo = (int(padded_h) - 1) // 2 + 1, (int(padded_w) - 1) // 2 + 1
+    y = torch.empty((ho * wo, 64), dtype=torch.float32, device=frame.device)
+    with torch.cuda.device(frame.device):
+        hip.check(hip.load().pod_stem7x7_split(hip.ptr(frame), 1 if frame.dtype == torch.uint8 else 0, hi, wi, hip.ptr(mean), hip.ptr(std), hip.ptr(y), hip.ptr(Ws),
+                                               hip.ptr(bias), int(padded_h), int(padded_w), 1 if relu else 0, hip.current_stream()), "pod_stem7x7_split")
+    return y
+
+
+def _maxpool3x3s2_cl(x, h, w) -> torch.Tensor:
+    torch._check(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[0] == h * w and x.shape[1] % 4 == 0 and x.shape[1] >= 4,
+                 lambda: "x: contiguous CUDA fp32 (h * w, C), C % 4 == 0")
+    y = torch.empty((((h - 1) // 2 + 1) * ((w - 1) // 2 + 1), x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        hip.check(hip.load().pod_maxpool3x3s2_cl(hip.ptr(x), hip.ptr(y), int(h), int(w), int(x.shape[1]), hip.current_stream()), "pod_maxpool3x3s2_cl")
+    return y
+
+
 _IMPL = torch.library.Library("pod_mi355x", "IMPL")
+_IMPL.impl("conv1x1_filter_split", _conv1x1_filter_split, "CUDA")
+_IMPL.impl("conv1x1_split", _conv1x1_split, "CUDA")
+_IMPL.impl("stem7x7_filter_split", _stem7x7_filter_split, "CUDA")
+_IMPL.impl("stem7x7_split", _stem7x7_split, "CUDA")
+_IMPL.impl("maxpool3x3s2_cl", _maxpool3x3s2_cl, "CUDA")
 _IMPL.impl("predict", _predict, "CUDA")
 _IMPL.impl("nms_cluster", _nms_cluster, "CUDA")
 _IMPL.impl("reg_nll", _reg_nll, "CUDA")

@@ -106,3 +106,36 @@ def test_wino_conv_operator_equals_conv2d():
         torch.ops.pod_mi355x.wino_conv3x3(src.cpu(), U, b, table, K, src.shape[0] * 64)
     with pytest.raises(Exception):
         torch.ops.pod_mi355x.wino_conv3x3(src, U[:-1], b, table, K, src.shape[0] * 64)
+
+
+def test_trunk_operators_equal_conv2d_and_max_pool():
+    """torch.ops.pod_mi355x.{conv1x1_filter_split, conv1x1_split, stem7x7_filter_split, stem7x7_split, maxpool3x3s2_cl}: the channels-last
+    trunk's kernels as operators, against torch on the same tensors."""
+    import torch.nn.functional as F
+    ops = torch.ops.pod_mi355x
+    g = torch.Generator(device="cuda").manual_seed(8)
+    frame = torch.randint(0, 256, (3, 70, 122), dtype=torch.uint8, device="cuda", generator=g)
+    mean, std = torch.tensor([103.53, 116.28, 123.675], device="cuda"), torch.tensor([1.0, 57.0, 58.0], device="cuda")
+    w7 = torch.randn(64, 3, 7, 7, device="cuda", generator=g) * 0.1
+    b7 = torch.randn(64, device="cuda", generator=g)
+    y = ops.stem7x7_split(frame, ops.stem7x7_filter_split(w7), b7, mean, std, 96, 128, relu=True)
+    x = F.pad((frame.float() - mean.view(3, 1, 1)) / std.view(3, 1, 1), (0, 128 - 122, 0, 96 - 70)).unsqueeze(0)
+    want = F.conv2d(x, w7, b7, stride=2, padding=3).relu()
+    assert tuple(y.shape) == (48 * 64, 64)
+    assert float((y.view(1, 48, 64, 64).permute(0, 3, 1, 2) - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    p = ops.maxpool3x3s2_cl(y, 48, 64)
+    assert torch.equal(p.view(1, 24, 32, 64).permute(0, 3, 1, 2), F.max_pool2d(y.view(1, 48, 64, 64).permute(0, 3, 1, 2), 3, 2, 1))
+    w1 = torch.randn(128, 64, 1, 1, device="cuda", generator=g) * 0.2
+    b1 = torch.randn(128, device="cuda", generator=g)
+    ws = ops.conv1x1_filter_split(w1)
+    res = torch.randn(12 * 16, 128, device="cuda", generator=g)
+    for splits in (1, 2):
+        z = ops.conv1x1_split(p, ws, b1, res, 24, 32, 2, 128, relu=True, n_splits=splits)
+        wantz = (F.conv2d(p.view(1, 24, 32, 64).permute(0, 3, 1, 2), w1, b1, stride=2) + res.view(1, 12, 16, 128).permute(0, 3, 1, 2)).relu()
+        assert float((z.view(1, 12, 16, 128).permute(0, 3, 1, 2) - wantz).abs().max()) <= 2e-5 * max(1.0, float(wantz.abs().max()))
+    for bad in (lambda: ops.conv1x1_split(p.cpu(), ws, b1, None, 24, 32, 1, 128), lambda: ops.conv1x1_split(p, ws[:-1], b1, None, 24, 32, 1, 128),
+                lambda: ops.conv1x1_split(p, ws, b1, None, 24, 32, 3, 128), lambda: ops.conv1x1_split(p, ws, b1, None, 24, 32, 1, 128, n_splits=3),
+                lambda: ops.stem7x7_split(frame, ops.stem7x7_filter_split(w7), b7, mean, None, 96, 128), lambda: ops.stem7x7_split(frame, ops.stem7x7_filter_split(w7), b7, None, None, 64, 128),
+                lambda: ops.maxpool3x3s2_cl(y, 48, 63)):
+        with pytest.raises(Exception):
+            bad()
