@@ -815,7 +815,8 @@ class ProbabilisticRetinaNet(nn.Module):
             self._cl_ok = self.bottom_up.cl_eligible() and self.fpn.cl_eligible()       # (cached once true: folding is one-way)
         return self._cl_ok
 
-    def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
+    def _trunk_eager(self, image: torch.Tensor):
+        """Frame -> (the five FPN maps, padded (h, w)): everything ahead of the head."""
         if (FUSED_PREPROCESS and image.is_cuda and image.device == self.device and image.dim() == 3 and image.shape[0] == 3 and image.is_contiguous()
                 and image.dtype in (torch.uint8, torch.float32) and self._cl_backbone(self.pixel_mean) and self.bottom_up.hip_stem_ok()):
             # the frame as the loader hands it over: pod_stem7x7_split normalises ((x - mean) / std, PR:96) and pads on load
@@ -828,12 +829,19 @@ class ProbabilisticRetinaNet(nn.Module):
             else:
                 feats = self.fpn(self.bottom_up(x))
             padded = tuple(x.shape[-2:])
+        return feats, padded
+
+    def _head_eager(self, feats, padded, image_hw, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
         cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
                                                  skip_unused_last_run=skip_unused_last_run)
         shapes = [tuple(f.shape[-2:]) for f in feats]
         skipped = skip_unused_last_run and n > 1 and bool(mc_dropout) and self.use_dropout
         return HeadOutputs(cls, delta, cls_var, reg_var, self.anchors_for(padded), shapes, self.num_anchors,
-                           self.num_classes, tuple(image.shape[-2:]), last_run_valid=not skipped)
+                           self.num_classes, tuple(image_hw), last_run_valid=not skipped)
+
+    def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
+        feats, padded = self._trunk_eager(image)
+        return self._head_eager(feats, padded, image.shape[-2:], n, mc_dropout, skip_unused_last_run)
 
 
 def resize_test_image(image: torch.Tensor, min_size: int = 800, max_size: int = 1333) -> torch.Tensor:
