@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 10
+#define POD_ABI_VERSION 11
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -362,6 +362,17 @@ int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const fl
 int pod_wino_conv3x3_split_replicas(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                     int32_t C, int32_t K, int32_t relu, int32_t replicas, float p, uint64_t seed, uint64_t offset,
                                     const uint64_t* epoch, pod_stream_t stream);
+/* Up to four convolutions of ONE shape in one grid (round 4; ABI 11): the cls- and the bbox-subnet layer l of the head (PR:403-427), their
+ * first layers with the replicas, the four predictors (PR:430-484).  The kernel runs one workgroup per CU, so a launch costs whole rounds
+ * of 256 workgroups: two launches of 1.5 rounds cost 4, one of 3.0 costs 3.  blocks = the sets' tables concatenated, set s owning blocks
+ * [set_first[s], set_first[s + 1]) (set_first[0] = 0); a record stays relative to ITS set's in[s] / out[s]; every set has its own filter
+ * Us[s], bias[s], Philox offset offsets[s], replica count replicas[s] (0: an ordinary launch; r >= 1: pod_wino_conv3x3_split_replicas'
+ * store pass) and plane count k_planes[s] (0: channels-last out; > 0:
+ * NCHW planes, then p = 0 and no replicas).  C, K, relu, p, seed, epoch are shared.  Bit for bit the n_sets separate launches. */
+int pod_wino_conv3x3_split_grouped(int32_t n_sets, const float* const* in, float* const* out, const void* const* Us, const float* const* bias,
+                                   const int32_t* set_first, const int32_t* replicas, const int32_t* k_planes, const uint64_t* offsets,
+                                   const int32_t* blocks, int32_t n_blocks, int32_t C, int32_t K, int32_t relu, float p, uint64_t seed,
+                                   const uint64_t* epoch, pod_stream_t stream);
 /* Small maps (round 4): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  pod_wino_conv3x3_split_partial
  * cuts the INPUT channels into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): `partials` receives
  * n_splits channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart (K = round_up(real K, 64));

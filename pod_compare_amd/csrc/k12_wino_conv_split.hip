@@ -92,7 +92,16 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     const int chunk0 = (int)blockIdx.y * nchunk;
     const int i32 = lane & 31, h = lane >> 5;
     const int a = __builtin_amdgcn_readfirstlane(wave);
-    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(P.U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
+    // which convolution of a grouped launch this block belongs to: read off the block index alone (no memory in the way of the first
+    // filter loads below)
+    const int set = (tb >= P.sets.first[1] ? 1 : 0) + (tb >= P.sets.first[2] ? 1 : 0) + (tb >= P.sets.first[3] ? 1 : 0);
+    const float* const set_U = P.sets.U[set];
+    const float* const set_in = P.sets.in[set];
+    float* const set_out = P.sets.out[set];
+    const float* const set_bias = P.sets.bias[set];
+    const uint64_t set_offset = P.sets.offset[set];
+    const int set_replicas = P.sets.replicas[set], set_k_planes = P.sets.k_planes[set];
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(set_U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
                                                           nchunk * WINO_US_BYTES, 0x00020000);
     const int u_off = (a * 6 * 6 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*3 + split) KB, + chunk * 144 KB
     vu32x4 uP[3][6];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
@@ -160,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     uint32_t amini[2];                                                    // LDS byte address in mini stage h (the lane's 8 channels of chunk 0): [row0 / row1]; + 16: second half
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) amini[rs] = lds_base + 2 * WINO_SB_FLOATS * 4 + h * 12288 + ((2 * ty + (rs ? row1 : row0)) * 21 + tx) * 32;
-    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in + base_px * P.in_stride + chunk0 * 16), 0,
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(set_in + base_px * P.in_stride + chunk0 * 16), 0,
                                                           n_img * HWi * P.in_stride * 4 - chunk0 * 64, 0x00020000);
     // Where a patch pixel lives in the source: thread t works out pixel t (and t + 256) of the 18 x 18 patch ONCE -- canvas row ->
     // (grid row, row inside the image), canvas column -> (grid column, column) -- and parks its pixel index (-1: outside every image:
@@ -523,8 +532,8 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     return;
 #endif
     constexpr int ZA = 32 * TS;                // floats per position row a
-    float* const out_base = P.out + (int64_t)blockIdx.y * P.split_out_stride;
-    if (P.k_planes > 0) {
+    float* const out_base = set_out + (int64_t)blockIdx.y * P.split_out_stride;
+    if (set_k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
         int m;
@@ -534,15 +543,15 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         for (int e = 0; e < 4; ++e) {
             int n;
             const int gx = cell(x0 + ox + e, Wv, rWv, n), img = m * gcols + n;
-            px0[e] = (n < gcols && img < n_img && gx < W && gy < H) ? (out_px + (int64_t)img * HWi) * P.k_planes + (int64_t)gy * W + gx : -1;
+            px0[e] = (n < gcols && img < n_img && gx < W && gy < H) ? (out_px + (int64_t)img * HWi) * set_k_planes + (int64_t)gy * W + gx : -1;
         }
         const bool vec = px0[0] >= 0 && px0[3] == px0[0] + 3 && (px0[0] & 3) == 0 && (HWi & 3) == 0;
         const int tile = (oy >> 1) * 4 + (tid & 3);
 #pragma unroll 2
         for (int it = 0; it < 16; ++it) {
             const int k = it * 4 + (tid >> 6), kg = ks * 64 + k;
-            if (kg >= P.k_planes) continue;
-            const float bias = P.bias ? P.bias[kg] : 0.0f;
+            if (kg >= set_k_planes) continue;
+            const float bias = set_bias ? set_bias[kg] : 0.0f;
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -567,9 +576,9 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         // thread -> 8 consecutive channels (one Philox call: 16 mask bits per element) of one pixel column, rows of one parity
         const int k8 = (tid & 7) * 8, kg = ks * 64 + k8, ox = (tid >> 3) & 15, odd = tid >> 7;
         f32x4 bias0 = f32x4{0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
-        if (P.bias) {
-            bias0 = *reinterpret_cast<const f32x4*>(P.bias + kg);
-            bias1 = *reinterpret_cast<const f32x4*>(P.bias + kg + 4);
+        if (set_bias) {
+            bias0 = *reinterpret_cast<const f32x4*>(set_bias + kg);
+            bias1 = *reinterpret_cast<const f32x4*>(set_bias + kg + 4);
         }
         const uint64_t drop_key = P.thresh ? dropout_key(P.seed, P.epoch) : 0ull;
         int n;
@@ -596,14 +605,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
             int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
-            if (P.replicas > 1) {
+            if (set_replicas > 0) {                                  // (0: an ordinary launch; 1: one "replica" under the replicas' mask)
                 // The first conv of an MC-dropout subnet: its output is the same for every run, so the store pass writes the runs'
                 // masked replicas itself (replica r = image r of the output canvas) -- the separate expand pass read this tensor back
                 // and wrote them in a launch of its own.  Mask of replica r = pod_expand_dropout's: counter word 2, 16 bits per element.
-                for (int rep = 0; rep < P.replicas; ++rep, e += (int64_t)HWi * P.out_stride) {
+                for (int rep = 0; rep < set_replicas; ++rep, e += (int64_t)HWi * P.out_stride) {
                     f32x4 w0 = v0, w1 = v1;
                     if (P.thresh) {
-                        const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
+                        const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
                         const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
                                                        (uint32_t)(drop_key >> 32));
                         w0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
@@ -621,7 +630,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 continue;
             }
             if (P.thresh && !(POD_WINO_ELIM & 64)) {
-                const uint64_t ctr = P.offset + (uint64_t)(e >> 3);
+                const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
                 const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
                                                (uint32_t)(drop_key >> 32));
                 v0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
@@ -684,6 +693,14 @@ static int wino_split_prepare() {        // the kernel's dynamic LDS size, once 
     return attr[dev] == hipSuccess ? POD_OK : POD_E_LAUNCH;
 }
 
+static void wino_one_set(pod::WinoParams& P) {      // an ordinary launch is a grouped launch of one convolution
+    for (int s = 0; s < 4; ++s) {
+        P.sets.first[s] = s == 0 ? 0 : INT32_MAX;
+        P.sets.in[s] = P.in; P.sets.out[s] = P.out; P.sets.U[s] = P.U; P.sets.bias[s] = P.bias;
+        P.sets.offset[s] = P.offset; P.sets.replicas[s] = P.replicas; P.sets.k_planes[s] = P.k_planes;
+    }
+}
+
 extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
                                       int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                                       const uint64_t* epoch, pod_stream_t stream) {
@@ -703,7 +720,8 @@ extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* U
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 1;
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 0;
+    wino_one_set(P);
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
@@ -735,6 +753,51 @@ extern "C" int pod_wino_conv3x3_split_replicas(const float* in, float* out, cons
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
     P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = replicas;
+    wino_one_set(P);
+    const int64_t grid = pod::wino_grid(KS, n_blocks);
+    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+// Up to four convolutions of ONE shape (C, K, ReLU, dropout rate) in one grid: the cls- and the bbox-subnet layer l of the head
+// (PR:403-427), their first layers with the replicas, the four predictors (PR:430-484, k_planes[s] > 0: NCHW planes).  blocks = the sets'
+// tables concatenated, set s owning blocks [set_first[s], set_first[s + 1]); every record stays relative to its set's own in / out
+// buffers, every set keeps its own filter, bias, Philox offset, replica count.  Bit for bit the n_sets separate launches
+// (pod_wino_conv3x3_split / _replicas) -- minus their partial last rounds of workgroups (the kernel runs one workgroup per CU).
+extern "C" int pod_wino_conv3x3_split_grouped(int32_t n_sets, const float* const* in, float* const* out, const void* const* Us, const float* const* bias,
+                                              const int32_t* set_first, const int32_t* replicas, const int32_t* k_planes, const uint64_t* offsets,
+                                              const int32_t* blocks, int32_t n_blocks, int32_t C, int32_t K, int32_t relu, float p, uint64_t seed,
+                                              const uint64_t* epoch, pod_stream_t stream) {
+    if (n_sets < 1 || n_sets > 4 || !in || !out || !Us || !bias || !set_first || !replicas || !k_planes || !offsets || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 ||
+        K < 64 || (K & 63) != 0 || !(p >= 0.0f && p < 1.0f) || set_first[0] != 0)
+        return POD_E_INVALID;
+    const int32_t KS = K / 64;
+    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
+    if ((reinterpret_cast<uintptr_t>(blocks) & 15u) != 0) return POD_E_INVALID;
+    pod::WinoParams P;
+    for (int s = 0; s < 4; ++s) {
+        const int t = s < n_sets ? s : 0;
+        if (s < n_sets) {
+            if (!in[s] || !out[s] || in[s] == out[s] || !Us[s] || replicas[s] < 0 || replicas[s] > 127 || k_planes[s] < 0 || k_planes[s] > K ||
+                (k_planes[s] > 0 && (p != 0.0f || replicas[s] != 0)) || (s > 0 && set_first[s] < set_first[s - 1]) || set_first[s] > n_blocks)
+                return POD_E_INVALID;
+            if (((reinterpret_cast<uintptr_t>(in[s]) | reinterpret_cast<uintptr_t>(out[s]) | reinterpret_cast<uintptr_t>(Us[s]) | reinterpret_cast<uintptr_t>(bias[s])) & 15u) != 0)
+                return POD_E_INVALID;
+        }
+        P.sets.first[s] = s < n_sets ? set_first[s] : INT32_MAX;
+        P.sets.in[s] = in[t]; P.sets.out[s] = out[t]; P.sets.U[s] = reinterpret_cast<const float*>(Us[t]); P.sets.bias[s] = bias[t];
+        P.sets.offset[s] = offsets[t]; P.sets.replicas[s] = replicas[t]; P.sets.k_planes[s] = k_planes[t];
+    }
+    if (n_blocks == 0) return POD_OK;
+    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
+    P.in = in[0]; P.out = out[0]; P.U = reinterpret_cast<const float*>(Us[0]); P.bias = bias[0]; P.blocks = reinterpret_cast<const int4*>(blocks);
+    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes[0];
+    P.thresh = POD_DROPOUT_THRESH16(p);
+    P.scale = 1.0f / (1.0f - p);
+    P.seed = seed; P.offset = offsets[0];
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = replicas[0];
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
@@ -759,7 +822,8 @@ extern "C" int pod_wino_conv3x3_split_partial(const float* in, float* partials, 
     P.in = in; P.out = partials; P.U = reinterpret_cast<const float*>(Us); P.bias = nullptr; P.blocks = reinterpret_cast<const int4*>(blocks);
     P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = 0; P.k_planes = 0;
     P.thresh = 0; P.scale = 1.0f; P.seed = 0; P.offset = 0;
-    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride; P.epoch = nullptr; P.replicas = 1;
+    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride; P.epoch = nullptr; P.replicas = 0;
+    wino_one_set(P);
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);

@@ -69,6 +69,20 @@ struct WinoParams {
     // the store pass writes `replicas` copies of the image (pod_wino_conv3x3_split_replicas: channels-last, one input image per record),
     // replica r as image r of the output canvas, each under its own dropout mask -- the mask pod_expand_dropout would draw for it.  1: off.
     int32_t replicas;
+    // Grouped launch (pod_wino_conv3x3_split_grouped): up to four convolutions of the same shape -- the cls- and the bbox-subnet layer l,
+    // the four predictors -- in ONE grid.  Blocks [set_first[s], set_first[s + 1]) of the concatenated table belong to set s (its records
+    // are relative to ITS buffers); a set has its own input, output, filter, bias, Philox offset, replica count and plane count.
+    // k_wino_conv3x3_split reads these, not the fields above (an ordinary launch is one set).
+    struct Sets {
+        int32_t first[4];         // first block of set s (first[0] = 0; unused sets: INT32_MAX)
+        const float* in[4];
+        float* out[4];
+        const float* U[4];
+        const float* bias[4];
+        uint64_t offset[4];
+        int32_t replicas[4];
+        int32_t k_planes[4];
+    } sets;
 };
 
 

@@ -241,6 +241,7 @@ def branches(fns, kind=""):
 # NCHW: MIOpen GEMM + one element-wise pass each for bias / residual / ReLU, plus a layout pass in front of every 3x3.  On
 # pod_conv1x1_split (csrc/k13_conv1x1_split.hip: channels-last GEMM, bias + residual + ReLU in the store, same exact-split products as
 # the 3x3 kernel) a bottleneck is three launches on (pixels, C) buffers and the whole trunk stays channels-last from the max-pool on.
+GROUPED_HEAD = __import__("os").environ.get("POD_GROUPED_HEAD", "1") != "0"         # layer l of the cls and the bbox subnet, and the four predictors, in one launch each
 FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0"     # the first conv of an MC-dropout subnet stores its masked replicas itself
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
 FUSED_PREPROCESS = __import__("os").environ.get("POD_FUSED_PREPROCESS", "1") != "0"   # ... which then also normalises and pads the frame on load
@@ -590,6 +591,69 @@ class ProbabilisticRetinaNetHead(nn.Module):
             a, b = b, a
         return a, copies
 
+    def _grouped_ok(self, *copies) -> bool:
+        """Both subnets' launches in one grid (pod_wino_conv3x3_split_grouped): the split kernel, the replicas in the store pass."""
+        return (GROUPED_HEAD and FUSED_REPLICAS and not BRANCHES and all(1 <= c <= 127 for c in copies)
+                and all(self._wino(c).split for c in list(self.cls_subnet) + list(self.bbox_subnet)))
+
+    def _trunks_grouped(self, x0: torch.Tensor, levels, copies_c: int, copies_b: int, dropout: bool):
+        """`_trunk_all_levels` of the cls and the bbox subnet with layer l of both in ONE launch (the kernel runs one workgroup per CU, so
+        a launch costs whole rounds of 256 workgroups: two launches of 1.5 rounds cost 4, one of 3.0 costs 3).  Same buffers, tables,
+        Philox offsets and therefore the same bits as the two separate trunks.  Returns (cls buffer, images, bbox buffer, images)."""
+        from .wino import block_table, grouped_launch, level_pixel_offsets
+        subs, L, C, dev = (self.cls_subnet, self.bbox_subnet), len(self.cls_subnet), x0.shape[1], x0.device
+        if not dropout:
+            ys = [x0, x0]
+            t1 = block_table(levels, 1, dev)
+            for l in range(L):
+                outs = [torch.empty_like(x0), torch.empty_like(x0)]
+                grouped_launch([{"conv": self._wino(subs[i][l]), "src": ys[i], "dst": outs[i], "table": t1} for i in range(2)], relu=True)
+                ys = outs
+            return ys[0], 1, ys[1], 1
+        copies = (copies_c, copies_b)
+        replay = self.dropout_replay is not None
+        p = 0.0 if replay else float(self.dropout_rate)
+        ids = [[self._drop_calls + i * L + l + 1 for l in range(L)] for i in range(2)]       # the offsets the two separate trunks would draw
+        self._drop_calls += 2 * L
+        offn = [level_pixel_offsets(levels, c) for c in copies]
+        a = [torch.empty((offn[i][-1], C), dtype=x0.dtype, device=dev) for i in range(2)]
+
+        def mask_in_place(bufs, layer):             # parity mode: the recorded masks on the channels-last images of the buffers
+            for i in range(2):
+                for lv, (h, w) in enumerate(levels):
+                    v = bufs[i][offn[i][lv]:offn[i][lv + 1]].view(copies[i], h, w, C)
+                    v.copy_(self._replayed(v.permute(0, 3, 1, 2), i, layer, lv).permute(0, 2, 3, 1))
+
+        grouped_launch([{"conv": self._wino(subs[i][0]), "src": x0, "dst": a[i], "table": block_table(levels, 1, dev, out_copies=copies[i]),
+                         "offset": ids[i][0] << 34, "replicas": copies[i]} for i in range(2)],
+                       relu=True, dropout_p=p, seed=self.dropout_seed, epoch=self._epoch)
+        if replay:
+            mask_in_place(a, 0)
+        tn = [block_table(levels, c, dev) for c in copies]
+        b = [torch.empty_like(t) for t in a]
+        for l in range(1, L):
+            grouped_launch([{"conv": self._wino(subs[i][l]), "src": a[i], "dst": b[i], "table": tn[i], "offset": ids[i][l] << 34} for i in range(2)],
+                           relu=True, dropout_p=p, seed=self.dropout_seed, epoch=self._epoch)
+            if replay:
+                mask_in_place(b, l)
+            a, b = b, a
+        return a[0], copies_c, a[1], copies_b
+
+    def _predict_grouped(self, jobs, levels):
+        """The predictor convs in ONE launch.  jobs: (conv, buffer, images in the buffer per level, first image, image count, output images)
+        as `_predict_all_levels` takes them; returns its result for each job."""
+        from .wino import block_table, grouped_launch, level_pixel_offsets
+        sets, outs = [], []
+        for conv, buf, buf_copies, first, count, out_copies in jobs:
+            K = conv.out_channels
+            offs = level_pixel_offsets(levels, out_copies)
+            out = (torch.zeros if out_copies > count else torch.empty)(offs[-1] * K, dtype=buf.dtype, device=buf.device)
+            sets.append({"conv": self._wino(conv), "src": buf, "dst": out, "planes": True,
+                         "table": block_table(levels, count, buf.device, in_copies=buf_copies, in_first=first, out_copies=out_copies)})
+            outs.append([out[offs[i] * K:offs[i + 1] * K].view(out_copies, K, h, w) for i, (h, w) in enumerate(levels)])
+        grouped_launch(sets)
+        return outs
+
     def _predict_all_levels(self, conv, buf: torch.Tensor, levels, buf_copies: int, first: int, count: int, out_copies: int):
         """A predictor conv (cls_score / bbox_pred / cls_var / bbox_cov, PR:430-484) on images first .. first+count-1 of every level
         of a trunk buffer, one launch; returns per level an (out_copies, K, H, W) NCHW tensor -- the planes K1 streams -- whose
@@ -651,9 +715,32 @@ class ProbabilisticRetinaNetHead(nn.Module):
             # every conv of the head on pod_wino_conv3x3: one launch per layer over all levels and all runs
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
             x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
-            (tc, nc), (tb, nb) = branches([lambda: self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout),
-                                           lambda: self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)], "head")
-            if dropout:
+            grouped = self._grouped_ok(cls_copies, box_copies)
+            if grouped:
+                tc, nc, tb, nb = self._trunks_grouped(x0, levels, cls_copies, box_copies, dropout)
+            else:
+                (tc, nc), (tb, nb) = branches([lambda: self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout),
+                                               lambda: self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout)], "head")
+            preds = [c for c in (self.cls_score, self.bbox_pred, self.cls_var if self.compute_cls_var else None, self.bbox_cov if self.compute_bbox_cov else None)
+                     if c is not None]
+            if grouped and len({self._wino(c).Kpad for c in preds}) == 1 and all(self._wino(c).split for c in preds):
+                # the predictors in one launch too
+                if dropout:
+                    jobs = [(self.cls_score, tc, nc, 0, m, n), (self.bbox_pred, tb, nb, 0, n, n)]
+                    jobs += [(self.cls_var, tc, nc, m, m, n)] if self.compute_cls_var else []          # independent dropout draw (Q2)
+                    jobs += [(self.bbox_cov, tb, nb, n, m, n)] if self.compute_bbox_cov else []
+                    res = self._predict_grouped(jobs, levels)
+                else:
+                    jobs = [(self.cls_score, tc, 1, 0, 1, 1), (self.bbox_pred, tb, 1, 0, 1, 1)]
+                    jobs += [(self.cls_var, tc, 1, 0, 1, 1)] if self.compute_cls_var else []
+                    jobs += [(self.bbox_cov, tb, 1, 0, 1, 1)] if self.compute_bbox_cov else []
+                    res = self._predict_grouped(jobs, levels)
+                    if n > 1:
+                        res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
+                logits, deltas = res[0], res[1]
+                logit_vars = res[2] if self.compute_cls_var else []
+                delta_covs = res[-1] if self.compute_bbox_cov else []
+            elif dropout:
                 logits = self._predict_all_levels(self.cls_score, tc, levels, nc, 0, m, n)
                 deltas = self._predict_all_levels(self.bbox_pred, tb, levels, nb, 0, n, n)
                 if self.compute_cls_var:

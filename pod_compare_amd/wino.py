@@ -104,6 +104,44 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
 SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"
 
 
+def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int = 0, epoch: Optional[torch.Tensor] = None) -> None:
+    """Up to four convolutions of one shape in ONE grid (pod_wino_conv3x3_split_grouped).  sets: dicts {conv: WinoConv (split kernel),
+    src, dst, table, offset = 0, replicas = 0 (r >= 1: WinoConv.replicas' store pass), planes = False}; every set keeps its own buffers, table, filter, bias, Philox offset.
+    Bit for bit the separate launches conv(src, dst, table, ...) / conv.replicas(...)."""
+    import ctypes
+    assert 1 <= len(sets) <= 4
+    c0 = sets[0]["conv"]
+    firsts, tabs = [], []
+    n = 0
+    for s in sets:
+        conv, src, dst, table = s["conv"], s["src"], s["dst"], s["table"]
+        planes = bool(s.get("planes", False))
+        assert conv.split and conv.C == c0.C and conv.Kpad == c0.Kpad and src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == conv.C
+        assert planes or dst.shape[-1] == conv.Kpad
+        assert getattr(table, "pod_channels", 512) >= max(conv.C, conv.K if planes else conv.Kpad)
+        firsts.append(n)
+        n += int(table.shape[0])
+        tabs.append(table)
+    key = tuple((t.data_ptr(), t._version, int(t.shape[0])) for t in tabs)
+    cat = _GROUPED_TABLES.get(key)
+    if cat is None:
+        if len(_GROUPED_TABLES) >= 64:
+            _GROUPED_TABLES.pop(next(iter(_GROUPED_TABLES)))
+        cat = _GROUPED_TABLES[key] = (torch.cat(tabs).contiguous(), tabs)          # (keeps the parts alive: their addresses are the key)
+    table = cat[0]
+    k = len(sets)
+    vp = lambda xs: (ctypes.c_void_p * k)(*[ctypes.c_void_p(x) for x in xs])
+    i32 = lambda xs: (ctypes.c_int32 * k)(*[int(x) for x in xs])
+    hip.check(hip.load().pod_wino_conv3x3_split_grouped(
+        k, vp([s["src"].data_ptr() for s in sets]), vp([s["dst"].data_ptr() for s in sets]), vp([s["conv"].U.data_ptr() for s in sets]),
+        vp([hip.ptr(s["conv"].bias) or 0 for s in sets]), i32(firsts), i32([s.get("replicas", 0) for s in sets]),
+        i32([(s["conv"].K if s.get("planes", False) else 0) for s in sets]), (ctypes.c_uint64 * k)(*[int(s.get("offset", 0)) for s in sets]),
+        table.data_ptr(), n, c0.C, c0.Kpad, 1 if relu else 0, float(dropout_p), seed, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split_grouped")
+
+
+_GROUPED_TABLES = {}
+
+
 class WinoConv:
     """One conv3x3(C -> K, stride 1, pad 1) with its filter transformed once.  K is padded to a multiple of 64 with zero
     filters (outputs written for the padded channels are zero + nothing: bias is padded with zeros too)."""

@@ -278,11 +278,18 @@ def test_eval_mode_trunk_sharing_on_the_gpu():
         calls["n"] += len(levels)
         return real_all(convs, x0, levels, copies, dropout)
 
+    real_grouped = model.head._trunks_grouped
+
+    def counting_grouped(x0, levels, copies_c, copies_b, dropout):          # (both subnets, layer by layer in one launch each)
+        calls["n"] += 2 * len(levels)
+        return real_grouped(x0, levels, copies_c, copies_b, dropout)
+
     model.head._trunk = counting
     model.head._trunk_all_levels = counting_all
+    model.head._trunks_grouped = counting_grouped
     cls, delta, cls_var, reg_var = model.head(feats, 1, mc_dropout=False)
     assert calls["n"] == 2 * len(feats)                           # one cls trunk + one box trunk per level, not four
-    model.head._trunk, model.head._trunk_all_levels = real, real_all
+    model.head._trunk, model.head._trunk_all_levels, model.head._trunks_grouped = real, real_all, real_grouped
     for l, f in enumerate(feats):
         tc, tb = f, f
         for conv in model.head.cls_subnet:

@@ -245,6 +245,72 @@ def test_replicas_from_the_store_pass_equal_conv_then_expand_dropout(levels, rep
                                                128, 0.0, 0, 0, None, hip.current_stream()) == -1        # replicas <= 127
 
 
+def test_grouped_launch_equals_the_separate_launches():
+    """pod_wino_conv3x3_split_grouped: several convolutions of one shape in one grid -- ordinary layers with dropout, first layers with
+    replicas, predictors writing planes -- bit for bit the separate launches, set by set."""
+    from pod_compare_amd.wino import grouped_launch
+    levels, C = [(20, 28), (9, 13), (5, 7)], 64
+    lib = hip.load()
+    # (a) two trunk layers with dropout, different image counts, own Philox offsets
+    convs, srcs, tabs = [], [], []
+    for i, copies in enumerate((3, 5)):
+        w, b, xs = make(levels, copies, C, 64, seed=20 + i)
+        convs.append(WinoConv(w, b, split=True)); srcs.append(flat(xs)); tabs.append(block_table(levels, copies, "cuda"))
+    want = [convs[i](srcs[i], torch.empty(srcs[i].shape[0], 64, device="cuda"), tabs[i], relu=True, dropout_p=0.2, seed=5, offset=(7 + i) << 34) for i in range(2)]
+    got = [torch.full_like(t, float("nan")) for t in want]
+    grouped_launch([{"conv": convs[i], "src": srcs[i], "dst": got[i], "table": tabs[i], "offset": (7 + i) << 34} for i in range(2)], relu=True, dropout_p=0.2, seed=5)
+    assert all(torch.equal(g, w_) for g, w_ in zip(got, want))
+    # (b) two first layers on ONE input, each storing its own number of masked replicas
+    w0, b0, xs = make(levels, 1, C, 64, seed=30)
+    w1, b1, _ = make(levels, 1, C, 64, seed=31)
+    firsts, src = [WinoConv(w0, b0, split=True), WinoConv(w1, b1, split=True)], flat(xs)
+    reps = (4, 7)
+    want = [firsts[i].replicas(src, torch.empty(level_pixel_offsets(levels, reps[i])[-1], 64, device="cuda"), block_table(levels, 1, "cuda", out_copies=reps[i]), reps[i],
+                               relu=True, dropout_p=0.3, seed=9, offset=(2 + i) << 34) for i in range(2)]
+    got = [torch.full_like(t, float("nan")) for t in want]
+    grouped_launch([{"conv": firsts[i], "src": src, "dst": got[i], "table": block_table(levels, 1, "cuda", out_copies=reps[i]), "offset": (2 + i) << 34, "replicas": reps[i]}
+                    for i in range(2)], relu=True, dropout_p=0.3, seed=9)
+    assert all(torch.equal(g, w_) for g, w_ in zip(got, want))
+    # (c) four predictors: K = 63 / 36 / 63 / 40 real channels (one 64-channel slice each), planes out, subsets of the images
+    jobs = [(63, 0, 3, 3), (36, 0, 3, 3), (63, 1, 2, 3), (40, 2, 1, 3)]          # (K, first image, image count, output images)
+    sets, want = [], []
+    for j, (K, first, count, out_copies) in enumerate(jobs):
+        w, b, _ = make(levels, 1, C, K, seed=40 + j)
+        conv = WinoConv(w, b, split=True)
+        table = block_table(levels, count, "cuda", in_copies=3, in_first=first, out_copies=out_copies)
+        n_out = level_pixel_offsets(levels, out_copies)[-1] * K
+        want.append(conv(srcs[0], torch.zeros(n_out, device="cuda"), table, planes=True))
+        sets.append({"conv": conv, "src": srcs[0], "dst": torch.zeros(n_out, device="cuda"), "table": table, "planes": True})
+    grouped_launch(sets)
+    assert all(torch.equal(s_["dst"], w_) for s_, w_ in zip(sets, want))
+    # invalid: five sets, a set list that does not start at block 0
+    import ctypes
+    one = (ctypes.c_void_p * 1)(ctypes.c_void_p(srcs[0].data_ptr()))
+    assert lib.pod_wino_conv3x3_split_grouped(5, one, one, one, one, (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_uint64 * 1)(0),
+                                              tabs[0].data_ptr(), 1, C, 64, 1, 0.0, 0, None, hip.current_stream()) == -1
+    assert lib.pod_wino_conv3x3_split_grouped(1, one, one, one, one, (ctypes.c_int32 * 1)(1), (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_uint64 * 1)(0),
+                                              tabs[0].data_ptr(), 1, C, 64, 1, 0.0, 0, None, hip.current_stream()) == -1
+
+
+def test_head_with_grouped_launches_equals_the_head_with_separate_launches(monkeypatch):
+    """The whole head, MC-dropout mode (replicas, masks, skipped last run) and eval mode: POD_GROUPED_HEAD on against off, bit for bit."""
+    torch.manual_seed(21)
+    model = modeling.ProbabilisticRetinaNet(dropout_rate=0.1, cls_var_loss="loss_attenuation", cls_var_num_samples=10,
+                                            bbox_cov_loss="negative_log_likelihood").cuda().eval()
+    for q in model.parameters():
+        q.requires_grad_(False)
+    feats = [torch.randn(1, 256, h, w, device="cuda") for h, w in ((24, 40), (12, 20), (6, 10))]
+    for mc, n, skip in ((True, 5, True), (True, 1, False), (False, 1, False), (False, 3, False)):
+        outs = []
+        for g in (True, False):
+            monkeypatch.setattr(modeling, "GROUPED_HEAD", g)
+            model.head._drop_calls = 0
+            outs.append(model.head(feats, n, mc_dropout=mc, skip_unused_last_run=skip))
+        for a, b in zip(outs[0], outs[1]):
+            for ta, tb in zip(a, b):
+                assert torch.equal(ta, tb), (mc, n, skip)
+
+
 @pytest.mark.parametrize("H,W,C,K,splits", [(24, 42, 512, 512, 4), (48, 84, 256, 256, 2), (24, 42, 256, 256, 4), (6, 11, 128, 64, 2), (13, 17, 64, 36, 2)])
 def test_small_maps_split_over_the_input_channels(H, W, C, K, splits):
     """pod_wino_conv3x3_split_partial + pod_wino_reduce (backbone convolutions on small maps: res4 / res5 / p4 / p5): the input channels
