@@ -182,6 +182,16 @@ def conv_census(model, img, N, quirk, dev):
         calls.append(("3x3_head_winograd_hip", 2.0 * src.shape[0] * self.C * self.K * 9, e0, e1))
         return y
 
+    real_grouped = wino.grouped_launch
+
+    def probe_grouped(sets, **kw):                       # layer l of both subnets / the four predictors in one launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_grouped(sets, **kw)
+        e1.record()
+        flops = sum(2.0 * (st["src"].shape[0] if st.get("replicas", 0) else st["table"].pod_pixels) * st["conv"].C * st["conv"].K * 9 for st in sets)
+        calls.append(("3x3_head_winograd_hip", flops, e0, e1))
+
     real_cl = wino.WinoConv.channels_last_of_one_image
 
     def probe_cl(self, src, table, **kw):               # the same convolutions in the channels-last backbone
@@ -220,6 +230,7 @@ def conv_census(model, img, N, quirk, dev):
     reps = 3
     conv1x1.Stem7x7.__call__ = probe_stem
     wino.WinoConv.replicas = probe_rep
+    wino.grouped_launch = probe_grouped
     F.conv2d = probe
     wino.WinoConv.__call__ = probe_wino
     wino.WinoConv.planes_of_one_image = probe_planes
@@ -241,6 +252,7 @@ def conv_census(model, img, N, quirk, dev):
         conv1x1.Conv1x1.__call__ = real_c1
         conv1x1.Stem7x7.__call__ = real_stem
         wino.WinoConv.replicas = real_rep
+        wino.grouped_launch = real_grouped
     out = {}
     for cat, flops, e0, e1 in calls:
         d = out.setdefault(cat, {"calls": 0, "gflop": 0.0, "ms": 0.0})
