@@ -92,6 +92,8 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
         t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table
         t.pod_levels = len(levels)
         t.pod_channels = channels
+        if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(t.device).synchronize()           # made once, then read from any stream
         _TABLES[key] = t
     return t
 
@@ -128,6 +130,8 @@ def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int =
         if len(_GROUPED_TABLES) >= 64:
             _GROUPED_TABLES.pop(next(iter(_GROUPED_TABLES)))
         cat = _GROUPED_TABLES[key] = (torch.cat(tabs).contiguous(), tabs)          # (keeps the parts alive: their addresses are the key)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(tabs[0].device).synchronize()               # made once, then read from any stream
     table = cat[0]
     k = len(sets)
     vp = lambda xs: (ctypes.c_void_p * k)(*[ctypes.c_void_p(x) for x in xs])
