@@ -11,8 +11,8 @@
 // operands (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the weights split once (pod_conv1x1_filter_split),
 // the activations in the loop with the very functions k12 uses (pod_wino.h: wino_bf16_pair / wino_bf16_residual).
 //
-// Mapping.  Workgroup = ONE wavefront = 64 output pixels x (32 NCB) output channels (NCB = 4, or 2 when Cout % 128 != 0): 2 NCB
-// accumulator blocks of 32 x 32.  The filter is the ROW operand of the MFMAs (a lane's accumulator quad is 4 consecutive output
+// Mapping.  Workgroup = ONE wavefront = 64 output pixels x (32 NCB) output channels (NCB = 2 as shipped): 2 NCB accumulator blocks
+// of 32 x 32.  The filter is the ROW operand of the MFMAs (a lane's accumulator quad is 4 consecutive output
 // channels of one pixel: 16-byte stores into the channels-last output).  No LDS: with both operands K-contiguous a lane's MFMA
 // fragment IS a contiguous piece of memory -- 32 B of one pixel's channels, 16 B of one filter row's pre-split terms -- so fragments
 // are loaded straight into registers, TWO k-steps (16 channels each) ahead through three rotating register buffers; wavefronts that
@@ -462,29 +462,21 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     pod::C1Params P;
     P.x = x; P.y = n_splits > 1 ? partials : y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.residual = residual;
     P.P_out = (int32_t)P_out; P.W_out = W_out; P.W_in = W_in; P.stride = stride; P.Cin = Cin; P.Cout = Cout; P.relu = relu;
-#ifdef POD_C1_NCB
-    const int ncb = POD_C1_NCB;
-#else
-    const int ncb = 2;      // 64-channel tiles: 186 registers = two wavefronts per SIMD, one's epilogue under the other's MFMAs (measured: 1.17 ms per image against 1.29 with 128-channel tiles)
-#endif
-    P.n_pt = (int32_t)((P_out + 63) / 64); P.n_ct = Cout / (32 * ncb);
+    // 64 pixels x 64 channels per wavefront (two wavefronts per SIMD: one's epilogue under the other's MFMAs; 128-channel tiles measured
+    // 1.29 ms per image against 1.17)
+    P.n_pt = (int32_t)((P_out + 63) / 64); P.n_ct = Cout / 64;
     P.ks_per_split = nks / n_splits;
     P.split_stride = n_splits > 1 ? P_out * Cout : 0;
     const int64_t grid = 8LL * ((P.n_pt + 7) / 8) * P.n_ct;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-#ifdef POD_C1_LDSPAD
-    const unsigned pad = (grid * n_splits <= POD_C1_LDSPAD_MAXGRID) ? POD_C1_LDSPAD : 0;
-#else
-    const unsigned pad = 0;
-#endif
 #ifndef POD_C1_RING
 #define POD_C1_RING 3
 #endif
-    if (ncb == 4) hipLaunchKernelGGL((pod::k_conv1x1_split<4, 3>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
-#ifndef POD_C1_DIRECT
-    else if ((P.ks_per_split & 1) == 0) hipLaunchKernelGGL(pod::k_conv1x1_split_lds<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
+#ifndef POD_C1_DIRECT       // (experiment builds: the direct-fragment kernel everywhere, tools/conv1x1_ab.py, tools/conv1x1_elim.py)
+    if ((P.ks_per_split & 1) == 0) hipLaunchKernelGGL(pod::k_conv1x1_split_lds<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
+    else
 #endif
-    else hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), pad, (hipStream_t)stream, P);
+        hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     if (n_splits > 1) {
         const int64_t n4 = P_out * Cout / 4;
