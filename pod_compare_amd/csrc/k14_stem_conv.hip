@@ -64,8 +64,10 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
     // ---- the input patch: rows 2 oy0 - 3 .., columns 2 ox0 - 3 .., zero outside the image
     {
         const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-#pragma unroll 5
-        for (int e = lane; e < 3 * ST_PR * ST_PC; e += 64) {
+#pragma unroll
+        for (int it = 0; it < (3 * ST_PR * ST_PC + 63) / 64; ++it) {            // 25 loads per lane, all in flight before the first is parked
+            const int e = lane + 64 * it;
+            if (e >= 3 * ST_PR * ST_PC) break;
             const int c = e / (ST_PR * ST_PC), r = (e - c * ST_PR * ST_PC) / ST_PC, col = e - c * ST_PR * ST_PC - r * ST_PC;
             const int iy = iy0 + r, ix = ix0 + col;
             float v = 0.f;
