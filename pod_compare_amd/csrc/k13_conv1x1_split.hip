@@ -241,6 +241,50 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
 #endif
 }
 
+// The epilogue of the LDS kernels, in whole lines: the accumulators (a lane: 4 consecutive channels of ONE pixel per register quad -- 32
+// pixels x 32 B per store instruction) go through 16 KB of LDS, [pixel 64][chunk position 16][16 B] with position = chunk ^ (pixel & 15),
+// and come back as 4 pixels x 256 B per instruction: residual loads and output stores of 8 full lines each, all 16 residual loads
+// requested before the first is used (one wavefront per SIMD: nobody else hides them).
+__device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_o, f32x16 (&acc)[2][2], int tp, int tc, int lane, int i32, int h) {
+    constexpr int NCB = 2;
+    float* __restrict__ const yo = P.y + (int64_t)blockIdx.y * P.split_stride;
+    const float* __restrict__ const res = P.residual;
+    const bool final_pass = P.split_stride == 0;
+    const int oc = lane & 15, op = lane >> 4;                       // read side: chunk oc (channels 4 oc ..) of pixel 4 j + op
+    const int gp0 = tp * 64 + op;
+    const int64_t e0 = (int64_t)gp0 * P.Cout + tc * 64 + 4 * oc;    // + 4 j Cout
+    f32x4 r[16];
+    if (final_pass && res) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[j] = (gp0 + 4 * j < P.P_out) ? *reinterpret_cast<const f32x4*>(res + e0 + (int64_t)(4 * j) * P.Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (final_pass && P.bias) b4 = *reinterpret_cast<const f32x4*>(P.bias + tc * 64 + 4 * oc);
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pix = 32 * pb + i32, c = 8 * cb + 2 * q + h;
+                *reinterpret_cast<f32x4*>(lds_o + pix * 64 + 4 * (c ^ (i32 & 15))) =
+                    f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
+            }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int pix = 4 * j + op;
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + pix * 64 + 4 * (oc ^ (pix & 15)));
+        if (final_pass) {
+            v += b4;
+            if (res) v += r[j];
+            if (P.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+        }
+        if (gp0 + 4 * j < P.P_out) *reinterpret_cast<f32x4*>(yo + e0 + (int64_t)(4 * j) * P.Cout) = v;
+    }
+}
+
 // The same tile with the activations taken through LDS (the production form whenever a workgroup set accumulates an even number of
 // k-steps).  k_conv1x1_split loads a lane's MFMA fragment straight from memory: 16 B of each of 32 pixels per instruction = 32 cache
 // lines for 1 KB, and the CU's L1 takes a cycle per line -- measured (POD_C1_ELIM builds, res4 conv1): the activation loads are 6.3 of
@@ -305,8 +349,11 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     };
     const WinoSplitSel sel;
     // Built, measured and dropped (profiles/r04_experiments.md, K13): splitting k-step j + 1 beside the MFMAs of k-step j slot by slot as
-    // k12 does (units of 7 VALU instructions in every second MFMA gap: the loop kept its 0.73 us per k-step and the second term buffer
-    // cost the second wavefront per SIMD that the large maps need: 1.02 ms per image against 0.975); a four-wavefront workgroup sharing
+    // k12 does -- first with units of 7 VALU instructions in every second MFMA gap (the loop kept its 0.73 us per k-step and the second
+    // term buffer cost the second wavefront per SIMD that the large maps need: 1.02 ms per image against 0.975), then evenly (one part
+    // of <= 3 instructions and <= 1 memory operation per slot, fragments read two k-steps ahead, one wavefront per SIMD, launches of
+    // <= 1100 wavefronts only: 10 % fewer cycles per k-step at a 10 % lower clock; 5 - 10 % faster on the long-K shapes of one box,
+    // nothing on another, and 1 % SLOWER end to end on cfg2, where a 456-register wavefront keeps other streams' work off its SIMD); a four-wavefront workgroup sharing
     // the channel tile's filter terms through LDS (half the L1 / L2 traffic per MFMA, one barrier per pair: 1.02 against 0.93, the
     // small maps 30-40 % slower).  The counters say where a lone wavefront's k-step goes: 768 cycles of MFMA + ~450 of VALU issue
     // (113 instructions) + ~250 of waits, one after the other -- the VALU block of a k-step does not overlap its own MFMAs.
@@ -372,48 +419,7 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     for (int j0 = 0; j0 < nks; j0 += 6) trip(trip, c1_ic<0>{}, j0);
     C1_STAMP(2);
 
-    // ---- epilogue, also in whole lines: the accumulators (a lane: 4 consecutive channels of ONE pixel per register quad -- 32 pixels
-    // x 32 B per store instruction) go through the same 16 KB of LDS, [pixel 64][chunk position 16][16 B] with position = chunk ^
-    // (pixel & 15), and come back as 4 pixels x 256 B per instruction: residual loads and output stores of 8 full lines each, all 16
-    // residual loads requested before the first is used (one wavefront per SIMD: nobody else hides them).
-    static_assert(NCB == 2, "the LDS epilogue is laid out for 64-channel tiles");
-    float* const lds_o = &lds_a[0][0];
-    float* __restrict__ const yo = P.y + (int64_t)blockIdx.y * P.split_stride;
-    const float* __restrict__ const res = P.residual;
-    const bool final_pass = P.split_stride == 0;
-    const int oc = lane & 15, op = lane >> 4;                       // read side: chunk oc (channels 4 oc ..) of pixel 4 j + op
-    const int gp0 = tp * 64 + op;
-    const int64_t e0 = (int64_t)gp0 * P.Cout + tc * 64 + 4 * oc;    // + 4 j Cout
-    f32x4 r[16];
-    if (final_pass && res) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = (gp0 + 4 * j < P.P_out) ? *reinterpret_cast<const f32x4*>(res + e0 + (int64_t)(4 * j) * P.Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (final_pass && P.bias) b4 = *reinterpret_cast<const f32x4*>(P.bias + tc * 64 + 4 * oc);
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pix = 32 * pb + i32, c = 8 * cb + 2 * q + h;
-                *reinterpret_cast<f32x4*>(lds_o + pix * 64 + 4 * (c ^ (i32 & 15))) =
-                    f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
-            }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int pix = 4 * j + op;
-        f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + pix * 64 + 4 * (oc ^ (pix & 15)));
-        if (final_pass) {
-            v += b4;
-            if (res) v += r[j];
-            if (P.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-        }
-        if (gp0 + 4 * j < P.P_out) *reinterpret_cast<f32x4*>(yo + e0 + (int64_t)(4 * j) * P.Cout) = v;
-    }
+    c1_epilogue(P, &lds_a[0][0], acc, tp, tc, lane, i32, h);
 #ifdef POD_C1_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     C1_STAMP(3);
