@@ -12,12 +12,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The driver runs `pytest -x -q -m gpu`: the first failure ends the run.  The order below puts the CONTRACT first -- the golden
+# fixtures of the five BASELINE configs, the bit-exact index / NMS / top-k tests, NLL parity, the predictor against the reference's
+# captured outputs -- then the kernels' own arithmetic tests, and the plumbing / experiment-grade tests last, so that a failure in
+# the latter can never hide the former (round 4: one stray fixture stopped the run at test 86 of 387).
+GPU_ORDER = ("test_hip_parity", "test_nms_gpu", "test_topk_gpu", "test_nll_gpu", "test_predictor_gpu", "test_native_exact_gpu",
+             "test_hip_edge_cases", "test_run_image_gpu", "test_eval_matching", "test_probabilistic_metrics", "test_torch_ops_gpu", "test_head_reference_gpu",
+             "test_wino_conv_gpu", "test_stem_gpu", "test_conv1x1_gpu", "test_graphs_gpu", "test_ensemble_dist_gpu",
+             "test_apply_net_gpu", "test_multi_gpu")
+# inside test_hip_parity: goldens and index sequences before everything else
+FUNC_ORDER = ("test_hip_matches_reference_golden", "test_hip_indices_bit_exact", "test_records_match_json_of_oracle",
+              "test_reg_nll_matches_scoring_rule")
+
+
+def gpu_order_key(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    m = GPU_ORDER.index(mod) if mod in GPU_ORDER else len(GPU_ORDER)
+    fn = getattr(item, "originalname", None) or item.name.split("[")[0]
+    f = FUNC_ORDER.index(fn) if fn in FUNC_ORDER else len(FUNC_ORDER)
+    # BASELINE-config goldens (cfg1..cfg5, then the full-size ones) ahead of the side-mode goldens
+    name = item.name
+    g = 0 if "[cfg" in name else 1 if "[full_cfg" in name else 2
+    return (m, f, g)
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch
         has_gpu = torch.cuda.is_available()
     except Exception:  # pragma: no cover
         has_gpu = False
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if gpu_items:      # stable sort: CPU tests keep their places, GPU tests are re-ordered among the places GPU tests held
+        ordered = iter(sorted(gpu_items, key=gpu_order_key))
+        items[:] = [next(ordered) if "gpu" in it.keywords else it for it in items]
     if has_gpu:
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -24,10 +24,22 @@ def sha(tensors) -> str:
     return h.hexdigest()
 
 
+def is_predictor_fixture(path) -> bool:
+    """A whole-predictor fixture (oracle/make_golden.py) is recognised by WHAT IT HOLDS -- a JSON `meta` member carrying a `spec` --
+    never by what its file name is not: any other .npz dropped into tests/golden/ (unit vectors, evaluation fixtures, model fixtures,
+    calibration fixtures ...) is simply not one."""
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            if "meta" not in z.files:
+                return False
+            meta = json.loads(str(z["meta"]))
+    except Exception:
+        return False
+    return isinstance(meta, dict) and "spec" in meta and "name" in meta and "input_sha" in meta
+
+
 def fixture_paths(prefix=""):
-    skip = ("unit_functions.npz", "eval_matching.npz", "eval_metrics.npz")     # not whole-predictor fixtures
-    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz"))
-                  if not p.endswith(skip) and not os.path.basename(p).startswith("head_"))      # head_*: model fixtures (row a1)
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")) if is_predictor_fixture(p))
 
 
 def fixture_id(path):
