@@ -240,7 +240,8 @@ def main(argv=None):
         predictor.return_device = True      # no per-image host sync: records and counts stay in HBM until the gather
         for m in [predictor.model] + list(predictor.model_list):
             if isinstance(m, modeling.ProbabilisticRetinaNet):
-                m.enable_graphs(not getattr(args, "no_graphs", False))      # one host call per dropout-free forward instead of ~200 launches
+                m.enable_graphs(not getattr(args, "no_graphs", False))      # one host call per forward instead of ~200 launches
+                m.graph_after_seen = 2                                      # (a frame size is captured once it has come back: data sets of many sizes stay eager)
     # images are independent units: keep a few in flight on separate HIP streams so one image's low-occupancy backbone
     # stretches overlap another image's head convs (+12 % images/s on one MI355X); the predictor keeps a workspace per stream
     n_streams = args.streams if args.streams > 0 else (2 if (getattr(predictor, "mc_dropout_enabled", False) and getattr(predictor, "num_mc_dropout_runs", 1) > 1) else 3)

@@ -30,7 +30,7 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     const bool merged = cfg->n_runs > 1;
     const bool prune = cfg->has_cls_var != 0;           // native draws + variance head: K1 flags, K1b samples
     const bool has_cov = cfg->cov_dims > 0 || merged;   // PI:381: otherwise the reference carries no covariance
-    if (prune && !ws->maybe_bits) return POD_E_INVALID;
+    if (prune && !ws->probs_dense) return POD_E_INVALID;
     if (!ws->cat_keys || !ws->cat_level || !ws->n_total) return POD_E_INVALID;
     if (mode == POD_MODE_BAYES_OD && !has_cov) return POD_E_INVALID;
 

@@ -129,15 +129,12 @@ class HotPath:
         D = self.cov_dims
         # K1 outputs
         merged = self.n_runs > 1
-        self.mean_cls = f32(self.R * K) if merged else None
-        self.mean_cls_var = f32(self.R * K) if merged and has_cls_var else None
-        self.mean_delta = f32(self.R * 4) if merged and dense_box_merge else None
-        self.mean_reg_var = f32(self.R * D) if merged and D > 0 and dense_box_merge else None
+        # merged planes + the K1 -> K1b bitmap: only the two-launch form (pod_mc_merge_score + pod_score_maybe; eps replay, dense-merge
+        # gate) reads or writes them -- pod_run_image's fused launch stores no planes -- so they are allocated on first use
+        self._planes = None         # see _merged_planes(); read through the properties mean_cls / mean_cls_var / mean_delta / mean_reg_var / maybe_bits
         self.cand_keys = torch.empty(self.R, dtype=torch.int64, device=dev)
         self.counters = torch.zeros(2 * hip.POD_MAX_LEVELS, dtype=torch.int32, device=dev)   # [0:L] cand_count, [L:2L] K2's tickets
         self.cand_count = self.counters[: self.L]
-        n_words = sum(A * K * ((h * w + 63) // 64) for h, w in self.shapes)     # == pod_maybe_words(): a word per (plane, 64 cells)
-        self.maybe_bits = torch.zeros(n_words, dtype=torch.int64, device=dev) if has_cls_var else None
         # K2 outputs
         self.sel_keys = torch.empty(self.L * params.topk_candidates, dtype=torch.int64, device=dev)
         self.sel_count = i32(self.L)
@@ -164,9 +161,9 @@ class HotPath:
         self.cfg = self._make_cfg()
         self._levels_t = hip.PodLevel * self.L
         ws = hip.PodWorkspace()
-        for name, t in (("anchors", self.anchors), ("mean_cls", self.mean_cls), ("mean_cls_var", self.mean_cls_var),
-                        ("mean_delta", self.mean_delta), ("mean_reg_var", self.mean_reg_var), ("cand_keys", self.cand_keys),
-                        ("cand_count", self.cand_count), ("maybe_bits", self.maybe_bits), ("sel_keys", self.sel_keys),
+        for name, t in (("anchors", self.anchors), ("mean_cls", None), ("mean_cls_var", None),
+                        ("mean_delta", None), ("mean_reg_var", None), ("cand_keys", self.cand_keys),
+                        ("cand_count", self.cand_count), ("maybe_bits", None), ("sel_keys", self.sel_keys),
                         ("sel_count", self.sel_count), ("cat_keys", self.cat_keys), ("cat_level", self.cat_level),
                         ("probs_dense", self.probs_dense), ("n_total", self.n_total), ("cand_anchor_idx", self.cand_anchor_idx),
                         ("cand_level", self.cand_level), ("cand_class", self.cand_class), ("cand_score", self.cand_score),
@@ -180,6 +177,30 @@ class HotPath:
         self.ws = ws
         self._draws = 0          # native-RNG calls served so far (default Philox key stream, see _begin_draw)
         self._dirty = False      # an enqueue failed half way: counters / bitmap may be non-zero, reset before the next image
+
+    def _merged_planes(self) -> dict:
+        """Allocates (once) what only the two-launch merge / the eps-replay path touches."""
+        if self._planes is None:
+            K, D, dev = self.p.num_classes, self.cov_dims, self.device
+            f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+            merged = self.n_runs > 1
+            pl = {"mean_cls": f32(self.R * K) if merged else None,
+                  "mean_cls_var": f32(self.R * K) if merged and self.has_cls_var else None,
+                  "mean_delta": f32(self.R * 4) if merged and self.dense_box_merge else None,
+                  "mean_reg_var": f32(self.R * D) if merged and D > 0 and self.dense_box_merge else None, "maybe_bits": None}
+            if self.has_cls_var:
+                n_words = sum(self.p.num_anchors * K * ((h * w + 63) // 64) for h, w in self.shapes)   # == pod_maybe_words(): a word per (plane, 64 cells)
+                pl["maybe_bits"] = torch.zeros(n_words, dtype=torch.int64, device=dev)
+            for name, t in pl.items():
+                setattr(self.ws, name, hip.ptr(t))
+            self._planes = pl
+        return self._planes
+
+    mean_cls = property(lambda self: self._merged_planes()["mean_cls"])
+    mean_cls_var = property(lambda self: self._merged_planes()["mean_cls_var"])
+    mean_delta = property(lambda self: self._merged_planes()["mean_delta"])
+    mean_reg_var = property(lambda self: self._merged_planes()["mean_reg_var"])
+    maybe_bits = property(lambda self: self._merged_planes()["maybe_bits"])
 
     # ------------------------------------------------------------------------------------------
     def set_anchors(self, anchors: Sequence[torch.Tensor]) -> None:
@@ -220,8 +241,8 @@ class HotPath:
         if self._dirty:
             hip.check(self.lib.pod_reset_counters(hip.ptr(self.counters), int(self.counters.numel()), hip.current_stream()),
                       "pod_reset_counters")
-            if self.maybe_bits is not None:
-                self.maybe_bits.zero_()
+            if self._planes is not None and self._planes["maybe_bits"] is not None:
+                self._planes["maybe_bits"].zero_()
             self._dirty = False
 
     def _run_strided(self, name, l, t, c):

@@ -71,6 +71,8 @@ def fold_frozen_bn(module: nn.Module) -> int:
             n += 1
         else:
             n += fold_frozen_bn(child)
+    if n and hasattr(module, "_param_generation"):              # (a model serving HIP graphs: they were captured against the unfolded filters)
+        module._param_generation += 1
     return n
 
 
@@ -806,7 +808,14 @@ class ProbabilisticRetinaNet(nn.Module):
         self._anchor_cache: Dict[Tuple[int, int], List[torch.Tensor]] = {}
         self.use_graphs = False
         self.max_graphs = 12                                   # (stream, frame shape, flags) entries kept; each owns its activations
+        self.graph_after_seen = 0                              # forwards of a (stream, shape, flags) run eagerly before it is captured
         self._graphs: Dict[tuple, tuple] = {}
+        self._graph_seen: Dict[tuple, int] = {}
+        self._graph_serial = 0
+        self._param_generation = 0
+        self._fingerprint_tensors = None
+        self._graphs_fingerprint = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_param_generation", module._param_generation + 1))
 
     @property
     def device(self):
@@ -838,43 +847,96 @@ class ProbabilisticRetinaNet(nn.Module):
     # of the same (stream, shape, flags) -- on the same stream, so a consumer enqueued there before that is safe.
     def enable_graphs(self, on: bool = True) -> "ProbabilisticRetinaNet":
         self.use_graphs = bool(on)
-        if not on and self._graphs:
+        if not on:
+            self._drop_graphs()
+        return self
+
+    def _drop_graphs(self):
+        if self._graphs:
             torch.cuda.synchronize(self.device)          # (a consumer of a graph's tensors may still be queued)
             self._graphs.clear()
-        return self
+
+    # A captured graph holds raw pointers to the pre-transformed filters (WinoConv.U, Conv1x1.Ws, Stem7x7.Ws) and folded biases of the
+    # moment of capture: a graph must never answer for parameters that changed since.  Two things change them: a move / re-allocation
+    # (.to(), .cuda(), load_state_dict(assign=True), fold_frozen_bn: all go through _apply / the load hook / module surgery -> the
+    # generation counter) and an in-place write (load_state_dict, copy_: bumps the tensors' `_version`).  Both are in the fingerprint;
+    # when it moves, every graph is dropped and the next forward re-captures against re-transformed filters.
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._param_generation = getattr(self, "_param_generation", 0) + 1
+        return out
+
+    def _param_fingerprint(self):
+        gen = self._param_generation
+        ts = self._fingerprint_tensors
+        if ts is None or ts[0] != gen:
+            ts = self._fingerprint_tensors = (gen, [t for t in list(self.parameters()) + list(self.buffers()) if t is not self.head._epoch])
+        return gen, len(ts[1]), sum(t._version for t in ts[1])
 
     def _forward_graphed(self, image: torch.Tensor, n: int, dropout: bool, skip: bool) -> HeadOutputs:
         stream = torch.cuda.current_stream(image.device)
         from . import wino
+        fp = self._param_fingerprint()
+        if fp != self._graphs_fingerprint:
+            self._drop_graphs()
+            self._fingerprint_tensors = None                   # (module surgery -- fold_frozen_bn -- also changes WHICH tensors there are)
+            self._graphs_fingerprint = self._param_fingerprint()
         # (the kernel selection is part of the key: a graph captured with one convolution kernel must not answer for the other)
         key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip, bool(wino.SPLIT_BF16), CL_BACKBONE, WINO_BACKBONE)
         ent = self._graphs.get(key)
         if ent is None:
+            # graphs are for (stream, shape) pairs that come back: the first GRAPH_AFTER_SEEN forwards of a key run eagerly (a data set of
+            # many frame sizes would otherwise pay two eager forwards + a capture per image -- slower than no graphs at all)
+            seen = self._graph_seen.get(key, 0) + 1
+            if len(self._graph_seen) > 4096:
+                self._graph_seen.clear()
+            self._graph_seen[key] = seen
+            if seen <= self.graph_after_seen:
+                return self._forward_eager(image, n, dropout, skip)
             static_in = image.clone()
-            for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
-                self._forward_eager(static_in, n, dropout, skip)
-            stream.synchronize()
-            side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
-            side.wait_stream(stream)
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events must
-            # not abort it)
-            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                if dropout:
-                    self.head._epoch.add_(1)           # (captured: every replay starts by moving on to the next set of masks)
-                out = self._forward_eager(static_in, n, dropout, skip)
-            stream.wait_stream(side)
+            shared_epoch = self.head._epoch
+            # every graph owns its epoch word: replays of two graphs on two streams must not read-modify-write one word (the masks
+            # would depend on GPU timing).  It starts at (serial of the graph) << 32, so no two graphs ever draw the same masks and
+            # the masks of the i-th replay of the j-th captured graph are a function of (seed, j, i) alone.
+            self._graph_serial += 1
+            epoch = torch.full_like(shared_epoch, self._graph_serial << 32)
+            self.head._epoch = epoch
+            try:
+                for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
+                    self._forward_eager(static_in, n, dropout, skip)
+                stream.synchronize()
+                side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
+                side.wait_stream(stream)
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events
+                # must not abort it)
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    if dropout:
+                        epoch.add_(1)                      # (captured: every replay starts by moving on to the next set of masks)
+                    out = self._forward_eager(static_in, n, dropout, skip)
+                stream.wait_stream(side)
+            finally:
+                self.head._epoch = shared_epoch
             while len(self._graphs) >= self.max_graphs:          # frames of many different sizes: keep the most recent shapes only
-                torch.cuda.synchronize(image.device)             # (a consumer of the evicted graph's tensors may still be queued)
-                self._graphs.pop(next(iter(self._graphs)))
-            ent = (graph, static_in, out)
+                old_key = next(iter(self._graphs))
+                torch.cuda.ExternalStream(old_key[0], device=image.device).synchronize()   # (a consumer of the evicted graph's tensors may
+                self._graphs.pop(old_key)                                                  #  still be queued -- on ITS stream, nowhere else)
+            ent = (graph, static_in, out, epoch)
         else:
             self._graphs.pop(key)
         self._graphs[key] = ent                                # most recently used last
-        graph, static_in, out = ent
+        graph, static_in, out, _ = ent
         static_in.copy_(image, non_blocking=True)
         graph.replay()
         return out
+
+    def graph_epoch(self, stream=None, **match) -> Optional[torch.Tensor]:
+        """The epoch word of the most recently used graph on `stream` (default: the current one); tests and diagnostics."""
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        for key in reversed(list(self._graphs)):
+            if key[0] == st and key[4]:
+                return self._graphs[key][3]
+        return None
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False,

@@ -53,18 +53,21 @@ def test_graph_replay_equals_the_eager_forward_for_every_image_and_stream():
 
 def test_mc_dropout_forwards_replay_with_fresh_masks():
     """A captured MC-dropout forward must not repeat its masks: seed / offset are constants of the captured launches, so the Philox key
-    folds in a device word (head._epoch) that the graph itself bumps at the start of every replay.  Same epoch -> same bits; next
+    folds in a device word -- one PER GRAPH -- that the graph itself bumps at the start of every replay.  Same epoch -> same bits; next
     epoch -> other masks; and the masks are real dropout (a fifth of the first activation's copies zeroed)."""
     m = build(dropout_rate=0.2).enable_graphs()
     f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda")
     a = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
     assert len(m._graphs) == 1
-    e1 = int(m.head._epoch.item())
+    epoch = m.graph_epoch()
+    e1 = int(epoch.item())
+    assert e1 == (1 << 32) + 1                                         # graph serial 1, first replay
+    assert int(m.head._epoch.item()) == 0                              # the model's shared word is not what graphs write
     b = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
-    assert int(m.head._epoch.item()) == e1 + 1 and len(m._graphs) == 1
+    assert int(epoch.item()) == e1 + 1 and len(m._graphs) == 1
     assert not torch.equal(a[0], b[0])                                 # fresh masks
     assert not torch.equal(b[0][0], b[0][1])                           # and independent ones per run
-    m.head._epoch.fill_(e1 - 1)                                        # the replay bumps it to e1 again
+    epoch.fill_(e1 - 1)                                                # the replay bumps it to e1 again
     c = [t.clone() for t in tensors(m(f, num_mc_dropout_runs=3))]
     # (MIOpen's backbone kernels accumulate with atomics: to rounding, not bit for bit)
     for x, y in zip(a, c):
@@ -72,6 +75,74 @@ def test_mc_dropout_forwards_replay_with_fresh_masks():
     assert float((a[0] - b[0]).abs().max()) > 1e-3                      # while another epoch moves the outputs visibly
     m(f)                                                               # the dropout-free forward of the same model: its own graph
     assert len(m._graphs) == 2
+
+
+def test_two_streams_replaying_mc_dropout_graphs_are_deterministic_and_never_share_masks():
+    """apply_net runs two streams, each replaying its own graph, concurrently.  Each graph owns its epoch word (no read-modify-write race
+    on a shared one), so the masks of replay i of graph j are a function of (seed, j, i): two identical sessions give identical outputs,
+    whatever the GPU's timing, and no two forwards of a session share masks."""
+    f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+
+    def session():
+        m = build(dropout_rate=0.2).enable_graphs()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = []
+        for rep in range(4):
+            for s in streams:                       # both streams busy at once: replays of the two graphs overlap on the device
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    o = m(f, num_mc_dropout_runs=3)
+                    outs.append(o.cls[0].clone())
+        torch.cuda.synchronize()
+        assert len(m._graphs) == 2
+        ep = sorted(int(e[3].item()) for e in m._graphs.values())
+        assert ep == [(1 << 32) + 4, (2 << 32) + 4], ep
+        return outs
+
+    a, b = session(), session()
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 2e-4 * max(1.0, float(y.abs().max()))       # (MIOpen atomics: to rounding)
+    for i in range(len(a)):
+        for j in range(i + 1, len(a)):
+            assert float((a[i] - a[j]).abs().max()) > 1e-3, (i, j)                        # fresh masks everywhere
+
+
+def test_graphs_are_dropped_when_the_parameters_change():
+    """A graph holds pointers to filters transformed at capture time: after load_state_dict / an in-place write / a move, the next forward
+    must run on the new weights (it silently replayed the stale ones)."""
+    m = build().enable_graphs()
+    f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda")
+    a = [t.clone() for t in tensors(m(f))]
+    assert len(m._graphs) == 1
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["head.cls_score.weight"] = sd["head.cls_score.weight"] * 3.0
+    m.load_state_dict(sd)
+    b = [t.clone() for t in tensors(m(f))]
+    assert len(m._graphs) == 1                                          # dropped and re-captured
+    m.enable_graphs(False)
+    want = tensors(m(f))
+    close(b, want)
+    assert float((a[0] - b[0]).abs().max()) > 1e-4
+    m.enable_graphs()
+    m(f)
+    with torch.no_grad():
+        m.head.bbox_pred.bias.add_(0.5)                                 # in-place write: the tensors' version counters
+    c = [t.clone() for t in tensors(m(f))]
+    assert float((c[1] - b[1]).abs().min()) > 0.4
+    m.float()                                                           # _apply: generation counter
+    assert m._param_generation >= 2
+    close([t.clone() for t in tensors(m(f))], c)
+
+
+def test_a_shape_is_captured_only_after_it_came_back():
+    m = build().enable_graphs()
+    m.graph_after_seen = 2
+    f = torch.randint(0, 256, (3, 128, 160), dtype=torch.uint8, device="cuda")
+    a = [t.clone() for t in tensors(m(f))]
+    m(f)
+    assert not m._graphs
+    close(m(f), a)
+    assert len(m._graphs) == 1
 
 
 def test_parity_mode_and_the_miopen_head_path_are_not_captured():
