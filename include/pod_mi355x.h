@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 11
+#define POD_ABI_VERSION 12
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -345,43 +345,73 @@ int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* b
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                      const uint64_t* epoch, pod_stream_t stream);
 
-/* The same convolution with every fp32 product formed on the BF16 matrix cores (experimental, opt-in; csrc/k12_wino_conv_split.hip):
- * both operands are split exactly into three bf16 terms and the six significant partial products are accumulated in fp32
- * (v_mfma_f32_32x32x16_bf16) -- fp32-class accuracy against an fp64 convolution at 6/16 of the fp32 MFMA's matrix-pipe cycles.
- * Us = pod_wino_filter_transform_split(weight): 3 * 24 * round_up(K, 64) * C bf16 values.  Same arguments otherwise; C % 16 == 0. */
+/* ---- operand abs-max words (round 5; ABI 12) ------------------------------------------------------------------------------------
+ * The split convolutions below form every fp32 product from TWO F16 terms per operand; f16 has fp32's precision budget here (11 + 1 + 11
+ * bits, pod_wino.h) but not its range, so every operand tensor is scaled by a power of two derived from its abs-max.  Filters: static,
+ * inside the *_filter_split transforms.  Activations: a device word `in_amax` >= max |x| over what the launch reads -- an upper bound is
+ * enough (a looser bound costs low-order bits of tiny values only; a bound BELOW the true maximum overflows f16: the outputs are inf /
+ * nan, never silently wrong).  Producers publish it: every pod_* convolution takes `out_amax` (NULL, or a device word it max'es
+ * atomically with |every value it stores| -- the caller zeroes the word before the launch); pod_absmax computes it for any other tensor
+ * (the same max'ing: zero the word first).  Non-finite values are ignored by the max (they make the consumer's products inf / nan as
+ * they would in fp32). */
+int pod_absmax(const float* x, int64_t n, float* amax, pod_stream_t stream);
+
+/* The same convolution with every fp32 product formed on the 16-BIT matrix cores (csrc/k12_wino_conv_split.hip).  Rounds 3-4: exact 3-way
+ * bf16 splits, six partial products.  Round 5: 2-way F16 splits of the power-of-two-scaled operands, THREE partial products
+ * (v_mfma_f32_32x32x16_f16, fp32 accumulate) -- half the matrix instructions, and measured against fp64 on the matrix cores a smaller
+ * error than both the bf16 form and the fp32 MFMA (the fp32 accumulation chain is half as long; tools/f16_split_numerics.hip).
+ * Us = pod_wino_filter_transform_split(weight): pod_wino_filter_split_bytes(K, C) bytes (2 * 24 * round_up(K, 64) * C f16 terms + a 16-byte
+ * trailer holding the transformed filter's abs-max), 16-byte aligned.  C % 16 == 0.
+ *
+ * ONE entry for every form of the launch (rounds 3-4 exported pod_wino_conv3x3_split{,_replicas,_grouped,_partial}; they could not carry
+ * the abs-max words and are gone -- ABI 12):
+ *   - n_sets = 1..4 convolutions of ONE shape (C, K, relu, p, seed, epoch shared) in one grid: the cls- and the bbox-subnet layer l of the
+ *     head (PR:403-427), their first layers with the replicas, the four predictors (PR:430-484).  The kernel runs one workgroup per CU,
+ *     so a launch costs whole rounds of 256 workgroups: two launches of 1.5 rounds cost 4, one of 3.0 costs 3.  `blocks` = the sets' tables
+ *     concatenated; set s owns blocks [sets[s].first_block, sets[s + 1].first_block) (first_block of set 0 = 0) and its records stay
+ *     relative to ITS in / out.  Bit for bit the n_sets separate launches.
+ *   - sets[s].replicas = r >= 1: the first conv of an MC-dropout subnet and the replication behind it (PR:403-427's first Conv2d + ReLU +
+ *     Dropout under PR:95-108's run loop): every MC run sees the same features, so the conv is evaluated once and the store pass writes
+ *     the runs' r (<= 127) dropout-masked copies -- replica i = image i of the record's output canvas (table: one input image per record,
+ *     r output images).  Bit for bit p = 0 followed per level by pod_expand_dropout(copies = r, p, seed, offset + (index of the level's
+ *     first output float) / 8, epoch).
+ *   - sets[s].k_planes > 0: NCHW planes (the predictor convs); then p = 0 and no replicas.
+ *   - n_splits > 1 (small maps; one set): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  The INPUT channels
+ *     are cut into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): sets[0].out receives n_splits
+ *     channels-last (out_pixels, K) arrays of partial sums (no bias / ReLU / dropout), split_stride floats apart; pod_wino_reduce /
+ *     pod_reduce_partials add them in a fixed order. */
+typedef struct PodConvSet {
+    const float* in;        /* channels-last activations [pixel][C] */
+    float* out;             /* channels-last [pixel][K], NCHW planes (k_planes > 0) or partial sums (n_splits > 1) */
+    const void* Us;         /* pod_wino_filter_transform_split */
+    const float* bias;      /* K floats (zero-padded) or NULL */
+    const float* in_amax;   /* device word >= max |in| (see above); required */
+    float* out_amax;        /* NULL, or a zeroed device word: max'ed with |every value stored| */
+    uint64_t offset;        /* Philox offset of this set's dropout masks */
+    int32_t first_block;    /* first record of the set in `blocks` */
+    int32_t replicas;       /* 0: an ordinary launch; r >= 1: r masked replicas per input image */
+    int32_t k_planes;       /* 0: channels-last out; > 0: NCHW planes of k_planes real channels */
+    int32_t reserved;
+} PodConvSet;
+typedef struct PodWinoConv {
+    const int32_t* blocks;  /* device, 16-byte aligned int32x4 records (pod_wino_conv3x3) */
+    int32_t n_blocks, n_sets;
+    int32_t C, K, relu;
+    float p;                /* dropout rate of the store pass, [0, 1) */
+    uint64_t seed;
+    const uint64_t* epoch;  /* NULL or the device word folded into the Philox key (pod_expand_dropout) */
+    int32_t n_splits;       /* <= 1: off */
+    int32_t reserved;
+    int64_t split_stride;
+    PodConvSet sets[4];
+} PodWinoConv;
+int64_t pod_wino_filter_split_bytes(int32_t K, int32_t C);
 int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream);
-int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                           int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                           const uint64_t* epoch, pod_stream_t stream);
-/* The first conv of an MC-dropout subnet and the replication behind it in ONE launch (round 4; ABI 9).  Replaces PR:403-427's first
- * Conv2d + ReLU + Dropout under PR:95-108's run loop: every MC run sees the same features, so the conv is evaluated once and its store
- * pass writes the runs' `replicas` (<= 127) dropout-masked copies -- replica r = image r of the record's output canvas (the table:
- * one input image per record, `replicas` output images; pod_compare_amd/wino.py block_table(levels, 1, out_copies = replicas)).
- * Channels-last in and out.  Bit for bit pod_wino_conv3x3_split with p = 0, followed per level by pod_expand_dropout(copies = replicas,
- * p, seed, offset + (index of the level's first output float) / 8, epoch): the separate pass (0.17 ms of a 10-ms image) is gone. */
-int pod_wino_conv3x3_split_replicas(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                                    int32_t C, int32_t K, int32_t relu, int32_t replicas, float p, uint64_t seed, uint64_t offset,
-                                    const uint64_t* epoch, pod_stream_t stream);
-/* Up to four convolutions of ONE shape in one grid (round 4; ABI 11): the cls- and the bbox-subnet layer l of the head (PR:403-427), their
- * first layers with the replicas, the four predictors (PR:430-484).  The kernel runs one workgroup per CU, so a launch costs whole rounds
- * of 256 workgroups: two launches of 1.5 rounds cost 4, one of 3.0 costs 3.  blocks = the sets' tables concatenated, set s owning blocks
- * [set_first[s], set_first[s + 1]) (set_first[0] = 0); a record stays relative to ITS set's in[s] / out[s]; every set has its own filter
- * Us[s], bias[s], Philox offset offsets[s], replica count replicas[s] (0: an ordinary launch; r >= 1: pod_wino_conv3x3_split_replicas'
- * store pass) and plane count k_planes[s] (0: channels-last out; > 0:
- * NCHW planes, then p = 0 and no replicas).  C, K, relu, p, seed, epoch are shared.  Bit for bit the n_sets separate launches. */
-int pod_wino_conv3x3_split_grouped(int32_t n_sets, const float* const* in, float* const* out, const void* const* Us, const float* const* bias,
-                                   const int32_t* set_first, const int32_t* replicas, const int32_t* k_planes, const uint64_t* offsets,
-                                   const int32_t* blocks, int32_t n_blocks, int32_t C, int32_t K, int32_t relu, float p, uint64_t seed,
-                                   const uint64_t* epoch, pod_stream_t stream);
-/* Small maps (round 4): a res5 convolution of the backbone is 48 workgroups of 32 chunks for 256 CUs.  pod_wino_conv3x3_split_partial
- * cuts the INPUT channels into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): `partials` receives
- * n_splits channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart (K = round_up(real K, 64));
- * pod_wino_reduce adds them in a fixed order, applies bias (K values, zero-padded) + ReLU and writes the k_real planes of ONE NCHW
- * image (HW = out_pixels).  Replaces the same reference lines as pod_wino_conv3x3 (detectron2 BottleneckBlock.conv2, FPN.output_convs). */
-int pod_wino_conv3x3_split_partial(const float* in, float* partials, const void* Us, const int32_t* blocks, int32_t n_blocks, int32_t C,
-                                   int32_t K, int32_t n_splits, int64_t split_stride, pod_stream_t stream);
+int pod_wino_conv3x3_split(const PodWinoConv* conv, pod_stream_t stream);
+/* pod_wino_reduce: the partial sums of an n_splits launch -> bias (K values, zero-padded) + ReLU -> the k_real planes of ONE NCHW image (HW =
+ * out_pixels).  Replaces the same reference lines as pod_wino_conv3x3 (detectron2 BottleneckBlock.conv2, FPN.output_convs). */
 int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
-                    int32_t K, int32_t k_real, int32_t relu, pod_stream_t stream);
+                    int32_t K, int32_t k_real, int32_t relu, float* out_amax, pod_stream_t stream);
 
 /* ---- the ResNet stem, channels-last (round 4; ABI 10; csrc/k14_stem_conv.hip) -------------------------------------------
  * Replaces detectron2's BasicStem as probabilistic_retinanet.py:96-100 runs it (`features = self.backbone(images.tensor)`):
@@ -429,6 +459,8 @@ int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids,
 /* test support for pod_wino_conv3x3_split's arithmetic contract: the three bf16 terms (bit patterns, terms dev uint16 [3][n]) the kernel
  * forms of each fp32 operand x[i] (dev, n even): x == t0 + t1 + t2 exactly (tests/test_wino_conv_gpu.py). */
 int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t stream);
+/* terms[2][n] f16 bit patterns: x[i] * scale = t0 + t1 to 2^-23 |x[i] scale| (scale a power of two; the round-5 split kernels' own code) */
+int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, pod_stream_t stream);
 
 /* ---- K13 conv1x1_split (round 4): the 1x1 convolutions of the backbone / FPN as a channels-last GEMM ------------------------
  * Replaces: detectron2 BottleneckBlock.conv1 / conv3 / shortcut (1x1, stride 1 or 2, FrozenBN folded, ReLU, residual add) and
@@ -442,7 +474,7 @@ int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t s
  * floats), added in a fixed order with bias / residual / ReLU by a second launch. */
 int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
 int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y,
-                        int64_t n, int32_t Cout, int32_t relu, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
+                        int64_t n, int32_t Cout, int32_t relu, float* out_amax, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
 int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
                       int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
                       pod_stream_t stream);

@@ -1,27 +1,25 @@
 // The head's 3x3 convolutions (probabilistic_retinanet.py:403-484) once more -- same Winograd F(2,3) x F(4,3) formulation, same data
 // path (patch as full 128-byte lines by LDS-DMA, filters from L2, the same prologue and epilogue) and the same results to fp32
-// rounding as pod_wino_conv3x3 (k11_wino_conv.hip) -- with every fp32 product formed on the BF16 matrix cores: both operands are
-// split exactly into three bf16 terms (x = x0 + x1 + x2, 8 significand bits each) and the six partial products that matter are
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Against an fp64 reference this is as accurate as the fp32 MFMA
-// (profiles/r03_experiments.md: error constant 2.5 vs 3.1 on a K = 2304 dot product) at 6/16 of its matrix-pipe cycles: the fp32
-// MFMA of gfx950 runs at the vector rate, 1/16 of the bf16 rate.
+// rounding as pod_wino_conv3x3 (k11_wino_conv.hip) -- with every fp32 product formed on the 16-BIT matrix cores.
+// Round 5: both operands are scaled by a power of two and split into TWO f16 terms (x s = x0 + x1 to 2^-23 |x s|, pod_wino.h) and the
+// three partial products that matter (x0 u1, x1 u0, x0 u0) are accumulated in fp32 by v_mfma_f32_32x32x16_f16: half the matrix
+// instructions of rounds 3-4's 3-way bf16 split (six products), two thirds of its filter bytes and 4/7 of its split arithmetic -- and,
+// measured on the matrix cores against fp64 (tools/f16_split_numerics.hip), a SMALLER error than both the bf16 x 6 form and the fp32
+// MFMA: the fp32 accumulation chain, not the products, is where these kernels lose bits, and it is half as long.
 #include "pod_wino.h"
 
 namespace pod {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t vu32x4 __attribute__((ext_vector_type(4)));
-constexpr int WINO_US_BYTES = 24 * 2 * 3 * 64 * 16;      // pre-split filter terms of a 16-channel chunk: [24 positions][kb][term][h][j][8 bf16]  144 KB
+constexpr int WINO_US_BYTES = 24 * 2 * 2 * 64 * 16;      // pre-split filter terms of a 16-channel chunk: [24 positions][kb][term][h][j][8 f16]  96 KB
+constexpr int WINO_U_TOP = 14, WINO_V_TOP = 9;           // scaled filter abs-max in [2^14, 2^15); activations: 2^9 <= s amax < 2^10, x gain of Bt4 (x) Bt6 < 32
 constexpr int WINO_WAIT_VM24 = 0x4078;                    // lgkmcnt(0) vmcnt(24)
 
-// Filter transform U = G4 g G6t as in k_wino_filter, every value split into three bf16 terms (round to nearest: u = u0 + u1 + u2),
+// Filter transform U = G4 g G6t as in k_wino_filter.  Two passes: the abs-max of U (-> the trailer word of Us, behind the terms), then
+// every value times the power of two that puts that abs-max into [2^14, 2^15) split into two f16 terms (round to nearest even) and
 // written in the order the kernel's lanes load them:
-// Us[ks][chunk16][q = 6 a + p][kb][term][h][j][e] = term(U_q[c = 16 chunk16 + 8 h + e][k = 64 ks + 32 kb + j]); channels >= K are zero.
-__global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Us, int32_t K, int32_t C, int32_t Kpad) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)Kpad * C) return;
-    const int k = (int)(t / C), c = (int)(t % C);
+// Us[ks][chunk16][q = 6 a + p][kb][term][h][j][e] = term(s U_q[c = 16 chunk16 + 8 h + e][k = 64 ks + 32 kb + j]); channels >= K are zero.
+__device__ __forceinline__ void wino_filter_values(const float* __restrict__ w, int k, int c, int K, int C, float (&u)[4][6]) {
     float g[3][3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = k < K ? w[((int64_t)k * C + c) * 9 + i] : 0.0f;
@@ -33,36 +31,49 @@ __global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restri
         t0[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
         t0[3][j] = g[2][j];
     }
-    const int nchunk = C / 16, ks = k >> 6, kb = (k >> 5) & 1, j32 = k & 31, ch = c >> 4, hh = (c >> 3) & 1, e = c & 7;
-    uint16_t* dst = Us + (((int64_t)ks * nchunk + ch) * (int64_t)WINO_US_BYTES) / 2 + (hh * 32 + j32) * 8 + e;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float x0 = t0[a][0], x1 = t0[a][1], x2 = t0[a][2];
-        float u[6];
-        u[0] = 0.25f * x0;
-        u[1] = (-1.0f / 6.0f) * (x0 + x1 + x2);
-        u[2] = (-1.0f / 6.0f) * (x0 - x1 + x2);
-        u[3] = (1.0f / 24.0f) * x0 + (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
-        u[4] = (1.0f / 24.0f) * x0 - (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
-        u[5] = x2;
+        u[a][0] = 0.25f * x0;
+        u[a][1] = (-1.0f / 6.0f) * (x0 + x1 + x2);
+        u[a][2] = (-1.0f / 6.0f) * (x0 - x1 + x2);
+        u[a][3] = (1.0f / 24.0f) * x0 + (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
+        u[a][4] = (1.0f / 24.0f) * x0 - (1.0f / 12.0f) * x1 + (1.0f / 6.0f) * x2;
+        u[a][5] = x2;
+    }
+}
+__global__ void __launch_bounds__(256) k_wino_filter_amax(const float* __restrict__ w, float* __restrict__ amax, int32_t K, int32_t C, int32_t Kpad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    if (t < (int64_t)Kpad * C) {
+        float u[4][6];
+        wino_filter_values(w, (int)(t / C), (int)(t % C), K, C, u);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) m = fmaxf(m, fabsf(u[i / 6][i % 6]));
+    }
+    wino_publish_amax(amax, m);
+}
+__global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Us, const float* __restrict__ amax,
+                                                           int32_t K, int32_t C, int32_t Kpad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Kpad * C) return;
+    const int k = (int)(t / C), c = (int)(t % C);
+    float u[4][6];
+    wino_filter_values(w, k, c, K, C, u);
+    const float sc = wino_pow2_scale(*amax, WINO_U_TOP);
+    const int nchunk = C / 16, ks = k >> 6, kb = (k >> 5) & 1, j32 = k & 31, ch = c >> 4, hh = (c >> 3) & 1, e = c & 7;
+    uint16_t* dst = Us + (((int64_t)ks * nchunk + ch) * (int64_t)WINO_US_BYTES) / 2 + (hh * 32 + j32) * 8 + e;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-            auto rne = [](float f) {                                             // fp32 -> bf16 bits in the top half, round to nearest even
-                uint32_t w = __float_as_uint(f);
-                w += 0x7FFFu + ((w >> 16) & 1u);
-                return w & 0xFFFF0000u;
-            };
-            const uint32_t b0 = rne(u[p]);
-            const float r1 = u[p] - __uint_as_float(b0);
-            const uint32_t b1 = rne(r1);
-            const float r2 = r1 - __uint_as_float(b1);
-            const uint32_t b2 = rne(r2);
-            uint16_t* d = dst + (((a * 6 + p) * 2 + kb) * 3) * 512;            // 512 bf16 = 64 lanes x 8 per (position, kb, term)
-            d[0] = (uint16_t)(b0 >> 16);
-            d[512] = (uint16_t)(b1 >> 16);
-            d[1024] = (uint16_t)(b2 >> 16);
+            const float x = u[a][p] * sc;                                        // exact
+            const _Float16 h0 = (_Float16)x;                                     // v_cvt_f16_f32: round to nearest even
+            const _Float16 h1 = (_Float16)(x - (float)h0);
+            uint16_t* d = dst + (((a * 6 + p) * 2 + kb) * 2) * 512;            // 512 f16 = 64 lanes x 8 per (position, kb, term)
+            d[0] = __builtin_bit_cast(uint16_t, h0);
+            d[512] = __builtin_bit_cast(uint16_t, h1);
         }
-    }
 }
 
 __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams P) {
@@ -99,20 +110,24 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     const float* const set_in = P.sets.in[set];
     float* const set_out = P.sets.out[set];
     const float* const set_bias = P.sets.bias[set];
+    // operand scales of the f16 split (pod_wino.h): two scalar loads, asked for first and needed only when the first patch is split
+    const float in_amax = *P.sets.in_amax[set];
+    const float u_amax = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(set_U) + (int64_t)P.KS * (P.C >> 4) * WINO_US_BYTES);
+    float* const set_out_amax = P.sets.out_amax[set];
     const uint64_t set_offset = P.sets.offset[set];
     const int set_replicas = P.sets.replicas[set], set_k_planes = P.sets.k_planes[set];
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(set_U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
                                                           nchunk * WINO_US_BYTES, 0x00020000);
-    const int u_off = (a * 6 * 6 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*3 + split) KB, + chunk * 144 KB
-    vu32x4 uP[3][6];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
-                                                                          // 12 MFMAs last 384 cycles, an L2 round trip under load longer)
-    auto filter_piece = [&](int q16, int p, vu32x4(&u)[6], int i) {       // i = kb*3 + split: one buffer_load_dwordx4 (8 bf16) each
-        u[i] = __builtin_bit_cast(vu32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, q16 * WINO_US_BYTES + (p * 6 + i) * 1024, 0));
+    const int u_off = (a * 6 * 4 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*2 + term) KB, + chunk * 96 KB
+    vu32x4 uP[3][4];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
+                                                                          // 6 MFMAs last 192 cycles, an L2 round trip under load longer)
+    auto filter_piece = [&](int q16, int p, vu32x4(&u)[4], int i) {       // i = kb*2 + term: one buffer_load_dwordx4 (8 f16) each
+        u[i] = __builtin_bit_cast(vu32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, q16 * WINO_US_BYTES + (p * 4 + i) * 1024, 0));
     };
 #pragma unroll
-    for (int i = 0; i < 6; ++i) filter_piece(0, 0, uP[0], i);
+    for (int i = 0; i < 4; ++i) filter_piece(0, 0, uP[0], i);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) filter_piece(0, 1, uP[1], i);
+    for (int i = 0; i < 4; ++i) filter_piece(0, 1, uP[1], i);
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
@@ -220,7 +235,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // hides), so the K loop fills the stages through registers: every chunk loads 6 pieces (one buffer_load_dwordx4 each) and parks the
     // 6 it loaded a chunk earlier (ds_write_b128: free).
     f32x4 stg[6];
-#define WINO_STG_SLOT(p, m) ((p) == 4 && (m) == 11 ? 0 : (p) == 5 && (m) == 6 ? 1 : (p) == 5 && (m) >= 8 ? (m) - 6 : -1)
     const uint32_t stg_addr = lds_base + a * 12288 + lane * 16;          // + stage * 48 KB + piece * 1 KB
     auto stage_load = [&](int k, int sc, int i) {
         stg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, doff[i], sc * 128, 0));
@@ -231,11 +245,11 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
 
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first product multiplies into a zero C
     f32x4 x[12];                                                         // raw patch, one 4-channel half at a time: x[row][c]
-    vu32x4 Vb[6][3];                                                      // the transformed patch as bf16 operands: [position][split], 8 channels (regs 0-1: channels 0-3, 2-3: 4-7)
+    vu32x4 Vb[6][2];                                                      // the transformed patch as f16 operands: [position][term], 8 channels (regs 0-1: channels 0-3, 2-3: 4-7)
     float tN[6][4], vN[2][6][4];                                         // the NEXT chunk's transform in flight: row-combined columns; transformed values [half][position] (fp32, split later)
 #if POD_WINO_ELIM
 #pragma unroll
-    for (int i = 0; i < 18; ++i) Vb[i / 3][i % 3] = vu32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + lane};
+    for (int i = 0; i < 12; ++i) Vb[i / 2][i % 2] = vu32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + lane};
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
 #pragma unroll
@@ -293,33 +307,35 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         vN[hf][4][e] = __builtin_fmaf(-2.0f, gs[e], fs[e]);
         wino_pin(vN[hf][0][e], vN[hf][1][e], vN[hf][2][e], vN[hf][3][e], vN[hf][4][e], vN[hf][5][e]);
     };
-    // The three bf16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in five steps whose
-    // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert -> residual -> convert):
-    // w = nearest-even bf16 pair (v_cvt_pk_bf16_f32), residual r = v - w exactly (in place: vN is dead afterwards).
-    const WinoSplitSel split_sel;
+    // The two f16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in three steps whose
+    // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert):
+    // w = nearest-even f16 pair of (v s) (v_fma_mixlo/hi_f16), residual r = v s - w exactly (v_fma_mix_f32, in place: vN is dead
+    // afterwards), second term = nearest-even f16 pair of r (v_cvt_pk_f16_f32).
+    const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(in_amax, WINO_V_TOP))));
     auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
         vu32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                                      // i = 2 hf + pair: regs 0-1 channels 0-3, 2-3 channels 4-7
             wino_pin(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
-            w[i] = wino_bf16_pair(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
+            w[i] = term == 0 ? wino_f16_pair_scaled(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1], sv)
+                             : wino_f16_pair(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
         }
         Vb[p][term] = w;
         wino_pin(Vb[p][term]);
     };
-    auto split_residual = [&](int p, int term, int i0, int i1) __attribute__((always_inline)) {      // v -= the term just made, exactly
-        wino_pin(Vb[p][term]);
+    auto split_residual = [&](int p, int i0, int i1) __attribute__((always_inline)) {      // v <- v s - the first term, exactly
+        wino_pin(Vb[p][0]);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             float& lo = vN[i >> 1][p][2 * (i & 1)];
             float& hi = vN[i >> 1][p][2 * (i & 1) + 1];
             wino_pin(lo, hi);
-            wino_bf16_residual(Vb[p][term][i], lo, hi, split_sel);
+            wino_f16_residual_scaled(Vb[p][0][i], lo, hi, sv);
             wino_pin(lo, hi);
         }
     };
-    auto split_position = [&](int p) __attribute__((always_inline)) {                      // all five steps back to back
-        split_convert(p, 0); split_residual(p, 0, 0, 4); split_convert(p, 1); split_residual(p, 1, 0, 4); split_convert(p, 2);
+    auto split_position = [&](int p) __attribute__((always_inline)) {                      // all three steps back to back
+        split_convert(p, 0); split_residual(p, 0, 4); split_convert(p, 1);
     };
     auto make_v = [&](int hf) __attribute__((always_inline)) {                             // serial form: x (12 reads of half hf) -> vN[hf]
         if (POD_WINO_ELIM & 8) return;
@@ -335,69 +351,62 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         for (int p = 0; p < 6; ++p) split_position(p);
     };
 
-    // One chunk = 16 input channels = one k-step of v_mfma_f32_32x32x16_bf16.  Every fp32 product x * u is formed from the three bf16
-    // terms of each operand: the 6 partial products that matter (x1u1, x0u2, x2u0, x0u1, x1u0, x0u0: small ones first), fp32 accumulate --
-    // against fp64 as accurate as the fp32 MFMA (profiles/r03_experiments.md), at 6/16 of its matrix-pipe cycles.  72 MFMAs per
-    // chunk: positions p = 0..5 of the wave's row, two channel blocks, 6 products; the filter terms of position p + 2 (6 x 16 B per lane,
-    // pre-split, from L2) are loaded behind the first six MFMAs of position p.
+    // One chunk = 16 input channels = one k-step of v_mfma_f32_32x32x16_f16.  Every fp32 product x * u is formed from the two f16 terms
+    // of each (scaled) operand: the 3 partial products that matter (x1 u0, x0 u1, x0 u0: small ones first), fp32 accumulate.  36 MFMAs
+    // per chunk: positions p = 0..5 of the wave's row, two channel blocks, 3 products; the filter terms of position p + 2 (4 x 16 B per
+    // lane, pre-split, from L2) are loaded behind the first four MFMAs of position p.
     //
-    // SOFTWARE PIPELINE (round 4).  The 312 VALU instructions that turn the next chunk's raw patch into bf16 operands used to run
-    // between the chunks -- 1 300 of a chunk's 5 080 cycles with the matrix pipe idle (elimination build: K loop 81.3 k -> 60.4 k cycles
-    // without them).  They now sit BEHIND the MFMAs of the running chunk, one unit of <= 4 independent instructions per slot:
-    //     A   the three terms of the running chunk's own position 5 (its values were computed during the previous chunk; Vb[5] is read
-    //         last, and could not be overwritten while the previous chunk's position 5 was still to come)
-    //     R0 T0   12 LDS reads of the next chunk's first 4-channel half, the row combination       (x -> tN)
+    // SOFTWARE PIPELINE (round 4, re-slotted for 36 MFMAs in round 5).  The VALU instructions that turn the next chunk's raw patch into f16
+    // operands sit BEHIND the MFMAs of the running chunk, one unit of <= 6 independent instructions at a time:
+    //     R0      12 LDS reads of the next chunk's first 4-channel half
+    //     A       the two terms of the running chunk's own position 5 (its values were computed during the previous chunk; Vb[5] is read
+    //             last, and could not be overwritten while the previous chunk's position 5 was still to come)
+    //     T0      the row combination of the first half                                             (x -> tN)
     //     R1 V0   the second half's reads; the first half's column transform                       (tN -> vN[0])
     //     T1 V1   the same for the second half                                                      (-> vN[1])
-    //     C0..C4  the three terms of the next chunk's positions 0..4 -- each after the running chunk's MFMAs of that position have issued
+    //     C0..C4  the two terms of the next chunk's positions 0..4 -- each after the running chunk's MFMAs of that position have issued
     // which needs the next chunk's patch to stand in a PUBLISHED stage when the chunk begins: super-chunk s + 1 is therefore complete one
     // chunk earlier than before -- chunk (s - 1, 1) parks its pieces 0..5, chunk (s, 0) pieces 6..11 -- in the stage whose last read (for
     // chunk (s - 1, 1), issued during (s - 1, 0)) lies a barrier behind.
-    constexpr int N_UNITS = 84;
+    constexpr int N_UNITS = 58, N_SLOTS = 36;
     auto unit = [&](auto U, auto npar_t, auto n16_t, auto hasA_t) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value, npar = decltype(npar_t)::value, n16 = decltype(n16_t)::value;
-        if constexpr (POD_WINO_ELIM & 8) { if constexpr (u >= 3 && !(u >= 16 && u < 19)) return; }
+        if constexpr (POD_WINO_ELIM & 8) { if constexpr (u >= 3 && !(u >= 13 && u < 16)) return; }
         if constexpr (u < 3) {                                                             // R0
             if constexpr (!(POD_WINO_ELIM & 1)) { WINO_READ(npar, n16, 0, 4 * u); WINO_READ(npar, n16, 0, 4 * u + 1); WINO_READ(npar, n16, 0, 4 * u + 2); WINO_READ(npar, n16, 0, 4 * u + 3); }
-        } else if constexpr (u < 10) {                                                     // A (7 units)
+        } else if constexpr (u < 7) {                                                      // A (4 units)
             if constexpr (decltype(hasA_t)::value) {
                 constexpr int k = u - 3;
                 if constexpr (k == 0) split_convert(5, 0);
-                else if constexpr (k == 1) split_residual(5, 0, 0, 2);
-                else if constexpr (k == 2) split_residual(5, 0, 2, 4);
-                else if constexpr (k == 3) split_convert(5, 1);
-                else if constexpr (k == 4) split_residual(5, 1, 0, 2);
-                else if constexpr (k == 5) split_residual(5, 1, 2, 4);
-                else split_convert(5, 2);
+                else if constexpr (k == 1) split_residual(5, 0, 2);
+                else if constexpr (k == 2) split_residual(5, 2, 4);
+                else split_convert(5, 1);
             }
-        } else if constexpr (u < 16) {                                                     // T0 (6 units: one column each)
-            if constexpr (u == 10) WINO_READS_LANDED();
-            rows_combine(u - 10, u - 9);
-        } else if constexpr (u < 19) {                                                     // R1
-            if constexpr (!(POD_WINO_ELIM & 1)) { WINO_READ(npar, n16, 1, 4 * (u - 16)); WINO_READ(npar, n16, 1, 4 * (u - 16) + 1); WINO_READ(npar, n16, 1, 4 * (u - 16) + 2); WINO_READ(npar, n16, 1, 4 * (u - 16) + 3); }
-        } else if constexpr (u < 31) {                                                     // V0 (12 units: level 1 and level 2 of each channel, 6 ops each)
-            constexpr int k = u - 19;
+        } else if constexpr (u < 13) {                                                     // T0 (6 units: one column each)
+            if constexpr (u == 7) WINO_READS_LANDED();
+            rows_combine(u - 7, u - 6);
+        } else if constexpr (u < 16) {                                                     // R1
+            if constexpr (!(POD_WINO_ELIM & 1)) { WINO_READ(npar, n16, 1, 4 * (u - 13)); WINO_READ(npar, n16, 1, 4 * (u - 13) + 1); WINO_READ(npar, n16, 1, 4 * (u - 13) + 2); WINO_READ(npar, n16, 1, 4 * (u - 13) + 3); }
+        } else if constexpr (u < 24) {                                                     // V0 (8 units: level 1 and level 2 of each channel, 6 ops each)
+            constexpr int k = u - 16;
             if constexpr (k < 4) columns_level1(k);
-            else if constexpr (k < 8) columns_level2(0, k - 4);
-        } else if constexpr (u < 37) {                                                     // T1
-            if constexpr (u == 31) WINO_READS_LANDED();
-            rows_combine(u - 31, u - 30);
-        } else if constexpr (u < 49) {                                                     // V1
-            constexpr int k = u - 37;
+            else columns_level2(0, k - 4);
+        } else if constexpr (u < 30) {                                                     // T1
+            if constexpr (u == 24) WINO_READS_LANDED();
+            rows_combine(u - 24, u - 23);
+        } else if constexpr (u < 38) {                                                     // V1
+            constexpr int k = u - 30;
             if constexpr (k < 4) columns_level1(k);
-            else if constexpr (k < 8) columns_level2(1, k - 4);
+            else columns_level2(1, k - 4);
         } else {                                                                           // C0..C4
-            constexpr int p = (u - 49) / 7, k = (u - 49) % 7;
+            constexpr int p = (u - 38) / 4, k = (u - 38) % 4;
             if constexpr (k == 0) split_convert(p, 0);
-            else if constexpr (k == 1) split_residual(p, 0, 0, 2);
-            else if constexpr (k == 2) split_residual(p, 0, 2, 4);
-            else if constexpr (k == 3) split_convert(p, 1);
-            else if constexpr (k == 4) split_residual(p, 1, 0, 2);
-            else if constexpr (k == 5) split_residual(p, 1, 2, 4);
-            else split_convert(p, 2);
+            else if constexpr (k == 1) split_residual(p, 0, 2);
+            else if constexpr (k == 2) split_residual(p, 2, 4);
+            else split_convert(p, 1);
         }
     };
-    // units of slot j: [j * 84 / 72, (j + 1) * 84 / 72) -- C(p) starts at unit 49 + 7 p = slot 42 + 6 p >= 12 (p + 1): behind position p's MFMAs
+    // units of slot j: [j * 58 / 36, (j + 1) * 58 / 36) -- C(p) starts at unit 38 + 4 p = slot >= 23 + 2 p >= 6 (p + 1): behind position p's MFMAs
     const int last = nchunk - 1, last_s = last >> 1;
     const int sc1 = last_s < 1 ? last_s : 1;
 #pragma unroll
@@ -442,27 +451,31 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         // its OWN stage (nobody reads it any more: the next chunk's operands come from the other one) and loads 6..11 of s + 2
         const int ls0 = (q >> 1) + 2, ls = ls0 < last_s ? ls0 : last_s;
         wino_static_for([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value, p = j / 12, m = j % 12, kb = m & 1, prod = m >> 1;
-            constexpr int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;      // filter term of the product
-            constexpr int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;   // patch term
+            constexpr int j = decltype(J)::value, p = j / 6, m = j % 6, kb = m & 1, prod = m >> 1;
+            constexpr int sa = prod == 1 ? 1 : 0;      // filter term of the product
+            constexpr int sb = prod == 0 ? 1 : 0;      // patch term:  x1 u0, x0 u1, x0 u0
             if constexpr (mode == 0 && prod == 0)
-                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), zero16, 0, 0, 0);
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p % 3][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), zero16, 0, 0, 0);
             else
-                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, uP[p % 3][kb * 3 + sa]), __builtin_bit_cast(bf16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
-            if constexpr (m < 6) { if (!(POD_WINO_ELIM & 2)) filter_piece(p >= 4 ? qn : q, (p + 2) % 6, uP[(p + 2) % 3], m); }
-            else if constexpr (m == 7) { if (!(POD_WINO_ELIM & 4)) stage_write(c16 == 0 ? par ^ 1 : par, p, c16 == 0 ? 6 + p : p); }
-            else if constexpr (WINO_STG_SLOT(p, m) >= 0) {       // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
-                if (!(POD_WINO_ELIM & 4)) stage_load(WINO_STG_SLOT(p, m), ls, 6 * c16 + WINO_STG_SLOT(p, m));           // order, and every filter term ahead is needed soon
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p % 3][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
+            if constexpr (m < 4) { if (!(POD_WINO_ELIM & 2)) filter_piece(p >= 4 ? qn : q, (p + 2) % 6, uP[(p + 2) % 3], m); }
+            else if constexpr (m == 4) { if (!(POD_WINO_ELIM & 4)) stage_write(c16 == 0 ? par ^ 1 : par, p, c16 == 0 ? 6 + p : p); }
+            if constexpr (p == 5 && m >= 4) {                    // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
+                if (!(POD_WINO_ELIM & 4)) {                      // order, and every filter term ahead is needed soon
+                    stage_load(3 * (m - 4), ls, 6 * c16 + 3 * (m - 4));
+                    stage_load(3 * (m - 4) + 1, ls, 6 * c16 + 3 * (m - 4) + 1);
+                    stage_load(3 * (m - 4) + 2, ls, 6 * c16 + 3 * (m - 4) + 2);
+                }
             }
             if constexpr (mode != 0) {
-                constexpr int u0 = j * N_UNITS / 72, u1 = (j + 1) * N_UNITS / 72;
+                constexpr int u0 = j * N_UNITS / N_SLOTS, u1 = (j + 1) * N_UNITS / N_SLOTS;
                 wino_static_for([&](auto K) __attribute__((always_inline)) {
                     unit(std::integral_constant<int, u0 + decltype(K)::value>{}, std::integral_constant<int, npar>{}, std::integral_constant<int, n16>{},
                          std::integral_constant<bool, mode == 2>{});
                 }, std::make_integer_sequence<int, u1 - u0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
-        }, std::make_integer_sequence<int, 72>{});
+        }, std::make_integer_sequence<int, N_SLOTS>{});
         // No vmcnt wait: the pieces this chunk parked were loaded a chunk ago (hipcc waits for them where they are stored), the DMA pieces of
         // the prologue were issued before filter terms this chunk's MFMAs have consumed, and loads return in order.  The barrier publishes the
         // stage and retires this chunk's LDS reads.
@@ -533,6 +546,11 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
 #endif
     constexpr int ZA = 32 * TS;                // floats per position row a
     float* const out_base = set_out + (int64_t)blockIdx.y * P.split_out_stride;
+    // the accumulators hold (s_u U) (s_v V) sums: the two powers of two come off again in the store pass -- exactly, inside the
+    // fused multiply-add that adds the bias
+    const float inv1 = wino_pow2_inverse(sv) * wino_pow2_inverse(wino_pow2_scale(u_amax, WINO_U_TOP));
+    const f32x4 inv = f32x4{inv1, inv1, inv1, inv1};
+    float lmax = 0.0f;                         // abs-max of what this thread stores (-> out_amax: the next convolution's operand scale)
     if (set_k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)
         const int oy = (tid >> 2) & 15, ox = (tid & 3) * 4;
@@ -558,10 +576,12 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 const float* r = lds + tile * TS + e * 64 + k;                 // Z[a][tile][e][k] at + a * ZA
                 y[e] = (oy & 1) == 0 ? (r[0] + r[ZA]) + r[2 * ZA] : (r[ZA] - r[2 * ZA]) - r[3 * ZA];
             }
-            f32x4 v = f32x4{y[0], y[1], y[2], y[3]} + bias;
+            f32x4 v = __builtin_elementwise_fma(f32x4{y[0], y[1], y[2], y[3]}, inv, f32x4{bias, bias, bias, bias});
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            if (set_out_amax)
+                lmax = fmaxf(fmaxf(lmax, px0[0] >= 0 ? fabsf(v.x) : 0.f), fmaxf(fmaxf(px0[1] >= 0 ? fabsf(v.y) : 0.f, px0[2] >= 0 ? fabsf(v.z) : 0.f), px0[3] >= 0 ? fabsf(v.w) : 0.f));
             float* plane = out_base + (int64_t)kg * HWi;
             if (vec) {
                 *reinterpret_cast<f32x4*>(plane + px0[0]) = v;
@@ -599,12 +619,18 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(r), a1 = *reinterpret_cast<const f32x4*>(r + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(r + ZA), b1 = *reinterpret_cast<const f32x4*>(r + ZA + 4);
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(r + 2 * ZA), c1 = *reinterpret_cast<const f32x4*>(r + 2 * ZA + 4);
-            f32x4 v0 = (odd ? (a0 - b0) - c0 : (a0 + b0) + c0) + bias0, v1 = (odd ? (a1 - b1) - c1 : (a1 + b1) + c1) + bias1;
+            f32x4 v0 = __builtin_elementwise_fma(odd ? (a0 - b0) - c0 : (a0 + b0) + c0, inv, bias0);
+            f32x4 v1 = __builtin_elementwise_fma(odd ? (a1 - b1) - c1 : (a1 + b1) + c1, inv, bias1);
             if (P.relu) {
                 v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                 v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
             int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
+            if (set_out_amax) {                                      // (a masked value is 0 or v * scale: v * scale bounds both, whatever the masks)
+                const f32x4 a0v = __builtin_elementwise_abs(v0), a1v = __builtin_elementwise_abs(v1);
+                const float mx = fmaxf(fmaxf(fmaxf(a0v.x, a0v.y), fmaxf(a0v.z, a0v.w)), fmaxf(fmaxf(a1v.x, a1v.y), fmaxf(a1v.z, a1v.w)));
+                lmax = fmaxf(lmax, P.thresh ? mx * P.scale : mx);
+            }
             if (set_replicas > 0) {                                  // (0: an ordinary launch; 1: one "replica" under the replicas' mask)
                 // The first conv of an MC-dropout subnet: its output is the same for every run, so the store pass writes the runs'
                 // masked replicas itself (replica r = image r of the output canvas) -- the separate expand pass read this tensor back
@@ -646,6 +672,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             *reinterpret_cast<f32x4*>(out_base + e + 4) = v1;
         }
     }
+    if (set_out_amax) wino_publish_amax(set_out_amax, lmax);
 #ifdef POD_TRACE
     __builtin_amdgcn_s_waitcnt(0);                      // the stores have left
     WINO_STAMP(5);
@@ -671,12 +698,22 @@ extern "C" int pod_wino_trace_dump_split(long long* host, int32_t n_workgroups) 
 }
 #endif
 
+extern "C" int64_t pod_wino_filter_split_bytes(int32_t K, int32_t C) {           // size of Us: the terms + the 16-byte trailer (abs-max word)
+    if (K < 1 || C < 16 || (C & 15) != 0) return 0;
+    const int64_t Kpad = (K + 63) / 64 * 64;
+    return Kpad / 64 * (C / 16) * (int64_t)pod::WINO_US_BYTES + 16;
+}
+
 extern "C" int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream) {
-    if (!weight || !Us || K < 1 || C < 16 || (C & 15) != 0) return POD_E_INVALID;
+    if (!weight || !Us || K < 1 || C < 16 || (C & 15) != 0 || (reinterpret_cast<uintptr_t>(Us) & 15u) != 0) return POD_E_INVALID;
     const int32_t Kpad = (K + 63) / 64 * 64;
     const int64_t n = (int64_t)Kpad * C;
+    float* amax = reinterpret_cast<float*>(reinterpret_cast<char*>(Us) + pod_wino_filter_split_bytes(K, C) - 16);
+    if (hipMemsetAsync(amax, 0, 16, (hipStream_t)stream) != hipSuccess) return POD_E_LAUNCH;
+    hipLaunchKernelGGL(pod::k_wino_filter_amax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, amax, K, C, Kpad);
+    POD_CHECK_LAUNCH();
     hipLaunchKernelGGL(pod::k_wino_filter_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       reinterpret_cast<uint16_t*>(Us), K, C, Kpad);
+                       reinterpret_cast<uint16_t*>(Us), amax, K, C, Kpad);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
@@ -693,140 +730,50 @@ static int wino_split_prepare() {        // the kernel's dynamic LDS size, once 
     return attr[dev] == hipSuccess ? POD_OK : POD_E_LAUNCH;
 }
 
-static void wino_one_set(pod::WinoParams& P) {      // an ordinary launch is a grouped launch of one convolution
-    for (int s = 0; s < 4; ++s) {
-        P.sets.first[s] = s == 0 ? 0 : INT32_MAX;
-        P.sets.in[s] = P.in; P.sets.out[s] = P.out; P.sets.U[s] = P.U; P.sets.bias[s] = P.bias;
-        P.sets.offset[s] = P.offset; P.sets.replicas[s] = P.replicas; P.sets.k_planes[s] = P.k_planes;
+// ONE entry for every form of the launch (round 5; rounds 3-4 had a symbol per form): 1..4 convolutions of one shape in one grid, each
+// with its own buffers, filter, bias, operand abs-max words, Philox offset, replica count and plane count; or (n_splits > 1) one
+// convolution cut over its input channels into partial sums.  See include/pod_mi355x.h: PodWinoConv.
+extern "C" int pod_wino_conv3x3_split(const PodWinoConv* d, pod_stream_t stream) {
+    if (!d || d->n_sets < 1 || d->n_sets > 4 || !d->blocks || d->n_blocks < 0 || d->C < 16 || (d->C & 15) != 0 || d->K < 64 || (d->K & 63) != 0 ||
+        !(d->p >= 0.0f && d->p < 1.0f) || d->sets[0].first_block != 0 || (reinterpret_cast<uintptr_t>(d->blocks) & 15u) != 0)
+        return POD_E_INVALID;
+    const int32_t C = d->C, K = d->K, KS = K / 64;
+    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
+    const bool partial = d->n_splits > 1;
+    if (partial) {
+        // whole 32-channel super-chunks (full 128-byte lines) per split; partial sums carry no bias / ReLU / dropout / replicas / planes
+        if (d->n_sets != 1 || d->n_splits > 16 || (C / 16) % d->n_splits != 0 || ((C / 16 / d->n_splits) & 1) != 0 || d->split_stride < 0 || (d->split_stride & 3) != 0 ||
+            d->p != 0.0f || d->relu || d->sets[0].bias || d->sets[0].replicas || d->sets[0].k_planes || d->sets[0].out_amax)
+            return POD_E_INVALID;
     }
-}
-
-extern "C" int pod_wino_conv3x3_split(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
-                                      const uint64_t* epoch, pod_stream_t stream) {
-    if (!in || !out || in == out || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0 ||
-        !(p >= 0.0f && p < 1.0f) || k_planes < 0 || k_planes > K || (k_planes > 0 && p != 0.0f))
-        return POD_E_INVALID;
-    const int32_t KS = K / 64;
-    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
-    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Us) |
-          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
-        return POD_E_INVALID;
-    if (n_blocks == 0) return POD_OK;
-    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
-    pod::WinoParams P;
-    P.in = in; P.out = out; P.U = reinterpret_cast<const float*>(Us); P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
-    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes;
-    P.thresh = POD_DROPOUT_THRESH16(p);
-    P.scale = 1.0f / (1.0f - p);
-    P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 0;
-    wino_one_set(P);
-    const int64_t grid = pod::wino_grid(KS, n_blocks);
-    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-// conv + bias + ReLU of ONE image per record, stored `replicas` times (image r of the record's output canvas = replica r), each replica
-// under its own dropout mask: the first conv of an MC-dropout subnet and the expand pass behind it (PR:403-427 under PR:95-108: every
-// run sees the same input, so the conv is evaluated once) in one launch.  Output equals pod_wino_conv3x3_split (p = 0) followed, per
-// record canvas, by pod_expand_dropout(.., copies = replicas, p, seed, offset + (first output float of the canvas) / 8, epoch) bit for bit.
-extern "C" int pod_wino_conv3x3_split_replicas(const float* in, float* out, const void* Us, const float* bias, const int32_t* blocks, int32_t n_blocks,
-                                               int32_t C, int32_t K, int32_t relu, int32_t replicas, float p, uint64_t seed, uint64_t offset,
-                                               const uint64_t* epoch, pod_stream_t stream) {
-    if (!in || !out || in == out || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0 || !(p >= 0.0f && p < 1.0f) ||
-        replicas < 1 || replicas > 127)
-        return POD_E_INVALID;
-    const int32_t KS = K / 64;
-    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
-    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Us) |
-          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
-        return POD_E_INVALID;
-    if (n_blocks == 0) return POD_OK;
-    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
-    pod::WinoParams P;
-    P.in = in; P.out = out; P.U = reinterpret_cast<const float*>(Us); P.bias = bias; P.blocks = reinterpret_cast<const int4*>(blocks);
-    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = 0;
-    P.thresh = POD_DROPOUT_THRESH16(p);
-    P.scale = 1.0f / (1.0f - p);
-    P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = replicas;
-    wino_one_set(P);
-    const int64_t grid = pod::wino_grid(KS, n_blocks);
-    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-// Up to four convolutions of ONE shape (C, K, ReLU, dropout rate) in one grid: the cls- and the bbox-subnet layer l of the head
-// (PR:403-427), their first layers with the replicas, the four predictors (PR:430-484, k_planes[s] > 0: NCHW planes).  blocks = the sets'
-// tables concatenated, set s owning blocks [set_first[s], set_first[s + 1]); every record stays relative to its set's own in / out
-// buffers, every set keeps its own filter, bias, Philox offset, replica count.  Bit for bit the n_sets separate launches
-// (pod_wino_conv3x3_split / _replicas) -- minus their partial last rounds of workgroups (the kernel runs one workgroup per CU).
-extern "C" int pod_wino_conv3x3_split_grouped(int32_t n_sets, const float* const* in, float* const* out, const void* const* Us, const float* const* bias,
-                                              const int32_t* set_first, const int32_t* replicas, const int32_t* k_planes, const uint64_t* offsets,
-                                              const int32_t* blocks, int32_t n_blocks, int32_t C, int32_t K, int32_t relu, float p, uint64_t seed,
-                                              const uint64_t* epoch, pod_stream_t stream) {
-    if (n_sets < 1 || n_sets > 4 || !in || !out || !Us || !bias || !set_first || !replicas || !k_planes || !offsets || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 ||
-        K < 64 || (K & 63) != 0 || !(p >= 0.0f && p < 1.0f) || set_first[0] != 0)
-        return POD_E_INVALID;
-    const int32_t KS = K / 64;
-    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
-    if ((reinterpret_cast<uintptr_t>(blocks) & 15u) != 0) return POD_E_INVALID;
     pod::WinoParams P;
     for (int s = 0; s < 4; ++s) {
-        const int t = s < n_sets ? s : 0;
-        if (s < n_sets) {
-            if (!in[s] || !out[s] || in[s] == out[s] || !Us[s] || replicas[s] < 0 || replicas[s] > 127 || k_planes[s] < 0 || k_planes[s] > K ||
-                (k_planes[s] > 0 && (p != 0.0f || replicas[s] != 0)) || (s > 0 && set_first[s] < set_first[s - 1]) || set_first[s] > n_blocks)
+        const PodConvSet& q = d->sets[s < d->n_sets ? s : 0];
+        if (s < d->n_sets) {
+            if (!q.in || !q.out || q.in == q.out || !q.Us || !q.in_amax || q.replicas < 0 || q.replicas > 127 || q.k_planes < 0 || q.k_planes > K ||
+                (q.k_planes > 0 && (d->p != 0.0f || q.replicas != 0)) || (s > 0 && q.first_block < d->sets[s - 1].first_block) || q.first_block > d->n_blocks)
                 return POD_E_INVALID;
-            if (((reinterpret_cast<uintptr_t>(in[s]) | reinterpret_cast<uintptr_t>(out[s]) | reinterpret_cast<uintptr_t>(Us[s]) | reinterpret_cast<uintptr_t>(bias[s])) & 15u) != 0)
+            if (((reinterpret_cast<uintptr_t>(q.in) | reinterpret_cast<uintptr_t>(q.out) | reinterpret_cast<uintptr_t>(q.Us) | reinterpret_cast<uintptr_t>(q.bias)) & 15u) != 0 ||
+                ((reinterpret_cast<uintptr_t>(q.in_amax) | reinterpret_cast<uintptr_t>(q.out_amax)) & 3u) != 0)
                 return POD_E_INVALID;
         }
-        P.sets.first[s] = s < n_sets ? set_first[s] : INT32_MAX;
-        P.sets.in[s] = in[t]; P.sets.out[s] = out[t]; P.sets.U[s] = reinterpret_cast<const float*>(Us[t]); P.sets.bias[s] = bias[t];
-        P.sets.offset[s] = offsets[t]; P.sets.replicas[s] = replicas[t]; P.sets.k_planes[s] = k_planes[t];
+        P.sets.first[s] = s < d->n_sets ? q.first_block : INT32_MAX;
+        P.sets.in[s] = q.in; P.sets.out[s] = q.out; P.sets.U[s] = reinterpret_cast<const float*>(q.Us); P.sets.bias[s] = q.bias;
+        P.sets.in_amax[s] = q.in_amax; P.sets.out_amax[s] = q.out_amax;
+        P.sets.offset[s] = q.offset; P.sets.replicas[s] = q.replicas; P.sets.k_planes[s] = q.k_planes;
     }
-    if (n_blocks == 0) return POD_OK;
+    if (d->n_blocks == 0) return POD_OK;
     if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
-    P.in = in[0]; P.out = out[0]; P.U = reinterpret_cast<const float*>(Us[0]); P.bias = bias[0]; P.blocks = reinterpret_cast<const int4*>(blocks);
-    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = relu; P.k_planes = k_planes[0];
-    P.thresh = POD_DROPOUT_THRESH16(p);
-    P.scale = 1.0f / (1.0f - p);
-    P.seed = seed; P.offset = offsets[0];
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = replicas[0];
-    const int64_t grid = pod::wino_grid(KS, n_blocks);
+    const PodConvSet& q0 = d->sets[0];
+    P.in = q0.in; P.out = q0.out; P.U = reinterpret_cast<const float*>(q0.Us); P.bias = q0.bias; P.blocks = reinterpret_cast<const int4*>(d->blocks);
+    P.n_blocks = d->n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = d->relu; P.k_planes = q0.k_planes;
+    P.thresh = POD_DROPOUT_THRESH16(d->p);
+    P.scale = 1.0f / (1.0f - d->p);
+    P.seed = d->seed; P.offset = q0.offset;
+    P.c_split = partial ? C / 16 / d->n_splits : 0; P.split_out_stride = partial ? d->split_stride : 0; P.epoch = d->epoch; P.replicas = q0.replicas;
+    const int64_t grid = pod::wino_grid(KS, d->n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-// The same convolution with the input channels cut into n_splits ranges, one workgroup set each: `partials` receives n_splits
-// channels-last (out_pixels, K) arrays of partial sums (no bias), split_stride floats apart; pod_wino_reduce finishes them.
-extern "C" int pod_wino_conv3x3_split_partial(const float* in, float* partials, const void* Us, const int32_t* blocks, int32_t n_blocks, int32_t C,
-                                              int32_t K, int32_t n_splits, int64_t split_stride, pod_stream_t stream) {
-    if (!in || !partials || in == partials || !Us || !blocks || n_blocks < 0 || C < 16 || (C & 15) != 0 || K < 64 || (K & 63) != 0) return POD_E_INVALID;
-    if (n_splits < 1 || n_splits > 16 || (C / 16) % n_splits != 0 || ((C / 16 / n_splits) & 1) != 0 || split_stride < 0 || (split_stride & 3) != 0)
-        return POD_E_INVALID;                                   // whole 32-channel super-chunks (full 128-byte lines) per split
-    const int32_t KS = K / 64;
-    if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
-    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(Us) | reinterpret_cast<uintptr_t>(blocks)) & 15u) != 0)
-        return POD_E_INVALID;
-    if (n_blocks == 0) return POD_OK;
-    if (wino_split_prepare() != POD_OK) return POD_E_LAUNCH;
-    pod::WinoParams P;
-    P.in = in; P.out = partials; P.U = reinterpret_cast<const float*>(Us); P.bias = nullptr; P.blocks = reinterpret_cast<const int4*>(blocks);
-    P.n_blocks = n_blocks; P.C = C; P.K = K; P.KS = KS; P.in_stride = C; P.out_stride = K; P.relu = 0; P.k_planes = 0;
-    P.thresh = 0; P.scale = 1.0f; P.seed = 0; P.offset = 0;
-    P.c_split = C / 16 / n_splits; P.split_out_stride = split_stride; P.epoch = nullptr; P.replicas = 0;
-    wino_one_set(P);
-    const int64_t grid = pod::wino_grid(KS, n_blocks);
-    if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, (unsigned)n_splits), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, partial ? (unsigned)d->n_splits : 1u), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

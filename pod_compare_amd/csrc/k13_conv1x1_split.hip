@@ -428,8 +428,10 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
 
 // y = act(sum of the partial outputs in order + bias + residual), channels-last, 16 B per lane
 __global__ void __launch_bounds__(256) k_conv1x1_reduce(const float* __restrict__ partials, int32_t n_splits, int64_t split_stride, const float* __restrict__ bias,
-                                                        const float* __restrict__ residual, float* __restrict__ y, int64_t n4, int32_t Cout, int32_t relu) {
+                                                        const float* __restrict__ residual, float* __restrict__ y, int64_t n4, int32_t Cout, int32_t relu,
+                                                        float* __restrict__ out_amax) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float lmax = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 v = *reinterpret_cast<const f32x4*>(partials + 4 * i);
         for (int s = 1; s < n_splits; ++s) v += *reinterpret_cast<const f32x4*>(partials + (int64_t)s * split_stride + 4 * i);
@@ -439,7 +441,9 @@ __global__ void __launch_bounds__(256) k_conv1x1_reduce(const float* __restrict_
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         *reinterpret_cast<f32x4*>(y + 4 * i) = v;
+        lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    if (out_amax) wino_publish_amax(out_amax, lmax);
 }
 
 }  // namespace pod
@@ -489,7 +493,7 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
         int64_t blocks = (n4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(pod::k_conv1x1_reduce, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, P_out * Cout, bias, residual, y, n4,
-                           Cout, relu);
+                           Cout, relu, (float*)nullptr);
         POD_CHECK_LAUNCH();
     }
     return POD_OK;
@@ -498,7 +502,7 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
 // The fixed-order sum of channels-last partial outputs as its own entry point (pod_wino_conv3x3_split_partial's partials when the
 // consumer wants channels-last, not planes): y = act(sum_s partials[s] + bias + residual), n = pixels * Cout floats.
 extern "C" int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y, int64_t n,
-                                   int32_t Cout, int32_t relu, pod_stream_t stream) {
+                                   int32_t Cout, int32_t relu, float* out_amax, pod_stream_t stream) {
     if (!partials || !y || n_splits < 1 || n_splits > 16 || n < 0 || (n & 3) != 0 || Cout < 4 || (Cout & 3) != 0 || n % Cout != 0) return POD_E_INVALID;
     if (n_splits > 1 && (split_stride < n || (split_stride & 3) != 0)) return POD_E_INVALID;
     if (((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15u) != 0)
@@ -507,7 +511,7 @@ extern "C" int pod_reduce_partials(const float* partials, int32_t n_splits, int6
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pod::k_conv1x1_reduce, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, split_stride, bias, residual, y, n / 4,
-                       Cout, relu);
+                       Cout, relu, out_amax);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

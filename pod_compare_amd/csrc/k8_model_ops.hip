@@ -5,7 +5,7 @@
 // per image in MC-dropout mode (PR:103-108).  torch runs it as two kernels (clamp: read+write, fused_dropout:
 // read+write+mask); this is one pass, 16 B per lane, 16 Philox bits per element (pod_device.h: dropout_words; keep iff
 // uniform >= p, scaled by 1/(1-p), torch.nn.functional.dropout's definition).  HBM-bound: 8 bytes per element.
-#include "pod_device.h"
+#include "pod_wino.h"
 
 namespace pod {
 
@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(256) k_bias_act_to_nchw(const float* __restric
 // applied, and the K real channels written as NCHW planes of one image (HW = pixels): what the consumer of a backbone convolution
 // reads.  64 (pixels) x 64 (channels) tiles through LDS: 16-byte loads along the channels, 16-byte stores along H*W.
 __global__ void __launch_bounds__(256) k_wino_reduce(const float* __restrict__ partials, int32_t n_splits, int64_t split_stride, const float* __restrict__ bias,
-                                                     float* __restrict__ planes, int64_t HW, int32_t Kpad, int32_t K, int32_t relu, int32_t tiles_c) {
+                                                     float* __restrict__ planes, int64_t HW, int32_t Kpad, int32_t K, int32_t relu, int32_t tiles_c,
+                                                     float* __restrict__ out_amax) {
+    float lmax = 0.0f;
     __shared__ float tile[64][65];   // [pixel][channel], padded
     const int tid = threadIdx.x;
     const int tc = (int)(blockIdx.x % tiles_c);
@@ -214,7 +216,9 @@ __global__ void __launch_bounds__(256) k_wino_reduce(const float* __restrict__ p
             }
         }
         tile[r][c4 + 0] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+        lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));     // (padded channels: 0 + 0)
     }
+    if (out_amax) wino_publish_amax(out_amax, lmax);
     __syncthreads();
     const bool vec = (HW & 3) == 0;
 #pragma unroll
@@ -314,14 +318,39 @@ extern "C" int pod_bias_act_to_nchw(const float* src, float* dst, const float* b
     return POD_OK;
 }
 
+// the abs-max of a tensor, max'ed into *amax (pod_mi355x.h: operand abs-max words)
+namespace pod {
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, int64_t n, float* __restrict__ amax) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    float m = 0.0f;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (; i < n; ++i) m = fmaxf(m, fabsf(x[i]));        // (the tail of an n that is not a multiple of 4: one thread)
+    wino_publish_amax(amax, m);
+}
+}  // namespace pod
+
+extern "C" int pod_absmax(const float* x, int64_t n, float* amax, pod_stream_t stream) {
+    if (!x || !amax || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(amax) & 3u) != 0) return POD_E_INVALID;
+    if (n == 0) return POD_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(pod::k_absmax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, amax);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
 extern "C" int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
-                               int32_t Kpad, int32_t K, int32_t relu, pod_stream_t stream) {
+                               int32_t Kpad, int32_t K, int32_t relu, float* out_amax, pod_stream_t stream) {
     if (!partials || !planes || n_splits < 1 || n_splits > 16 || HW < 1 || Kpad < 4 || (Kpad & 3) != 0 || K < 1 || K > Kpad) return POD_E_INVALID;
     if (n_splits > 1 && (split_stride < HW * Kpad || (split_stride & 3) != 0)) return POD_E_INVALID;
     if (((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(bias)) & 15u) != 0) return POD_E_INVALID;
     const int64_t tiles_hw = (HW + 63) / 64, tiles_c = (K + 63) / 64;
     hipLaunchKernelGGL(pod::k_wino_reduce, dim3((unsigned)(tiles_hw * tiles_c)), dim3(256), 0, (hipStream_t)stream, partials, n_splits, split_stride, bias,
-                       planes, HW, Kpad, K, relu, (int32_t)tiles_c);
+                       planes, HW, Kpad, K, relu, (int32_t)tiles_c, out_amax);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

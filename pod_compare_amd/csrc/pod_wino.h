@@ -79,6 +79,8 @@ struct WinoParams {
         float* out[4];
         const float* U[4];
         const float* bias[4];
+        const float* in_amax[4];  // device word >= max |in| of the set (the f16 split's operand scale is derived from it)
+        float* out_amax[4];       // null, or a device word the store pass max'es with |every value it stores|
         uint64_t offset[4];
         int32_t replicas[4];
         int32_t k_planes[4];
@@ -163,6 +165,56 @@ __device__ __forceinline__ void wino_bf16_split3(float lo, float hi, uint32_t (&
     w[1] = wino_bf16_pair(lo, hi);
     wino_bf16_residual(w[1], lo, hi, sel);
     w[2] = wino_bf16_pair(lo, hi);
+}
+
+// ---- an fp32 value as the sum of two FP16 values (round 5: k12 / k13 / k14; pod_debug_f16_split2 exposes the same code to the tests)
+// The f16 matrix cores run at the bf16 rate, and two f16 terms carry 11 + 1 (the sign of the residual) + 11 = 23 of an fp32's 24
+// significand bits: x s = x0 + x1 + e, |e| <= 2^-23 |x s| in the worst case (exact whenever the residual has <= 11 significant bits), where
+// x0 = f16(x s) (round to nearest even), r = x s - x0 EXACTLY (one fma), x1 = f16(r).  Three partial products (x0 u1, x1 u0, x0 u0) then form
+// an fp32 product where the 3-way bf16 split needs six -- and with half as many roundings in the fp32 accumulation chain the result is
+// CLOSER to the fp64 value than both the bf16 x 6 form and the fp32 MFMA (measured on the matrix cores: tools/f16_split_numerics.hip,
+// profiles/r05_f16_split_numerics.txt).  What f16 lacks is range (2^-24 .. 65504): every operand tensor is therefore multiplied by a
+// power of two s (exact) chosen from its abs-max, so that the largest scaled value lies in [2^14, 2^15) (filters; static) or below 2^15
+// (activations: abs-max word of the producing launch x the largest gain of the transform); values more than ~2^29 below their tensor's
+// abs-max fall into f16's denormals and keep an ABSOLUTE error of 2^-25 / s -- 2^-40 of the abs-max, against an fp32 rounding's 2^-24 |x|.
+typedef _Float16 wino_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wino_f16x8 __attribute__((ext_vector_type(8)));
+// 2^(top - floor(log2 amax)): the power of two that puts amax into [2^top, 2^(top+1)).  amax = 0 or absurdly small: the largest scale (the
+// operand is zero / all products underflow anyway); inf / nan: the smallest (the products are inf / nan, as an fp32 product would be).
+__device__ __forceinline__ float wino_pow2_scale(float amax, int top) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    int b = 254 + top - E;
+    b = b < 1 ? 1 : b > 254 ? 254 : b;
+    return __uint_as_float((uint32_t)b << 23);
+}
+__device__ __forceinline__ float wino_pow2_inverse(float s) {        // 1 / s for a power of two s = 2^k, |k| <= 126: exact
+    return __uint_as_float((254u << 23) - __float_as_uint(s));
+}
+// (lo s, hi s) -> the f16 pair nearest to them (v_fma_mixlo_f16 / v_fma_mixhi_f16: the scaling rides on the conversion)
+__device__ __forceinline__ uint32_t wino_f16_pair_scaled(float lo, float hi, float s) {
+    uint32_t w;
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(w) : "v"(lo), "v"(hi), "s"(s));
+    return w;
+}
+__device__ __forceinline__ uint32_t wino_f16_pair(float lo, float hi) {              // v_cvt_pk_f16_f32: nearest even, lo in bits 15:0
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, wino_f16x2));
+}
+// (lo, hi) <- (lo s, hi s) - the f16 pair w, exactly: one v_fma_mix_f32 per value (f32 x f32 - f16, a single rounding of a result that is
+// representable: |x s - x0| <= 2^-11 |x s| and both are multiples of the last place of x s)
+__device__ __forceinline__ void wino_f16_residual_scaled(uint32_t w, float& lo, float& hi, float s) {
+    asm("v_fma_mix_f32 %0, %0, %1, -%2 op_sel_hi:[0,0,1]" : "+v"(lo) : "s"(s), "v"(w));
+    asm("v_fma_mix_f32 %0, %0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(hi) : "s"(s), "v"(w));
+}
+__device__ __forceinline__ void wino_f16_split2(float lo, float hi, float s, uint32_t (&w)[2]) {
+    w[0] = wino_f16_pair_scaled(lo, hi, s);
+    wino_f16_residual_scaled(w[0], lo, hi, s);
+    w[1] = wino_f16_pair(lo, hi);
+}
+// the abs-max of what a launch stored -> its out_amax word (floats >= 0 order like their bit patterns)
+__device__ __forceinline__ void wino_publish_amax(float* word, float lmax) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((threadIdx.x & 63) == 0 && lmax > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(word), __float_as_uint(lmax));
 }
 
 template <typename F, int... Js>

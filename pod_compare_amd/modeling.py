@@ -901,6 +901,7 @@ class ProbabilisticRetinaNet(nn.Module):
             self._graph_serial += 1
             epoch = torch.full_like(shared_epoch, self._graph_serial << 32)
             self.head._epoch = epoch
+            from . import amax
             try:
                 for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
                     self._forward_eager(static_in, n, dropout, skip)
@@ -910,12 +911,14 @@ class ProbabilisticRetinaNet(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events
                 # must not abort it)
-                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                amax.reset()                               # the operand abs-max words of the captured launches come from pools zeroed INSIDE the
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):      # capture: every replay starts from zeroed words
                     if dropout:
                         epoch.add_(1)                      # (captured: every replay starts by moving on to the next set of masks)
                     out = self._forward_eager(static_in, n, dropout, skip)
                 stream.wait_stream(side)
             finally:
+                amax.reset()                               # (eager launches never max into a graph's words)
                 self.head._epoch = shared_epoch
             while len(self._graphs) >= self.max_graphs:          # frames of many different sizes: keep the most recent shapes only
                 old_key = next(iter(self._graphs))

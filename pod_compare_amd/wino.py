@@ -1,12 +1,13 @@
 """Host side of pod_wino_conv3x3 (csrc/k11_wino_conv.hip): the head subnets' 3x3 convolutions (probabilistic_retinanet.py:403-427)
 over all FPN levels and all MC runs in one launch.  Channels-last activations, every (level, run) image in one
 [pixel][C] buffer; `block_table` lists the 16x16-pixel output blocks of all images.  GPU only: there is no CPU path."""
+import ctypes
 import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import hip
+from . import amax, hip
 
 
 def level_pixel_offsets(levels: Sequence[Tuple[int, int]], copies: int) -> List[int]:
@@ -98,19 +99,36 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
     return t
 
 
-# Which kernel serves a 3x3 convolution.  Default (round 4): pod_wino_conv3x3_split (csrc/k12_wino_conv_split.hip) where the channel
-# count allows it (C % 16 == 0) -- the same fp32 Winograd with every product formed from EXACT 3-way bf16 splits of both fp32 operands
-# on the bf16 matrix cores (6 partial products, fp32 accumulate).  Its contract is tested, not assumed (tests/test_wino_conv_gpu.py):
-# x == x0 + x1 + x2 bit for bit, the three dropped partial products are below 2^-23 |x u| in the worst case (a quarter of that on average), and on every benchmark shape its error against an
-# fp64 convolution is no larger than the fp32-MFMA kernel's.  POD_WINO_SPLIT=0: pod_wino_conv3x3 (fp32 matrix instructions) everywhere.
-SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"
+# Which kernel serves a 3x3 convolution.  Default: pod_wino_conv3x3_split (csrc/k12_wino_conv_split.hip) where the channel count allows it
+# (C % 16 == 0) -- the same fp32 Winograd with every product formed on the 16-bit matrix cores from split operands (rounds 3-4: exact 3-way
+# bf16 splits, 6 partial products; round 5: 2-way f16 splits of the power-of-two-scaled operands, 3 partial products, fp32 accumulate).
+# Its contract is tested, not assumed (tests/test_wino_conv_gpu.py): x s == x0 + x1 to 2^-23 |x s|, and on every benchmark shape its error
+# against an fp64 convolution is no larger than the fp32-MFMA kernel's.  POD_WINO_SPLIT=0: pod_wino_conv3x3 (fp32 matrix instructions) everywhere.
+SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"      # (the name is rounds 3-4's; the switch selects the split kernel, whatever its terms)
+
+
+def _launch_split(sets, table: torch.Tensor, firsts, C: int, Kpad: int, relu: bool, dropout_p: float, seed: int, epoch, n_splits: int = 0,
+                  split_stride: int = 0, what: str = "pod_wino_conv3x3_split") -> None:
+    """sets: dicts {conv, src, dst, offset, replicas, planes, out_amax: bool}.  Fills a PodWinoConv and launches it; the input abs-max words
+    come from pod_compare_amd.amax (the producer's, or pod_absmax), the outputs' are published by the store pass."""
+    d = hip.PodWinoConv()
+    d.blocks, d.n_blocks, d.n_sets = table.data_ptr(), int(table.shape[0]), len(sets)
+    d.C, d.K, d.relu, d.p, d.seed, d.epoch = C, Kpad, 1 if relu else 0, float(dropout_p), int(seed), hip.ptr(epoch)
+    d.n_splits, d.split_stride = int(n_splits), int(split_stride)
+    for i, s in enumerate(sets):
+        q, conv = d.sets[i], s["conv"]
+        planes = bool(s.get("planes", False))
+        q.in_, q.out, q.Us, q.bias = s["src"].data_ptr(), s["dst"].data_ptr(), conv.U.data_ptr(), hip.ptr(conv.bias) if s.get("bias", True) else None
+        q.in_amax = amax.of(s["src"]).data_ptr()
+        q.out_amax = amax.produced(s["dst"]).data_ptr() if s.get("out_amax", not planes and n_splits <= 1) else None
+        q.offset, q.first_block, q.replicas, q.k_planes = int(s.get("offset", 0)), int(firsts[i]), int(s.get("replicas", 0)), (conv.K if planes else 0)
+    hip.check(hip.load().pod_wino_conv3x3_split(ctypes.byref(d), hip.current_stream()), what)
 
 
 def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int = 0, epoch: Optional[torch.Tensor] = None) -> None:
-    """Up to four convolutions of one shape in ONE grid (pod_wino_conv3x3_split_grouped).  sets: dicts {conv: WinoConv (split kernel),
+    """Up to four convolutions of one shape in ONE grid (pod_wino_conv3x3_split, n_sets > 1).  sets: dicts {conv: WinoConv (split kernel),
     src, dst, table, offset = 0, replicas = 0 (r >= 1: WinoConv.replicas' store pass), planes = False}; every set keeps its own buffers, table, filter, bias, Philox offset.
     Bit for bit the separate launches conv(src, dst, table, ...) / conv.replicas(...)."""
-    import ctypes
     assert 1 <= len(sets) <= 4
     c0 = sets[0]["conv"]
     firsts, tabs = [], []
@@ -132,15 +150,7 @@ def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int =
         cat = _GROUPED_TABLES[key] = (torch.cat(tabs).contiguous(), tabs)          # (keeps the parts alive: their addresses are the key)
         if not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(tabs[0].device).synchronize()               # made once, then read from any stream
-    table = cat[0]
-    k = len(sets)
-    vp = lambda xs: (ctypes.c_void_p * k)(*[ctypes.c_void_p(x) for x in xs])
-    i32 = lambda xs: (ctypes.c_int32 * k)(*[int(x) for x in xs])
-    hip.check(hip.load().pod_wino_conv3x3_split_grouped(
-        k, vp([s["src"].data_ptr() for s in sets]), vp([s["dst"].data_ptr() for s in sets]), vp([s["conv"].U.data_ptr() for s in sets]),
-        vp([hip.ptr(s["conv"].bias) or 0 for s in sets]), i32(firsts), i32([s.get("replicas", 0) for s in sets]),
-        i32([(s["conv"].K if s.get("planes", False) else 0) for s in sets]), (ctypes.c_uint64 * k)(*[int(s.get("offset", 0)) for s in sets]),
-        table.data_ptr(), n, c0.C, c0.Kpad, 1 if relu else 0, float(dropout_p), seed, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split_grouped")
+    _launch_split(sets, cat[0], firsts, c0.C, c0.Kpad, relu, dropout_p, seed, epoch)
 
 
 _GROUPED_TABLES = {}
@@ -158,8 +168,8 @@ class WinoConv:
             raise ValueError("pod_wino_conv3x3: C %% 8 == 0 and K <= 512 in steps of 64 required, got C=%d K=%d" % (self.C, self.K))
         lib = hip.load()
         self.split = (SPLIT_BF16 if split is None else bool(split)) and self.C % 16 == 0
-        if self.split:      # three bf16 terms per transformed filter value, in the split kernel's load order
-            self.U = torch.empty(3 * 24 * self.Kpad * self.C, dtype=torch.int16, device=weight.device)
+        if self.split:      # two f16 terms per (scaled) transformed filter value, in the split kernel's load order, + the abs-max trailer
+            self.U = torch.empty(lib.pod_wino_filter_split_bytes(self.K, self.C) // 2, dtype=torch.int16, device=weight.device)
             hip.check(lib.pod_wino_filter_transform_split(weight.detach().contiguous().data_ptr(), self.U.data_ptr(), self.K, self.C,
                                                           hip.current_stream()), "pod_wino_filter_transform_split")
         else:
@@ -180,10 +190,13 @@ class WinoConv:
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and src.dtype == dst.dtype == torch.float32
         assert planes or dst.shape[-1] == self.Kpad
         assert getattr(table, "pod_channels", 512) >= max(self.C, self.K if planes else self.Kpad), "block_table(channels=...) below this conv's channel count"
-        fn = hip.load().pod_wino_conv3x3_split if self.split else hip.load().pod_wino_conv3x3
-        hip.check(fn(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
-                     table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
-                     seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split" if self.split else "pod_wino_conv3x3")
+        if self.split:
+            _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "planes": planes}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch)
+            return dst
+        hip.check(hip.load().pod_wino_conv3x3(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
+                                              table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
+                                              seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3")
+        amax.forget(dst)
         return dst
 
     def replicas(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, replicas: int, relu: bool = False, dropout_p: float = 0.0,
@@ -193,9 +206,7 @@ class WinoConv:
         of pod_expand_dropout called per level with offset + (first float of the level in dst) / 8 (`expand_offset`)."""
         assert self.split and self.K == self.Kpad and 1 <= replicas <= 127
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and dst.shape[-1] == self.Kpad and src.dtype == dst.dtype == torch.float32
-        hip.check(hip.load().pod_wino_conv3x3_split_replicas(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
-                                                             table.shape[0], self.C, self.Kpad, 1 if relu else 0, int(replicas), float(dropout_p),
-                                                             seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3_split_replicas")
+        _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "replicas": int(replicas)}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch)
         return dst
 
     def splits_for(self, n_blocks: int, cus: int = 256) -> int:
@@ -217,12 +228,15 @@ class WinoConv:
             return self(src, dst, table, relu=relu, planes=True)
         hw = int(src.shape[0])
         partials = torch.empty((s, hw, self.Kpad), dtype=torch.float32, device=src.device)
-        lib = hip.load()
-        hip.check(lib.pod_wino_conv3x3_split_partial(src.data_ptr(), partials.data_ptr(), self.U.data_ptr(), table.data_ptr(), table.shape[0], self.C, self.Kpad,
-                                                     s, hw * self.Kpad, hip.current_stream()), "pod_wino_conv3x3_split_partial")
-        hip.check(lib.pod_wino_reduce(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), dst.data_ptr(), hw, self.Kpad, self.K, 1 if relu else 0,
-                                      hip.current_stream()), "pod_wino_reduce")
+        self._partial(src, partials, table, s, hw)
+        hip.check(hip.load().pod_wino_reduce(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), dst.data_ptr(), hw, self.Kpad, self.K, 1 if relu else 0,
+                                             None, hip.current_stream()), "pod_wino_reduce")
+        amax.forget(dst)
         return dst
+
+    def _partial(self, src, partials, table, s, hw):
+        _launch_split([{"conv": self, "src": src, "dst": partials, "bias": False, "out_amax": False}], table, [0], self.C, self.Kpad, False, 0.0, 0, None,
+                      n_splits=s, split_stride=hw * self.Kpad)
 
     def channels_last_of_one_image(self, src: torch.Tensor, table: torch.Tensor, relu: bool = False, n_splits: Optional[int] = None) -> torch.Tensor:
         """conv + bias (+ ReLU) of ONE image, channels-last in and out ((H*W, C) -> (H*W, K); K % 64 == 0): the form a channels-last
@@ -234,10 +248,7 @@ class WinoConv:
         if s <= 1:
             return self(src, dst, table, relu=relu)
         partials = torch.empty((s, hw, self.Kpad), dtype=torch.float32, device=src.device)
-        lib = hip.load()
-        hip.check(lib.pod_wino_conv3x3_split_partial(src.data_ptr(), partials.data_ptr(), self.U.data_ptr(), table.data_ptr(), table.shape[0], self.C, self.Kpad,
-                                                     s, hw * self.Kpad, hip.current_stream()), "pod_wino_conv3x3_split_partial")
-        hip.check(lib.pod_reduce_partials(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), None, dst.data_ptr(), hw * self.Kpad, self.Kpad,
-                                          1 if relu else 0, hip.current_stream()), "pod_reduce_partials")
+        self._partial(src, partials, table, s, hw)
+        hip.check(hip.load().pod_reduce_partials(partials.data_ptr(), s, hw * self.Kpad, hip.ptr(self.bias), None, dst.data_ptr(), hw * self.Kpad, self.Kpad,
+                                                 1 if relu else 0, amax.produced(dst).data_ptr(), hip.current_stream()), "pod_reduce_partials")
         return dst
-

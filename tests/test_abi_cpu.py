@@ -49,14 +49,20 @@ def test_struct_layout_matches_c(lib_path, tmp_path):
                    ' offsetof(PodLevel, H), sizeof(PodConfig), offsetof(PodConfig, score_thresh), offsetof(PodConfig, box_weights),'
                    ' offsetof(PodConfig, philox_seed), sizeof(PodWorkspace), offsetof(PodWorkspace, cand_run_delta),'
                    ' offsetof(PodWorkspace, m_probs), offsetof(PodWorkspace, n_capacity), sizeof(PodDetections),'
-                   ' offsetof(PodDetections, n_det)); return 0;}\n')
+                   ' offsetof(PodDetections, n_det));'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PodConvSet), offsetof(PodConvSet, in_amax), offsetof(PodConvSet, offset),'
+                   ' offsetof(PodConvSet, k_planes), sizeof(PodWinoConv), offsetof(PodWinoConv, p), offsetof(PodWinoConv, epoch),'
+                   ' offsetof(PodWinoConv, split_stride), offsetof(PodWinoConv, sets)); return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(hip.PodLevel), hip.PodLevel.run_stride_cls.offset, hip.PodLevel.H.offset, ctypes.sizeof(hip.PodConfig),
             hip.PodConfig.score_thresh.offset, hip.PodConfig.box_weights.offset, hip.PodConfig.philox_seed.offset,
             ctypes.sizeof(hip.PodWorkspace), hip.PodWorkspace.cand_run_delta.offset, hip.PodWorkspace.m_probs.offset,
-            hip.PodWorkspace.n_capacity.offset, ctypes.sizeof(hip.PodDetections), hip.PodDetections.n_det.offset]
+            hip.PodWorkspace.n_capacity.offset, ctypes.sizeof(hip.PodDetections), hip.PodDetections.n_det.offset,
+            ctypes.sizeof(hip.PodConvSet), hip.PodConvSet.in_amax.offset, hip.PodConvSet.offset.offset, hip.PodConvSet.k_planes.offset,
+            ctypes.sizeof(hip.PodWinoConv), hip.PodWinoConv.p.offset, hip.PodWinoConv.epoch.offset, hip.PodWinoConv.split_stride.offset,
+            hip.PodWinoConv.sets.offset]
     assert got == want
 
 
@@ -69,6 +75,10 @@ def test_invalid_arguments_are_rejected_without_a_gpu(lib_path):
     assert lib.pod_reg_nll(None, None, None, 3, None, None) == -1
     assert lib.pod_run_image(cfg, None, None, 0, 0, 0, 10, 10, 10, 10, None, None) == -1
     assert lib.pod_nms_cluster(cfg, None, 8, None, None, None, None, None, None, None) == -1
+    d = hip.PodWinoConv()
+    assert lib.pod_wino_conv3x3_split(ctypes.byref(d), None) == -1 and lib.pod_wino_conv3x3_split(None, None) == -1
+    assert lib.pod_absmax(None, 4, None, None) == -1
+    assert lib.pod_wino_filter_split_bytes(64, 32) == 2 * 24 * 64 * 32 * 2 + 16 and lib.pod_wino_filter_split_bytes(64, 8) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

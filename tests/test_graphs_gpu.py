@@ -128,7 +128,8 @@ def test_graphs_are_dropped_when_the_parameters_change():
     with torch.no_grad():
         m.head.bbox_pred.bias.add_(0.5)                                 # in-place write: the tensors' version counters
     c = [t.clone() for t in tensors(m(f))]
-    assert float((c[1] - b[1]).abs().min()) > 0.4
+    L = len(m(f).cls)                                                   # tensors(): cls levels, then delta levels, ...
+    assert float((c[L] - b[L]).abs().min()) > 0.4 and torch.equal(c[0], b[0])
     m.float()                                                           # _apply: generation counter
     assert m._param_generation >= 2
     close([t.clone() for t in tensors(m(f))], c)

@@ -2,6 +2,8 @@
 on the matrix cores.  Referees: a CPU fp64 direct convolution with a per-element bound in units of 2^-24 (|w| * |x| + |b|)
 (`test_error_against_an_fp64_direct_convolution`), and torch's conv2d on the same tensors with 2e-5 of the output's scale (fp32
 Winograd, F(2,3) down the rows x F(4,3) along the columns, differs from a direct fp32 convolution by ~2e-6 of the scale at C = 256)."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -32,7 +34,7 @@ def make(levels, copies, C, K, seed=0):
     ([(45, 80), (6, 10)], 2, 256, 256),                       # the head's channel counts
     ([(20, 24)], 1, 32, 512),
 ])
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "f16x3"])
 def test_channels_last_output_equals_conv2d(levels, copies, C, K, split):
     """split: pod_wino_conv3x3_split (3-way bf16 splits on the bf16 matrix cores; needs C % 16 == 0, else the fp32 kernel serves)."""
     w, b, xs = make(levels, copies, C, K)
@@ -49,7 +51,7 @@ def test_channels_last_output_equals_conv2d(levels, copies, C, K, split):
         assert float((got - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "f16x3"])
 @pytest.mark.parametrize("K", [63, 36, 90])
 def test_predictor_planes_of_a_subset_of_the_runs(K, split):
     """cls_score / bbox_pred / bbox_cov shapes: K real channels (padded to 64 / 128 inside), NCHW planes out, reading runs
@@ -113,74 +115,92 @@ def test_error_against_an_fp64_direct_convolution(K, planes):
     assert c12 <= c11, "the split kernel must not be further from fp64 than the fp32-MFMA kernel (%.2f vs %.2f)" % (c12, c11)
 
 
-def _split3(x):
+def _split2(x, scale):
     n = x.numel()
-    terms = torch.empty((3, n), dtype=torch.int16, device="cuda")
-    hip.check(hip.load().pod_debug_bf16_split3(x.data_ptr(), terms.data_ptr(), n, hip.current_stream()), "pod_debug_bf16_split3")
-    # bf16 bit pattern -> the fp32 value with those top 16 bits (exact)
-    return (terms.to(torch.int32) << 16).view(torch.float32)
+    terms = torch.empty((2, n), dtype=torch.int16, device="cuda")
+    hip.check(hip.load().pod_debug_f16_split2(x.data_ptr(), float(scale), terms.data_ptr(), n, hip.current_stream()), "pod_debug_f16_split2")
+    return terms.view(torch.float16)
 
 
-def test_three_bf16_terms_sum_to_the_fp32_value_exactly():
-    """The arithmetic contract of pod_wino_conv3x3_split, first half: x == x0 + x1 + x2 BIT FOR BIT for the values the kernel's own
-    split code produces (pod_debug_bf16_split3 runs pod_wino.h: wino_bf16_split3, the functions the K loop calls) -- over normals of
-    every binade incl. the extremes, values with long carry chains and ties, both signs; each term is a bf16 by construction, the
-    residuals shrink by >= 2^8 per term.  What happens below: when a residual falls under 2^-126 (|x| < 2^-110) it is an fp32
-    denormal; the conversion keeps or flushes it -- either way |x - sum| < 2^-126, asserted here and irrelevant to a convolution
-    whose other operand is finite.  At the other end, |x| >= 2^127 (2 - 2^-8) = 3.396e38 (the last 2^-9 of the fp32 range) rounds to
-    +-inf as a bf16, like any conversion to bf16: such an operand (and the channel it is paired with) gives inf / nan where an fp32
-    product would only overflow in the sum over the channels.
-    +-inf and nan stay inf / nan in the first term."""
+def test_two_f16_terms_carry_the_scaled_fp32_value_to_2_pow_minus_23():
+    """The arithmetic contract of the round-5 split kernels, first half: for the values the kernels' own split code produces
+    (pod_debug_f16_split2 runs pod_wino.h: wino_f16_split2, the functions the K loops call)
+        x s = x0 + x1 + e,   |e| <= 2^-23 |x s|   (and e = 0 whenever the residual fits 11 bits),
+    x0 the nearest-even f16 of x s, x1 the nearest-even f16 of the EXACT residual -- over every binade the scale can put an operand in
+    (the launch scales its operand tensor so that |x s| < 2^15), values with long carry chains and ties, both signs.  Below 2^-14 (f16's
+    denormals: values more than 2^29 under the tensor's abs-max) the error is absolute: |e| <= 2^-25.
+    An operand beyond the scale's promise (|x s| >= 65520) is +-inf in the first term: inf / nan out, never a silently wrong number."""
     g = torch.Generator(device="cuda").manual_seed(12)
     n = 1 << 20
     mant = torch.randint(0, 1 << 23, (n,), device="cuda", generator=g, dtype=torch.int32)
-    expo = torch.randint(1, 255, (n,), device="cuda", generator=g, dtype=torch.int32)          # every normal binade
+    expo = torch.randint(127 - 30, 127 + 15, (n,), device="cuda", generator=g, dtype=torch.int32)      # 2^-30 .. 2^15
     sign = torch.randint(0, 2, (n,), device="cuda", generator=g, dtype=torch.int32)
     x = ((sign << 31) | (expo << 23) | mant).view(torch.float32)
-    special = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.4028234663852886e38, -3.4028234663852886e38, 1.17549435e-38, -1.17549435e-38,
-                            1.0 + 2 ** -23, 1.0 - 2 ** -24, 1.00390625, 1.01171875, 0.99609375 + 2 ** -24, 255.99998474121094,
-                            1.0 + 2 ** -8 + 2 ** -16, 1.0 + 2 ** -9, 1.0 + 2 ** -9 + 2 ** -23, 1.0 + 2 ** -17, 3.0 * 2 ** -9 + 1.0, 2 ** -100, 0.1, 1 / 3.0],
+    special = torch.tensor([0.0, -0.0, 1.0, -1.0, 32767.998046875, -32767.998046875, 1.0 + 2 ** -23, 1.0 - 2 ** -24, 1.0 + 2 ** -11, 1.0 + 2 ** -11 + 2 ** -23,
+                            1.0 + 2 ** -10 - 2 ** -23, 1.0 + 2 ** -12, 3.0 * 2 ** -12 + 1.0, 2 ** -14, 2 ** -14 * (1 + 2 ** -10), 2 ** -24, 2 ** -25, 0.1, 1 / 3.0, 1000.0 / 3.0],
                            device="cuda")
     patterns = ((torch.arange(1 << 16, device="cuda", dtype=torch.int32) << 7) | 0x3F800000).view(torch.float32)     # every 16-bit tail in [1, 2)
     x = torch.cat([special, patterns, x[: n - special.numel() - patterns.numel()]])
-    t = _split3(x)
-    total = t[0].double() + t[1].double() + t[2].double()                                     # exact in fp64 (<= 24 + 16 significant bits)
-    over = x.abs() >= 2.0 ** 127 * (2.0 - 2.0 ** -8)
-    assert bool(torch.isinf(t[0][over]).all()) and int(over.sum()) >= 2
-    # values are converted in pairs (two channels of a pixel): the residual of the partner of an out-of-range value is 0 x inf = nan too
-    # -- both feed the same dot product over the channels, which is non-finite either way
-    over = over | over.view(-1, 2).flip(1).reshape(-1)
-    big = (x.abs() >= 2.0 ** -100) & ~over
-    assert torch.equal(total[big], x[big].double()), "x != x0 + x1 + x2 for %d values" % int((total[big] != x[big].double()).sum())
-    assert bool(((total - x.double()).abs()[~big & ~over] < 2.0 ** -126).all())
-    assert bool((t[1].abs()[big] <= 2.0 ** -8 * t[0].abs()[big]).all()) and bool((t[2].abs()[big] <= 2.0 ** -8 * t[1].abs()[big]).all())
-    assert bool((t[2].abs()[big] <= 2.0 ** -16 * t[0].abs()[big]).all())
-    # the dropped partial products x1 u2 + x2 u1 + x2 u2 of an operand pair: |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x| (nearest-even residuals of
-    # 8-bit significands), so they stay below 2^-23 (1 + 2^-9) |x u| in the worst case -- two fp32 half-ulps of the product, a quarter of
-    # that on average -- asserted here with x as both operands
-    x1, x2 = t[1].abs().double(), t[2].abs().double()
-    assert bool((x1[big] <= 2.0 ** -8 * x.abs().double()[big]).all()) and bool((x2[big] <= 2.0 ** -16 * x.abs().double()[big]).all())
-    assert bool(((x1 * x2 * 2 + x2 * x2)[big] <= 2.0 ** -23 * (1 + 2.0 ** -9) * (x.double() ** 2)[big]).all())
-    # the first term is the nearest-even bf16 (same as torch's conversion), also for inf / nan
-    odd = torch.tensor([float("inf"), -float("inf"), float("nan"), 1.0], device="cuda")
-    assert torch.equal(_split3(odd)[0][:2], odd[:2]) and bool(torch.isnan(_split3(odd)[0][2]))
-    assert torch.equal(t[0][big], x[big].to(torch.bfloat16).float())
+    for scale in (1.0, 2.0 ** -7, 2.0 ** 9):
+        xs = x.double() * scale
+        ok = xs.abs() < 2.0 ** 15
+        t = _split2(x, scale)
+        total = t[0].double() + t[1].double()
+        err = (total - xs).abs()
+        normal = ok & (xs.abs() >= 2.0 ** -2)                      # 2^-23 |x s| >= 2^-25, the absolute error of a residual in f16's denormals
+        assert bool((err[normal] <= 2.0 ** -23 * xs.abs()[normal]).all()), float((err[normal] / xs.abs()[normal]).max())
+        assert bool((err[ok] <= torch.clamp(2.0 ** -23 * xs.abs()[ok], min=2.0 ** -25)).all())
+        assert torch.equal(t[0][ok].double(), (x[ok] * scale).to(torch.float16).double())          # first term: the nearest-even f16 (torch's conversion)
+        assert bool((t[1].double().abs()[ok] <= 2.0 ** -11 * xs.abs()[ok] + 2.0 ** -25).all())     # second: at most half a last place of the first
+        few = ((x[ok].view(torch.int32) & 0x3) == 0) & normal[ok]        # 22 significant bits: always exact
+        assert bool((err[ok][few] == 0).all())
+        # on average: rms error 0.74 in units of 2^-24 |x s| (uniform significands; a correctly rounded fp32 operation: 0.29)
+        rms = float(((err[normal] / (2.0 ** -24 * xs.abs()[normal])) ** 2).mean().sqrt())
+        assert rms < 0.8, rms
+    big = torch.tensor([70000.0, -70000.0, float("inf"), float("nan")], device="cuda")
+    t = _split2(big, 1.0)
+    assert bool(torch.isinf(t[0][:3]).all()) and bool(torch.isnan(t[0][3]))
 
 
-def test_split_filter_terms_sum_to_the_fp32_winograd_filter_exactly():
-    """Second operand: pod_wino_filter_transform_split's three terms of every Winograd-domain filter value sum to the fp32 value
-    pod_wino_filter_transform computes (same transform arithmetic), exactly."""
+def test_split_filter_terms_carry_the_fp32_winograd_filter():
+    """Second operand: pod_wino_filter_transform_split's two terms of every Winograd-domain filter value sum to (the power of two s_u) x
+    (the fp32 value pod_wino_filter_transform computes -- same transform arithmetic) to 2^-23, s_u putting the filter's abs-max into
+    [2^14, 2^15); the abs-max itself sits in the trailer word."""
     K, C = 64, 32
     g = torch.Generator(device="cuda").manual_seed(4)
     w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * 0.05
     U = WinoConv(w, None, split=False).U.view(-1).double().cpu()                 # fp32 kernel's slab order: [chunk8][24][h][j][4]
-    Us = (WinoConv(w, None, split=True).U.to(torch.int32) << 16).view(torch.float32).double().cpu()
-    # compare as multisets per Winograd position is layout-free: both slabs hold, for every (position q, k, c), one value / three terms
+    raw = WinoConv(w, None, split=True).U
+    n_terms = 2 * 24 * K * C
+    assert raw.numel() == n_terms + 8
+    amax = float(raw[n_terms:n_terms + 2].view(torch.float32).item())
+    assert amax == float(U.abs().max())
+    su = 2.0 ** (14 - math.floor(math.log2(amax)))
+    Us = raw[:n_terms].view(torch.float16).double().cpu()
+    assert 2.0 ** 14 <= float(Us.abs().max()) < 2.0 ** 15
     # split slab: [chunk16][q][kb][term][h][j][e]; fp32 slab: [chunk8][q][h2][j64][4]
-    S = Us.view(C // 16, 24, 2, 3, 2, 32, 8).sum(dim=3)                           # [chunk16][q][kb][h][j][e]: channel 16 chunk + 8 h + e, k = 32 kb + j
+    S = Us.view(C // 16, 24, 2, 2, 2, 32, 8).sum(dim=3)                           # [chunk16][q][kb][h][j][e]: channel 16 chunk + 8 h + e, k = 32 kb + j
     S = S.permute(1, 2, 4, 0, 3, 5).reshape(24, 64, C)                             # [q][k][c]
-    F32 = U.view(C // 8, 24, 2, 64, 4).permute(1, 3, 0, 2, 4).reshape(24, 64, C)  # [q][k][c]: channel 8 chunk + 4 h2 + e
-    assert torch.equal(S, F32)
+    F32 = U.view(C // 8, 24, 2, 64, 4).permute(1, 3, 0, 2, 4).reshape(24, 64, C) * su    # [q][k][c]: channel 8 chunk + 4 h2 + e
+    assert bool(((S - F32).abs() <= torch.clamp(2.0 ** -23 * F32.abs(), min=2.0 ** -25)).all())
+
+
+def _conv_desc(conv, src, dst, table, n_sets=1, first_block=0, replicas=0, n_splits=0, split_stride=0, bias=True, in_amax=True):
+    """A PodWinoConv filled by hand (argument-validation tests)."""
+    from pod_compare_amd import amax
+    d = hip.PodWinoConv()
+    d.blocks, d.n_blocks, d.n_sets, d.C, d.K, d.relu, d.p = table.data_ptr(), int(table.shape[0]), n_sets, conv.C, conv.Kpad, 0, 0.0
+    d.n_splits, d.split_stride = n_splits, split_stride
+    q = d.sets[0]
+    q.in_, q.out, q.Us, q.bias = src.data_ptr(), dst.data_ptr(), conv.U.data_ptr(), (hip.ptr(conv.bias) if bias else None)
+    q.in_amax = amax.of(src).data_ptr() if in_amax else None
+    q.first_block, q.replicas = first_block, replicas
+    return d
+
+
+def _launch_rc(d):
+    import ctypes
+    return hip.load().pod_wino_conv3x3_split(ctypes.byref(d), hip.current_stream())
 
 
 def test_split_kernel_is_deterministic_and_independent_of_the_pipeline_position():
@@ -200,7 +220,7 @@ def test_split_kernel_is_deterministic_and_independent_of_the_pipeline_position(
         assert torch.equal(a, padded), C
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "f16x3"])
 def test_dropout_mask_is_the_one_pod_bias_act_draws(split):
     """bias + ReLU + dropout in the conv's store == the conv without them followed by pod_bias_act on the same channels-last
     tensor (same Philox counters), bit for bit."""
@@ -241,8 +261,8 @@ def test_replicas_from_the_store_pass_equal_conv_then_expand_dropout(levels, rep
     else:
         first = fused[offn[0]:offn[1]].view(replicas, -1)
         assert not torch.equal(first[0], first[1])               # every replica its own mask
-    assert lib.pod_wino_conv3x3_split_replicas(src.data_ptr(), fused.data_ptr(), conv.U.data_ptr(), conv.bias.data_ptr(), block_table(levels, 1, "cuda").data_ptr(), 1, C, K, 1,
-                                               128, 0.0, 0, 0, None, hip.current_stream()) == -1        # replicas <= 127
+    assert _launch_rc(_conv_desc(conv, src, fused, block_table(levels, 1, "cuda"), replicas=128)) == -1        # replicas <= 127
+    assert _launch_rc(_conv_desc(conv, src, fused, block_table(levels, 1, "cuda"), in_amax=False)) == -1        # the operand scale is not optional
 
 
 def test_grouped_launch_equals_the_separate_launches():
@@ -284,12 +304,10 @@ def test_grouped_launch_equals_the_separate_launches():
     grouped_launch(sets)
     assert all(torch.equal(s_["dst"], w_) for s_, w_ in zip(sets, want))
     # invalid: five sets, a set list that does not start at block 0
-    import ctypes
-    one = (ctypes.c_void_p * 1)(ctypes.c_void_p(srcs[0].data_ptr()))
-    assert lib.pod_wino_conv3x3_split_grouped(5, one, one, one, one, (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_uint64 * 1)(0),
-                                              tabs[0].data_ptr(), 1, C, 64, 1, 0.0, 0, None, hip.current_stream()) == -1
-    assert lib.pod_wino_conv3x3_split_grouped(1, one, one, one, one, (ctypes.c_int32 * 1)(1), (ctypes.c_int32 * 1)(0), (ctypes.c_int32 * 1)(0), (ctypes.c_uint64 * 1)(0),
-                                              tabs[0].data_ptr(), 1, C, 64, 1, 0.0, 0, None, hip.current_stream()) == -1
+    dst = torch.empty(srcs[0].shape[0], 64, device="cuda")
+    assert _launch_rc(_conv_desc(convs[0], srcs[0], dst, tabs[0], n_sets=5)) == -1
+    assert _launch_rc(_conv_desc(convs[0], srcs[0], dst, tabs[0], first_block=1)) == -1
+    assert _launch_rc(_conv_desc(convs[0], srcs[0], dst, tabs[0])) == 0
 
 
 def test_head_with_grouped_launches_equals_the_head_with_separate_launches(monkeypatch):
@@ -337,7 +355,9 @@ def test_small_maps_split_over_the_input_channels(H, W, C, K, splits):
     if (H, W, C, K) == (48, 84, 256, 256):
         assert conv.splits_for(int(table.shape[0])) == 2          # res4 / p4: 72 -> 144
     assert WinoConv(w, b, split=False).splits_for(int(table.shape[0])) == 1
-    assert hip.load().pod_wino_conv3x3_split_partial(src.data_ptr(), src.data_ptr(), conv.U.data_ptr(), table.data_ptr(), 1, C, conv.Kpad, 3, 0, hip.current_stream()) == -1
+    parts = torch.empty(3 * H * W * conv.Kpad, device="cuda")
+    assert _launch_rc(_conv_desc(conv, src, parts, table, n_splits=3, split_stride=H * W * conv.Kpad, bias=False)) == -1          # whole super-chunks per split
+    assert _launch_rc(_conv_desc(conv, src, parts, table, n_splits=2, split_stride=H * W * conv.Kpad, bias=True)) == -1           # partial sums carry no bias
 
 
 def test_invalid_arguments_are_rejected():
@@ -502,7 +522,7 @@ def test_full_frame_model_forward_winograd_head_equals_miopen_head():
             assert float((g - w).abs().max()) <= 1e-4 * max(1.0, float(w.abs().max())), name      # (the backbone is MIOpen in both)
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "bf16x6"])
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "f16x3"])
 @pytest.mark.parametrize("mid,H,W,stride", [(64, 47, 83, 1), (128, 25, 42, 2), (256, 13, 21, 1), (512, 6, 11, 2)])
 def test_bottleneck_with_conv2_on_the_winograd_kernel_equals_the_miopen_bottleneck(mid, H, W, stride, split, monkeypatch):
     """detectron2's BottleneckBlock (conv1 1x1 [stride], conv2 3x3, conv3 1x1, shortcut; FrozenBN folded) as modeling.Bottleneck runs it
