@@ -345,15 +345,20 @@ int pod_wino_conv3x3(const float* in, float* out, const float* U, const float* b
                      int32_t C, int32_t K, int32_t k_planes, int32_t relu, float p, uint64_t seed, uint64_t offset,
                      const uint64_t* epoch, pod_stream_t stream);
 
-/* ---- operand abs-max words (round 5; ABI 12) ------------------------------------------------------------------------------------
+/* ---- operand abs-max records (round 5; ABI 12) ----------------------------------------------------------------------------------
  * The split convolutions below form every fp32 product from TWO F16 terms per operand; f16 has fp32's precision budget here (11 + 1 + 11
  * bits, pod_wino.h) but not its range, so every operand tensor is scaled by a power of two derived from its abs-max.  Filters: static,
- * inside the *_filter_split transforms.  Activations: a device word `in_amax` >= max |x| over what the launch reads -- an upper bound is
+ * inside the *_filter_split transforms.  Activations: a device RECORD `in_amax` of POD_AMAX_FLOATS floats whose largest element is
+ * >= max |x| over what the launch reads (only elements k * POD_AMAX_STRIDE, k < POD_AMAX_SLOTS, are read or written: producers spread
+ * their atomics over 16 cache lines -- thousands of same-address atomics serialise in the L2) -- an upper bound is
  * enough (a looser bound costs low-order bits of tiny values only; a bound BELOW the true maximum overflows f16: the outputs are inf /
- * nan, never silently wrong).  Producers publish it: every pod_* convolution takes `out_amax` (NULL, or a device word it max'es
- * atomically with |every value it stores| -- the caller zeroes the word before the launch); pod_absmax computes it for any other tensor
- * (the same max'ing: zero the word first).  Non-finite values are ignored by the max (they make the consumer's products inf / nan as
+ * nan, never silently wrong).  Producers publish it: every pod_* convolution takes `out_amax` (NULL, or a device record it max'es
+ * atomically with |every value it stores| -- the caller zeroes the record before the launch); pod_absmax computes it for any other tensor
+ * (the same max'ing: zero the record first; x may itself be a record: that is how two bounds are joined).  Non-finite values are ignored by the max (they make the consumer's products inf / nan as
  * they would in fp32). */
+#define POD_AMAX_SLOTS 16
+#define POD_AMAX_STRIDE 32
+#define POD_AMAX_FLOATS (POD_AMAX_SLOTS * POD_AMAX_STRIDE)
 int pod_absmax(const float* x, int64_t n, float* amax, pod_stream_t stream);
 
 /* The same convolution with every fp32 product formed on the 16-BIT matrix cores (csrc/k12_wino_conv_split.hip).  Rounds 3-4: exact 3-way
@@ -385,8 +390,8 @@ typedef struct PodConvSet {
     float* out;             /* channels-last [pixel][K], NCHW planes (k_planes > 0) or partial sums (n_splits > 1) */
     const void* Us;         /* pod_wino_filter_transform_split */
     const float* bias;      /* K floats (zero-padded) or NULL */
-    const float* in_amax;   /* device word >= max |in| (see above); required */
-    float* out_amax;        /* NULL, or a zeroed device word: max'ed with |every value stored| */
+    const float* in_amax;   /* device record (POD_AMAX_FLOATS floats) bounding max |in| (see above); required */
+    float* out_amax;        /* NULL, or a zeroed device record: max'ed with |every value stored| */
     uint64_t offset;        /* Philox offset of this set's dropout masks */
     int32_t first_block;    /* first record of the set in `blocks` */
     int32_t replicas;       /* 0: an ordinary launch; r >= 1: r masked replicas per input image */
@@ -416,16 +421,17 @@ int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_strid
 /* ---- the ResNet stem, channels-last (round 4; ABI 10; csrc/k14_stem_conv.hip) -------------------------------------------
  * Replaces detectron2's BasicStem as probabilistic_retinanet.py:96-100 runs it (`features = self.backbone(images.tensor)`):
  * conv1 (7x7, stride 2, padding 3, 3 -> 64 channels, FrozenBN folded into weight + bias) + ReLU, then max_pool2d(3, 2, 1).
- * pod_stem7x7_filter_split: weight (64, 3, 7, 7) fp32 -> Ws, 3 * 64 * 192 bf16 values (the window padded to 8 x 8 with zeros, three exact
- * bf16 terms per value).  pod_stem7x7_split: x = the frame as (3, H_img, W_img) planes, fp32 or uint8 (x_is_u8); mean / stddev non-null:
+ * pod_stem7x7_filter_split: weight (64, 3, 7, 7) fp32 -> Ws, 2 * 64 * 192 f16 values (the window padded to 8 x 8 with zeros, two f16
+ * terms per scaled value) + a 16-byte trailer (the weight's abs-max): 64 * 192 * 4 + 16 bytes.  pod_stem7x7_split: x = the frame as (3, H_img, W_img) planes, fp32 or uint8 (x_is_u8); mean / stddev non-null:
  * the kernel normalises on load, (x - mean[c]) / stddev[c] in fp32 as PR:96's `self.normalizer` does (null: x is normalised already);
  * H x W >= H_img x W_img is the padded extent ImageList.from_tensors gives the frame (zeros outside the frame, as its padding and the
- * conv's own are) -> y ((H-1)/2+1) x ((W-1)/2+1) pixels x 64 channels, channels-last; every fp32 product from exact 3-way bf16 splits of
- * both operands (pod_conv1x1_split's arithmetic).  pod_maxpool3x3s2_cl: (H * W, C) channels-last -> ((H-1)/2+1) x ((W-1)/2+1) x C,
+ * conv's own are) -> y ((H-1)/2+1) x ((W-1)/2+1) pixels x 64 channels, channels-last; every fp32 product from 2-way f16 splits of the
+ * scaled operands (pod_conv1x1_split's arithmetic); in_amax: a device word >= max |normalised x| (operand abs-max words, above), out_amax:
+ * NULL or the zeroed word that receives max |y|.  pod_maxpool3x3s2_cl: (H * W, C) channels-last -> ((H-1)/2+1) x ((W-1)/2+1) x C,
  * C % 4 == 0; taps outside the map do not take part (torch's -inf padding). */
 int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream);
 int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, int32_t W_img, const float* mean, const float* stddev, float* y, const void* Ws,
-                      const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream);
+                      const float* bias, int32_t H, int32_t W, int32_t relu, const float* in_amax, float* out_amax, pod_stream_t stream);
 int pod_maxpool3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
@@ -465,19 +471,21 @@ int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, po
 /* ---- K13 conv1x1_split (round 4): the 1x1 convolutions of the backbone / FPN as a channels-last GEMM ------------------------
  * Replaces: detectron2 BottleneckBlock.conv1 / conv3 / shortcut (1x1, stride 1 or 2, FrozenBN folded, ReLU, residual add) and
  * FPN.lateral_convs as `self.backbone(images.tensor)` runs them (probabilistic_retinanet.py:96-100): 39 calls per image that PyTorch-ROCm
- * executes as fp32 GEMMs + one element-wise pass each.  Same arithmetic contract as pod_wino_conv3x3_split (exact 3 x bf16 splits of
- * both operands, 6 partial products, fp32 accumulate).
+ * executes as fp32 GEMMs + one element-wise pass each.  Same arithmetic contract as pod_wino_conv3x3_split (round 5: 2-way f16 splits of
+ * the power-of-two-scaled operands, 3 partial products, fp32 accumulate; in_amax / out_amax: operand abs-max words, above).
  *   y[p][k] = act(sum_c x[pin(p)][c] w[k][c] + bias[k] (+ residual[p][k])),  p = oy * W_out + ox,  pin = (stride oy) * W_in + stride ox
  * x dev (H_in * W_in, Cin), y / residual dev (H_out * W_out, Cout): channels-last.  Cin % 16 == 0, Cout % 64 == 0.
- * Ws = pod_conv1x1_filter_split(weight (Cout, Cin) fp32): 3 * Cout * Cin bf16 values.
+ * Ws = pod_conv1x1_filter_split(weight (Cout, Cin) fp32): pod_conv1x1_filter_split_bytes(Cout, Cin) bytes (2 * Cout * Cin f16 terms + a 16-byte trailer: the
+ * weight's abs-max), 16-byte aligned.
  * n_splits > 1 (small maps): the input channels cut over workgroup sets, partial sums in `partials` (n_splits * H_out * W_out * Cout
  * floats), added in a fixed order with bias / residual / ReLU by a second launch. */
+int64_t pod_conv1x1_filter_split_bytes(int32_t Cout, int32_t Cin);
 int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
 int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y,
                         int64_t n, int32_t Cout, int32_t relu, float* out_amax, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
 int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
                       int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
-                      pod_stream_t stream);
+                      const float* in_amax, float* out_amax, pod_stream_t stream);
 
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net

@@ -14,6 +14,7 @@ import torch
 from . import hip
 
 POOL_WORDS = 256
+RECORD = 512          # include/pod_mi355x.h: POD_AMAX_FLOATS (16 slots, one 128-byte line each)
 _POOLS: Dict[int, list] = {}
 
 
@@ -23,12 +24,12 @@ def reset() -> None:
 
 
 def word(device) -> torch.Tensor:
-    """A zeroed fp32 device word (a 1-element view of the current stream's pool)."""
+    """A zeroed abs-max record (a RECORD-float view of the current stream's pool)."""
     key = torch.cuda.current_stream(device).cuda_stream
     ent = _POOLS.get(key)
     if ent is None or ent[1] >= POOL_WORDS:
-        ent = _POOLS[key] = [torch.zeros(POOL_WORDS, dtype=torch.float32, device=device), 0]
-    w = ent[0][ent[1]:ent[1] + 1]
+        ent = _POOLS[key] = [torch.zeros(POOL_WORDS * RECORD, dtype=torch.float32, device=device), 0]
+    w = ent[0][ent[1] * RECORD:(ent[1] + 1) * RECORD]
     ent[1] += 1
     return w
 
@@ -69,5 +70,5 @@ def joined(dst: torch.Tensor, *srcs: torch.Tensor) -> torch.Tensor:
     a new one: a one-element pod_absmax each)."""
     w = word(dst.device)
     for s in srcs:
-        hip.check(hip.load().pod_absmax(of(s).data_ptr(), 1, w.data_ptr(), hip.current_stream()), "pod_absmax")
+        hip.check(hip.load().pod_absmax(of(s).data_ptr(), RECORD, w.data_ptr(), hip.current_stream()), "pod_absmax")
     return attach(dst, w)

@@ -1,11 +1,12 @@
 """Host side of pod_conv1x1_split (csrc/k13_conv1x1_split.hip): the backbone's / FPN's 1x1 convolutions (detectron2 BottleneckBlock conv1 /
 conv3 / shortcut, FPN lateral convs; probabilistic_retinanet.py:96-100 runs them as `self.backbone(images.tensor)`) as a channels-last GEMM
-with every fp32 product formed from exact 3 x bf16 splits on the bf16 matrix cores.  GPU only: there is no CPU path."""
+with every fp32 product formed on the 16-bit matrix cores from split operands (round 5: 2-way f16 splits of the power-of-two-scaled
+operands, 3 partial products; pod_compare_amd/amax.py carries the operand abs-max words).  GPU only: there is no CPU path."""
 from typing import Optional
 
 import torch
 
-from . import hip
+from . import amax, hip
 
 
 class Conv1x1:
@@ -16,7 +17,7 @@ class Conv1x1:
         self.K, self.C, self.stride = int(weight.shape[0]), int(weight.shape[1]), int(stride)
         if self.C % 16 or self.K % 64 or self.stride not in (1, 2):
             raise ValueError("pod_conv1x1_split: Cin %% 16 == 0, Cout %% 64 == 0, stride 1 or 2 required, got Cin=%d Cout=%d stride=%d" % (self.C, self.K, self.stride))
-        self.Ws = torch.empty(3 * self.K * self.C, dtype=torch.int16, device=weight.device)
+        self.Ws = torch.empty(2 * self.K * self.C + 8, dtype=torch.int16, device=weight.device)      # two f16 terms per value + the abs-max trailer
         hip.check(hip.load().pod_conv1x1_filter_split(weight.detach().reshape(self.K, self.C).contiguous().data_ptr(), self.Ws.data_ptr(), self.K, self.C,
                                                       hip.current_stream()), "pod_conv1x1_filter_split")
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().clone()
@@ -58,7 +59,8 @@ class Conv1x1:
         s = self.splits_for(ho * wo) if n_splits is None else int(n_splits)
         partials = torch.empty((s, ho * wo, self.K), dtype=torch.float32, device=x.device) if s > 1 else None
         hip.check(hip.load().pod_conv1x1_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), hip.ptr(residual), ho, wo, h, w, self.stride,
-                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), hip.current_stream()), "pod_conv1x1_split")
+                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), amax.of(x).data_ptr(), amax.produced(y).data_ptr(),
+                                               hip.current_stream()), "pod_conv1x1_split")
         return y
 
 
@@ -68,7 +70,8 @@ class Stem7x7:
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
         assert weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape) == (64, 3, 7, 7)
-        self.Ws = torch.empty(3 * 64 * 192, dtype=torch.int16, device=weight.device)
+        self.Ws = torch.empty(2 * 64 * 192 + 8, dtype=torch.int16, device=weight.device)       # two f16 terms per value + the abs-max trailer
+        self._bounds = {}
         hip.check(hip.load().pod_stem7x7_filter_split(weight.detach().contiguous().data_ptr(), self.Ws.data_ptr(), hip.current_stream()), "pod_stem7x7_filter_split")
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().clone()
 
@@ -89,9 +92,27 @@ class Stem7x7:
             assert mean.is_cuda and std.is_cuda and mean.dtype == std.dtype == torch.float32 and mean.numel() == std.numel() == 3 and mean.is_contiguous() and std.is_contiguous()
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = torch.empty((ho * wo, 64), dtype=torch.float32, device=x.device)
+        bound = self._input_bound(x, mean, std)
         hip.check(hip.load().pod_stem7x7_split(x.data_ptr(), 1 if x.dtype == torch.uint8 else 0, hi, wi, hip.ptr(mean), hip.ptr(std), y.data_ptr(), self.Ws.data_ptr(),
-                                               hip.ptr(self.bias), h, w, 1 if relu else 0, hip.current_stream()), "pod_stem7x7_split")
+                                               hip.ptr(self.bias), h, w, 1 if relu else 0, bound.data_ptr(), amax.produced(y).data_ptr(),
+                                               hip.current_stream()), "pod_stem7x7_split")
         return y, ho, wo
+
+    def _input_bound(self, x: torch.Tensor, mean: Optional[torch.Tensor], std: Optional[torch.Tensor]) -> torch.Tensor:
+        """A device record bounding max |normalised input| (the kernel's `in_amax`): |(x - mean) / std| <= (max |x| + max |mean|) / min |std|, with
+        max |x| = 255 for a uint8 frame (a constant word per (mean, std)) and the frame's own abs-max word otherwise."""
+        if mean is None:
+            return amax.of(x)
+        key = (mean.data_ptr(), mean._version, std.data_ptr(), std._version)
+        c = self._bounds.get(key)
+        if c is None:
+            inv = 1.0 / float(std.abs().min())
+            c = self._bounds[key] = (inv, torch.full((1,), float(mean.abs().max()) * inv, dtype=torch.float32, device=x.device),
+                                     torch.full((amax.RECORD,), (255.0 + float(mean.abs().max())) * inv, dtype=torch.float32, device=x.device))
+            torch.cuda.current_stream(x.device).synchronize()              # made once, then read from any stream
+        if x.dtype == torch.uint8:
+            return c[2]
+        return torch.add(c[1], amax.of(x), alpha=c[0])
 
 
 def maxpool3x3s2_cl(x: torch.Tensor, h: int, w: int):
@@ -100,4 +121,7 @@ def maxpool3x3s2_cl(x: torch.Tensor, h: int, w: int):
     hp, wp = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((hp * wp, x.shape[1]), dtype=torch.float32, device=x.device)
     hip.check(hip.load().pod_maxpool3x3s2_cl(x.data_ptr(), y.data_ptr(), h, w, int(x.shape[1]), hip.current_stream()), "pod_maxpool3x3s2_cl")
+    rec = getattr(x, "_pod_amax", None)
+    if rec is not None and rec[1] == x._version:
+        amax.attach(y, rec[0])                     # every output IS one of the inputs: the bound carries over
     return y, hp, wp

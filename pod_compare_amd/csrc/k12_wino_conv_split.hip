@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_wino_filter_amax(const float* __restric
 #pragma unroll
         for (int i = 0; i < 24; ++i) m = fmaxf(m, fabsf(u[i / 6][i % 6]));
     }
-    wino_publish_amax(amax, m);
+    wino_publish_amax1(amax, m);
 }
 __global__ void __launch_bounds__(256) k_wino_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Us, const float* __restrict__ amax,
                                                            int32_t K, int32_t C, int32_t Kpad) {
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     float* const set_out = P.sets.out[set];
     const float* const set_bias = P.sets.bias[set];
     // operand scales of the f16 split (pod_wino.h): two scalar loads, asked for first and needed only when the first patch is split
-    const float in_amax = *P.sets.in_amax[set];
+    const float in_amax_slot = wino_load_amax(P.sets.in_amax[set]);
     const float u_amax = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(set_U) + (int64_t)P.KS * (P.C >> 4) * WINO_US_BYTES);
     float* const set_out_amax = P.sets.out_amax[set];
     const uint64_t set_offset = P.sets.offset[set];
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert):
     // w = nearest-even f16 pair of (v s) (v_fma_mixlo/hi_f16), residual r = v s - w exactly (v_fma_mix_f32, in place: vN is dead
     // afterwards), second term = nearest-even f16 pair of r (v_cvt_pk_f16_f32).
-    const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(in_amax, WINO_V_TOP))));
+    const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_reduce_amax(in_amax_slot), WINO_V_TOP))));
     auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
         vu32x4 w;
 #pragma unroll
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             *reinterpret_cast<f32x4*>(out_base + e + 4) = v1;
         }
     }
-    if (set_out_amax) wino_publish_amax(set_out_amax, lmax);
+    if (set_out_amax) wino_publish_amax_block(set_out_amax, lmax);          // (set: uniform over the workgroup)
 #ifdef POD_TRACE
     __builtin_amdgcn_s_waitcnt(0);                      // the stores have left
     WINO_STAMP(5);

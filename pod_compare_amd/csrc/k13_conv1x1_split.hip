@@ -7,9 +7,12 @@
 //
 //   y[p][k] = act( sum_c x[pin(p)][c] w[k][c] + bias[k] (+ residual[p][k]) ),   x, y, residual channels-last ([pixel][channel])
 //
-// Same arithmetic contract as pod_wino_conv3x3_split (k12): every fp32 product is formed from the EXACT 3-way bf16 splits of both
-// operands (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the weights split once (pod_conv1x1_filter_split),
-// the activations in the loop with the very functions k12 uses (pod_wino.h: wino_bf16_pair / wino_bf16_residual).
+// Same arithmetic contract as pod_wino_conv3x3_split (k12).  Rounds 3-4: exact 3-way bf16 splits of both operands, 6 partial products.
+// Round 5: 2-way F16 splits of the power-of-two-scaled operands (pod_wino.h: x s = x0 + x1 to 2^-23 |x s|), 3 partial products on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate -- half the matrix instructions and a shorter fp32 accumulation chain (closer to fp64 than
+// both the bf16 form and the fp32 MFMA: tools/f16_split_numerics.hip).  The weights are split once (pod_conv1x1_filter_split, scale from
+// their own abs-max), the activations in the loop with the very functions k12 uses (wino_f16_pair_scaled / wino_f16_residual_scaled),
+// their scale from the launch's `in_amax` word; the store pass publishes the output's abs-max for the next convolution.
 //
 // Mapping.  Workgroup = ONE wavefront = 64 output pixels x (32 NCB) output channels (NCB = 2 as shipped): 2 NCB accumulator blocks
 // of 32 x 32.  The filter is the ROW operand of the MFMAs (a lane's accumulator quad is 4 consecutive output
@@ -43,13 +46,16 @@ static __device__ long long g_c1_cycles[8192 * 4];      // s_memtime beside the 
 
 namespace pod {
 
-typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t c1_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int C1_KS_U16 = 2 * 2 * 256;       // u16 values of one (32-channel block, k-step): [term 2][h 2][i32 32][8 f16]
+constexpr int C1_TOP = 14;                   // both operands: scaled abs-max in [2^14, 2^15)
 
 struct C1Params {
     const float* x;
     float* y;                 // output, or the partial sums of split 0 (split z at + z * split_stride)
-    const uint16_t* Ws;       // pre-split filter: [cout block 32][k-step 16][term 3][h 2][i32 32][8 bf16]
+    const uint16_t* Ws;       // pre-split filter: [cout block 32][k-step 16][term 2][h 2][i32 32][8 f16], then the abs-max word (16-byte trailer)
+    const float* in_amax;     // device word >= max |x| (the activation scale of the f16 split)
+    float* out_amax;          // null, or a device word max'ed with |every value stored| (final pass only)
     const float* bias;
     const float* residual;
     int32_t P_out, W_out, W_in, stride, Cin, Cout, relu;
@@ -58,18 +64,24 @@ struct C1Params {
     int64_t split_stride;     // floats between partial outputs; 0: no split (bias / residual / ReLU applied here)
 };
 
-// weight (Cout, Cin) fp32 -> Ws: three nearest-even bf16 terms per value (w = w0 + w1 + w2 exactly), in the order a lane loads them
-__global__ void __launch_bounds__(256) k_conv1x1_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Ws, int32_t Cout, int32_t Cin) {
+// weight (Cout, Cin) fp32 -> Ws: two nearest-even f16 terms per scaled value (w s = w0 + w1 to 2^-23), in the order a lane loads them;
+// s = the power of two that puts the weight's abs-max (first pass, -> the trailer word) into [2^14, 2^15)
+__global__ void __launch_bounds__(256) k_conv1x1_filter_amax(const float* __restrict__ w, int64_t n, float* __restrict__ amax) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    wino_publish_amax1(amax, m);
+}
+__global__ void __launch_bounds__(256) k_conv1x1_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Ws, const float* __restrict__ amax, int32_t Cout,
+                                                              int32_t Cin) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (cout, pair of cins)
     if (t >= (int64_t)Cout * (Cin / 2)) return;
     const int k = (int)(t / (Cin / 2)), c = 2 * (int)(t % (Cin / 2));
-    uint32_t terms[3];
-    const WinoSplitSel sel;
-    wino_bf16_split3(w[(int64_t)k * Cin + c], w[(int64_t)k * Cin + c + 1], terms, sel);
+    uint32_t terms[2];
+    wino_f16_split2(w[(int64_t)k * Cin + c], w[(int64_t)k * Cin + c + 1], wino_pow2_scale(*amax, C1_TOP), terms);
     const int nks = Cin >> 4, cb = k >> 5, i32 = k & 31, ks = c >> 4, h = (c >> 3) & 1, e = c & 7;
 #pragma unroll
-    for (int term = 0; term < 3; ++term) {
-        uint16_t* d = Ws + ((((int64_t)cb * nks + ks) * 3 + term) * 2 + h) * 256 + i32 * 8 + e;
+    for (int term = 0; term < 2; ++term) {
+        uint16_t* d = Ws + ((((int64_t)cb * nks + ks) * 2 + term) * 2 + h) * 256 + i32 * 8 + e;
         d[0] = (uint16_t)(terms[term] & 0xFFFFu);
         d[1] = (uint16_t)(terms[term] >> 16);
     }
@@ -109,13 +121,14 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
     const float* __restrict__ xa[2];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) xa[pb] = P.x + (int64_t)pin[pb] * P.Cin + ks0 * 16 + 8 * h;
-    const uint16_t* __restrict__ const wa = P.Ws + (((int64_t)(tc * NCB) * nks_all + ks0) * 3 * 2) * 256 + (h * 32 + i32) * 8;     // + cb * nks_all * 1536 + ks * 1536 + term * 512
-    const int64_t w_cb = (int64_t)nks_all * 1536;
+    const uint16_t* __restrict__ const wa = P.Ws + ((int64_t)(tc * NCB) * nks_all + ks0) * C1_KS_U16 + (h * 32 + i32) * 8;     // + cb * nks_all * 1024 + ks * 1024 + term * 512
+    const int64_t w_cb = (int64_t)nks_all * C1_KS_U16;
+    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_read_amax(P.in_amax), C1_TOP))));
 
     f32x16 acc[NCB][2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x4 araw[RING][2][2];           // [buffer][pb][4-channel half of the lane's 8]
-    c1_u32x4 wf[RING][NCB][3];        // [buffer][cb][term]
+    c1_u32x4 wf[RING][NCB][2];        // [buffer][cb][term]
     auto load = [&](auto buf_t, int ks) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_t)::value;
         if (!(POD_C1_ELIM & 1) || ks < RING) {
@@ -129,44 +142,40 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
+                for (int t = 0; t < 2; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * C1_KS_U16 + t * 512);
         }
     };
-    const WinoSplitSel sel;
     auto step = [&](auto buf_t, auto first_t) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_t)::value;
         constexpr bool first = decltype(first_t)::value;
-        c1_u32x4 at[2][3];            // the lane's 8 channels of its two pixels as three bf16 terms
+        c1_u32x4 at[2][2];            // the lane's 8 channels of its two pixels as two f16 terms
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // pair i: channels 2 i, 2 i + 1
                 float lo = araw[buf][pb][i >> 1][2 * (i & 1)], hi = araw[buf][pb][i >> 1][2 * (i & 1) + 1];
                 if (POD_C1_ELIM & 4) {
-                    at[pb][0][i] = at[pb][1][i] = at[pb][2][i] = __builtin_bit_cast(uint32_t, lo);
+                    at[pb][0][i] = at[pb][1][i] = __builtin_bit_cast(uint32_t, lo);
                     continue;
                 }
-                const uint32_t t0 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t0, lo, hi, sel);
-                const uint32_t t1 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t1, lo, hi, sel);
+                const uint32_t t0 = wino_f16_pair_scaled(lo, hi, sx);
+                wino_f16_residual_scaled(t0, lo, hi, sx);
                 at[pb][0][i] = t0;
-                at[pb][1][i] = t1;
-                at[pb][2][i] = wino_bf16_pair(lo, hi);
+                at[pb][1][i] = wino_f16_pair(lo, hi);
             }
-        // the 6 partial products that matter, small ones first (as k12): w1 x1, w2 x0, w0 x2, w1 x0, w0 x1, w0 x0
+        // the 3 partial products that matter, small ones first (as k12): w0 x1, w1 x0, w0 x0
 #pragma unroll
-        for (int prod = 0; prod < 6; ++prod) {
-            const int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;
-            const int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+        for (int prod = 0; prod < 3; ++prod) {
+            const int sa = prod == 1 ? 1 : 0;
+            const int sb = prod == 0 ? 1 : 0;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) {
                     if (first && prod == 0)
-                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), zero16, 0, 0, 0);
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, wf[buf][cb][sa]), __builtin_bit_cast(wino_f16x8, at[pb][sb]), zero16, 0, 0, 0);
                     else
-                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, wf[buf][cb][sa]), __builtin_bit_cast(wino_f16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
                 }
         }
     };
@@ -205,6 +214,10 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
     const float* __restrict__ const bias = P.bias;
     const bool final_pass = P.split_stride == 0;
     const int k0 = tc * NCB * 32 + 4 * h;                       // + 32 cb + 8 q
+    // the accumulators hold (s_w w) (s_x x) sums: the two powers of two come off here, exactly, inside the multiply-add that adds the bias
+    const float inv1 = wino_pow2_inverse(sx) * wino_pow2_inverse(wino_pow2_scale(*reinterpret_cast<const float*>(P.Ws + (int64_t)P.Cout * P.Cin * 2), C1_TOP));
+    const f32x4 inv = f32x4{inv1, inv1, inv1, inv1};
+    float lmax = 0.0f;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         if (pout[pb] < 0) continue;
@@ -224,17 +237,19 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
                 const int k = k0 + 32 * cb + 8 * q;
                 if (k >= P.Cout) continue;
                 f32x4 v = f32x4{acc[cb][pb][4 * q], acc[cb][pb][4 * q + 1], acc[cb][pb][4 * q + 2], acc[cb][pb][4 * q + 3]};
+                v = __builtin_elementwise_fma(v, inv, final_pass && bias ? *reinterpret_cast<const f32x4*>(bias + k) : f32x4{0.f, 0.f, 0.f, 0.f});
                 if (final_pass) {
-                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + k);
                     if (res) v += r[cb][q];
                     if (P.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
+                    lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 }
                 if (!(POD_C1_ELIM & 8) || v.x == 12345.678f) *reinterpret_cast<f32x4*>(yo + e0 + 32 * cb + 8 * q) = v;
             }
         }
     }
+    if (final_pass && P.out_amax) wino_publish_amax(P.out_amax, lmax);
 #ifdef POD_C1_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     C1_STAMP(3);
@@ -245,8 +260,11 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
 // pixels x 32 B per store instruction) go through 16 KB of LDS, [pixel 64][chunk position 16][16 B] with position = chunk ^ (pixel & 15),
 // and come back as 4 pixels x 256 B per instruction: residual loads and output stores of 8 full lines each, all 16 residual loads
 // requested before the first is used (one wavefront per SIMD: nobody else hides them).
-__device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_o, f32x16 (&acc)[2][2], int tp, int tc, int lane, int i32, int h) {
+__device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_o, f32x16 (&acc)[2][2], int tp, int tc, int lane, int i32, int h, float sx) {
     constexpr int NCB = 2;
+    const float inv1 = wino_pow2_inverse(sx) * wino_pow2_inverse(wino_pow2_scale(*reinterpret_cast<const float*>(P.Ws + (int64_t)P.Cout * P.Cin * 2), C1_TOP));
+    const f32x4 inv = f32x4{inv1, inv1, inv1, inv1};
+    float lmax = 0.0f;
     float* __restrict__ const yo = P.y + (int64_t)blockIdx.y * P.split_stride;
     const float* __restrict__ const res = P.residual;
     const bool final_pass = P.split_stride == 0;
@@ -273,16 +291,19 @@ __device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int pix = 4 * j + op;
-        f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + pix * 64 + 4 * (oc ^ (pix & 15)));
+        f32x4 v = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(lds_o + pix * 64 + 4 * (oc ^ (pix & 15))), inv, b4);      // (b4 = 0 for partial sums)
         if (final_pass) {
-            v += b4;
             if (res) v += r[j];
             if (P.relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
         }
-        if (gp0 + 4 * j < P.P_out) *reinterpret_cast<f32x4*>(yo + e0 + (int64_t)(4 * j) * P.Cout) = v;
+        if (gp0 + 4 * j < P.P_out) {
+            *reinterpret_cast<f32x4*>(yo + e0 + (int64_t)(4 * j) * P.Cout) = v;
+            lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
     }
+    if (final_pass && P.out_amax) wino_publish_amax(P.out_amax, lmax);
 }
 
 // The same tile with the activations taken through LDS (the production form whenever a workgroup set accumulates an even number of
@@ -319,8 +340,9 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     }
     const float* __restrict__ const xg = P.x;
     const int key = (i32 >> 1) & 7;
-    const uint16_t* __restrict__ const wa = P.Ws + (((int64_t)(tc * NCB) * nks_all + ks0) * 3 * 2) * 256 + (h * 32 + i32) * 8;
-    const int64_t w_cb = (int64_t)nks_all * 1536;
+    const uint16_t* __restrict__ const wa = P.Ws + ((int64_t)(tc * NCB) * nks_all + ks0) * C1_KS_U16 + (h * 32 + i32) * 8;
+    const int64_t w_cb = (int64_t)nks_all * C1_KS_U16;
+    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_read_amax(P.in_amax), C1_TOP))));
 
     f32x16 acc[NCB][2];
 #pragma unroll
@@ -331,7 +353,7 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
             for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
     const int npairs = nks >> 1;
     f32x4 stg[8];                     // the pair in flight
-    c1_u32x4 wf[3][NCB][3];           // [buffer][cb][term]
+    c1_u32x4 wf[3][NCB][2];           // [buffer][cb][term]
     auto stage_load = [&](int pair) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) stg[j] = *reinterpret_cast<const f32x4*>(xg + soff[j] + pair * 32);
@@ -345,9 +367,8 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * 1536 + t * 512);
+            for (int t = 0; t < 2; ++t) wf[buf][cb][t] = *reinterpret_cast<const c1_u32x4*>(wa + cb * w_cb + (int64_t)ks * C1_KS_U16 + t * 512);
     };
-    const WinoSplitSel sel;
     // Built, measured and dropped (profiles/r04_experiments.md, K13): splitting k-step j + 1 beside the MFMAs of k-step j slot by slot as
     // k12 does -- first with units of 7 VALU instructions in every second MFMA gap (the loop kept its 0.73 us per k-step and the second
     // term buffer cost the second wavefront per SIMD that the large maps need: 1.02 ms per image against 0.975), then evenly (one part
@@ -360,7 +381,7 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     auto step = [&](auto buf_t, auto t_t, int b) __attribute__((always_inline)) {       // k-step t of the pair in LDS buffer b
         constexpr int buf = decltype(buf_t)::value;
         constexpr int t = decltype(t_t)::value;
-        c1_u32x4 at[2][3];
+        c1_u32x4 at[2][2];
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const float* row = &lds_a[b][(pb * 32 + i32) * 32];
@@ -369,24 +390,21 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float lo = i < 2 ? a0[2 * (i & 1)] : a1[2 * (i & 1)], hi = i < 2 ? a0[2 * (i & 1) + 1] : a1[2 * (i & 1) + 1];
-                const uint32_t t0 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t0, lo, hi, sel);
-                const uint32_t t1 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t1, lo, hi, sel);
+                const uint32_t t0 = wino_f16_pair_scaled(lo, hi, sx);
+                wino_f16_residual_scaled(t0, lo, hi, sx);
                 at[pb][0][i] = t0;
-                at[pb][1][i] = t1;
-                at[pb][2][i] = wino_bf16_pair(lo, hi);
+                at[pb][1][i] = wino_f16_pair(lo, hi);
             }
         }
 #pragma unroll
-        for (int prod = 0; prod < 6; ++prod) {
-            const int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;
-            const int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+        for (int prod = 0; prod < 3; ++prod) {
+            const int sa = prod == 1 ? 1 : 0;
+            const int sb = prod == 0 ? 1 : 0;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(c1_bf16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, wf[buf][cb][sa]), __builtin_bit_cast(wino_f16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
         }
     };
     // prologue: pair 0 into LDS buffer 0, pair 1 in flight, filter terms of k-steps 0 and 1
@@ -419,7 +437,7 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     for (int j0 = 0; j0 < nks; j0 += 6) trip(trip, c1_ic<0>{}, j0);
     C1_STAMP(2);
 
-    c1_epilogue(P, &lds_a[0][0], acc, tp, tc, lane, i32, h);
+    c1_epilogue(P, &lds_a[0][0], acc, tp, tc, lane, i32, h, sx);
 #ifdef POD_C1_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     C1_STAMP(3);
@@ -443,23 +461,33 @@ __global__ void __launch_bounds__(256) k_conv1x1_reduce(const float* __restrict_
         *reinterpret_cast<f32x4*>(y + 4 * i) = v;
         lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    if (out_amax) wino_publish_amax(out_amax, lmax);
+    if (out_amax) wino_publish_amax_block(out_amax, lmax);
 }
 
 }  // namespace pod
 
+extern "C" int64_t pod_conv1x1_filter_split_bytes(int32_t Cout, int32_t Cin) {      // size of Ws: the terms + the 16-byte trailer (abs-max word)
+    if (Cout < 32 || (Cout & 31) != 0 || Cin < 16 || (Cin & 15) != 0) return 0;
+    return (int64_t)Cout * Cin * 4 + 16;
+}
+
 extern "C" int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream) {
-    if (!weight || !Ws || Cout < 32 || (Cout & 31) != 0 || Cin < 16 || (Cin & 15) != 0) return POD_E_INVALID;
+    if (!weight || !Ws || Cout < 32 || (Cout & 31) != 0 || Cin < 16 || (Cin & 15) != 0 || (reinterpret_cast<uintptr_t>(Ws) & 15u) != 0) return POD_E_INVALID;
     const int64_t n = (int64_t)Cout * (Cin / 2);
-    hipLaunchKernelGGL(pod::k_conv1x1_filter_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<uint16_t*>(Ws), Cout,
-                       Cin);
+    float* amax = reinterpret_cast<float*>(reinterpret_cast<char*>(Ws) + (int64_t)Cout * Cin * 4);
+    if (hipMemsetAsync(amax, 0, 16, (hipStream_t)stream) != hipSuccess) return POD_E_LAUNCH;
+    hipLaunchKernelGGL(pod::k_conv1x1_filter_amax, dim3(256), dim3(256), 0, (hipStream_t)stream, weight, (int64_t)Cout * Cin, amax);
+    POD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pod::k_conv1x1_filter_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<uint16_t*>(Ws), amax,
+                       Cout, Cin);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
 
 extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out, int32_t H_in,
-                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, pod_stream_t stream) {
-    if (!x || !y || !Ws || x == y || H_out < 1 || W_out < 1 || (stride != 1 && stride != 2) || Cin < 16 || (Cin & 15) != 0 || Cout < 64 || (Cout & 63) != 0)
+                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, const float* in_amax,
+                                 float* out_amax, pod_stream_t stream) {
+    if (!x || !y || !Ws || !in_amax || x == y || H_out < 1 || W_out < 1 || (stride != 1 && stride != 2) || Cin < 16 || (Cin & 15) != 0 || Cout < 64 || (Cout & 63) != 0)
         return POD_E_INVALID;
     if (H_in < (H_out - 1) * stride + 1 || W_in < (W_out - 1) * stride + 1 || (stride == 1 && (H_in != H_out || W_in != W_out))) return POD_E_INVALID;
     const int64_t P_out = (int64_t)H_out * W_out;
@@ -467,10 +495,12 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     const int nks = Cin / 16;
     if (n_splits < 1 || n_splits > 16 || nks % n_splits != 0 || (n_splits > 1 && !partials)) return POD_E_INVALID;
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias) |
-          reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(partials)) & 15u) != 0)
+          reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(partials)) & 15u) != 0 ||
+        ((reinterpret_cast<uintptr_t>(in_amax) | reinterpret_cast<uintptr_t>(out_amax)) & 3u) != 0)
         return POD_E_INVALID;
     pod::C1Params P;
     P.x = x; P.y = n_splits > 1 ? partials : y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.residual = residual;
+    P.in_amax = in_amax; P.out_amax = out_amax;
     P.P_out = (int32_t)P_out; P.W_out = W_out; P.W_in = W_in; P.stride = stride; P.Cin = Cin; P.Cout = Cout; P.relu = relu;
     // 64 pixels x 64 channels per wavefront (two wavefronts per SIMD: one's epilogue under the other's MFMAs; 128-channel tiles measured
     // 1.29 ms per image against 1.17)
@@ -491,9 +521,9 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     if (n_splits > 1) {
         const int64_t n4 = P_out * Cout / 4;
         int64_t blocks = (n4 + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
+        if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pod::k_conv1x1_reduce, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, n_splits, P_out * Cout, bias, residual, y, n4,
-                           Cout, relu, (float*)nullptr);
+                           Cout, relu, out_amax);
         POD_CHECK_LAUNCH();
     }
     return POD_OK;

@@ -5,8 +5,8 @@
 // conv1 + FrozenBN + ReLU + max_pool2d(3, 2, 1).  Before: MIOpen's conv (106 us on the 768 x 1344 frame) + pod_bias_act (21) +
 // torch's NCHW max-pool (38) + a transposing copy to channels-last (12).
 //
-// The convolution as a GEMM with k13's arithmetic (exact 3-way bf16 splits of both operands, 6 partial products on
-// v_mfma_f32_32x32x16_bf16, fp32 accumulate) and k13's filter layout: K = 3 channels x 4 row pairs x (2 rows x 8 columns) = 12 k-steps
+// The convolution as a GEMM with k13's arithmetic (round 5: 2-way f16 splits of the power-of-two-scaled operands, 3 partial products on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate; `in_amax` bounds the NORMALISED input) and k13's filter layout: K = 3 channels x 4 row pairs x (2 rows x 8 columns) = 12 k-steps
 // of 16 -- the 7 x 7 window padded to 8 x 8 with zero weights, ordered so that a lane's 8 k values are 8 CONSECUTIVE input columns of
 // one row (h = the row of the pair): k = ((c 4 + d2) 2 + h) 8 + dx, dy = 2 d2 + h.  Workgroup = one wavefront = an 8 x 8 tile of output
 // pixels x 64 channels; its 22 x 24 x 3 input patch is loaded once into LDS (zero outside the image) and every MFMA fragment is four
@@ -15,7 +15,7 @@
 
 namespace pod {
 
-typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int ST_KS_U16 = 2 * 2 * 256, ST_TOP = 14;     // u16 values of one (32-channel block, k-step); scaled abs-max of both operands in [2^14, 2^15)
 typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
 typedef float st_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -28,26 +28,32 @@ struct StemParams {
     const float* std_;        //   does; null: x is already normalised
     int32_t Hi, Wi, x_u8;     // extent of x; outside it -- the zero padding of the conv AND the frame's padding to a multiple of 32 -- the input is 0
     float* y;                 // (Ho * Wo, 64) channels-last
-    const uint16_t* Ws;       // pre-split filter: [cout block 2][k-step 12][term 3][h 2][i32 32][8 bf16]
+    const uint16_t* Ws;       // pre-split filter: [cout block 2][k-step 12][term 2][h 2][i32 32][8 f16], then the abs-max word (16-byte trailer)
+    const float* in_amax;     // device word >= max |normalised input|
+    float* out_amax;          // null, or a device word max'ed with |every value stored|
     const float* bias;
     int32_t H, W, Ho, Wo, tiles_x, relu;
 };
 
-// weight (64, 3, 7, 7) fp32 -> Ws: the (64 x 192) GEMM matrix in the k order above, three nearest-even bf16 terms per value
-__global__ void __launch_bounds__(256) k_stem_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Ws) {
+// weight (64, 3, 7, 7) fp32 -> Ws: the (64 x 192) GEMM matrix in the k order above, two nearest-even f16 terms per scaled value
+__global__ void __launch_bounds__(256) k_stem_filter_amax(const float* __restrict__ w, float* __restrict__ amax) {
+    float m = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 3 * 49; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    wino_publish_amax1(amax, m);
+}
+__global__ void __launch_bounds__(256) k_stem_filter_split(const float* __restrict__ w, uint16_t* __restrict__ Ws, const float* __restrict__ amax) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (cout, pair of k)
     if (t >= 64 * 96) return;
     const int co = t / 96, k = 2 * (t % 96);
     const int ks = k >> 4, h = (k >> 3) & 1, dx = k & 7, c = ks >> 2, dy = 2 * (ks & 3) + h;
     const float lo = (dy < 7 && dx < 7) ? w[((co * 3 + c) * 7 + dy) * 7 + dx] : 0.f;
     const float hi = (dy < 7 && dx + 1 < 7) ? w[((co * 3 + c) * 7 + dy) * 7 + dx + 1] : 0.f;
-    uint32_t terms[3];
-    const WinoSplitSel sel;
-    wino_bf16_split3(lo, hi, terms, sel);
+    uint32_t terms[2];
+    wino_f16_split2(lo, hi, wino_pow2_scale(*amax, ST_TOP), terms);
     const int cb = co >> 5, i32 = co & 31;
 #pragma unroll
-    for (int term = 0; term < 3; ++term) {
-        uint16_t* d = Ws + ((((int64_t)cb * ST_KS + ks) * 3 + term) * 2 + h) * 256 + i32 * 8 + dx;
+    for (int term = 0; term < 2; ++term) {
+        uint16_t* d = Ws + ((((int64_t)cb * ST_KS + ks) * 2 + term) * 2 + h) * 256 + i32 * 8 + dx;
         d[0] = (uint16_t)(terms[term] & 0xFFFFu);
         d[1] = (uint16_t)(terms[term] >> 16);
     }
@@ -79,7 +85,8 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
             lds[e] = v;
         }
     }
-    const uint16_t* __restrict__ const wa = P.Ws + (h * 32 + i32) * 8;          // + cb * 12 * 1536 + ks * 1536 + term * 512
+    const uint16_t* __restrict__ const wa = P.Ws + (h * 32 + i32) * 8;          // + cb * 12 * 1024 + ks * 1024 + term * 512
+    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_read_amax(P.in_amax), ST_TOP))));
     // this lane's two pixels (pb = 0, 1): tile pixel q = 32 pb + i32 = (q >> 3, q & 7); patch offset of its window's row h, column 0
     int base[2];
 #pragma unroll
@@ -94,18 +101,17 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
-    st_u32x4 wf[3][2][3];
+    st_u32x4 wf[3][2][2];
     auto load_w = [&](auto buf_t, int ks) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_t)::value;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) wf[buf][cb][t] = *reinterpret_cast<const st_u32x4*>(wa + (cb * ST_KS + ks) * 1536 + t * 512);
+            for (int t = 0; t < 2; ++t) wf[buf][cb][t] = *reinterpret_cast<const st_u32x4*>(wa + (cb * ST_KS + ks) * ST_KS_U16 + t * 512);
     };
-    const WinoSplitSel sel;
     auto step = [&](auto ks_t) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_t)::value, buf = ks % 3, c = ks >> 2, d2 = ks & 3;
-        st_u32x4 at[2][3];
+        st_u32x4 at[2][2];
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const float* row = lds + c * ST_PR * ST_PC + 2 * d2 * ST_PC + base[pb];
@@ -113,24 +119,21 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
             for (int i = 0; i < 4; ++i) {
                 const st_f32x2 v = *reinterpret_cast<const st_f32x2*>(row + 2 * i);
                 float lo = v.x, hi = v.y;
-                const uint32_t t0 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t0, lo, hi, sel);
-                const uint32_t t1 = wino_bf16_pair(lo, hi);
-                wino_bf16_residual(t1, lo, hi, sel);
+                const uint32_t t0 = wino_f16_pair_scaled(lo, hi, sx);
+                wino_f16_residual_scaled(t0, lo, hi, sx);
                 at[pb][0][i] = t0;
-                at[pb][1][i] = t1;
-                at[pb][2][i] = wino_bf16_pair(lo, hi);
+                at[pb][1][i] = wino_f16_pair(lo, hi);
             }
         }
 #pragma unroll
-        for (int prod = 0; prod < 6; ++prod) {
-            const int sa = prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 0 : prod == 3 ? 1 : 0;
-            const int sb = prod == 0 ? 1 : prod == 1 ? 0 : prod == 2 ? 2 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+        for (int prod = 0; prod < 3; ++prod) {
+            const int sa = prod == 1 ? 1 : 0;
+            const int sb = prod == 0 ? 1 : 0;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(st_bf16x8, wf[buf][cb][sa]), __builtin_bit_cast(st_bf16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, wf[buf][cb][sa]), __builtin_bit_cast(wino_f16x8, at[pb][sb]), acc[cb][pb], 0, 0, 0);
         }
     };
     load_w(st_ic<0>{}, 0);
@@ -146,6 +149,9 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
     const int oc = lane & 15, op = lane >> 4;
     f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (P.bias) b4 = *reinterpret_cast<const f32x4*>(P.bias + 4 * oc);
+    const float inv1 = wino_pow2_inverse(sx) * wino_pow2_inverse(wino_pow2_scale(*reinterpret_cast<const float*>(P.Ws + 64 * 192 * 2), ST_TOP));
+    const f32x4 inv = f32x4{inv1, inv1, inv1, inv1};
+    float lmax = 0.0f;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -159,12 +165,16 @@ __global__ void __launch_bounds__(64, 2) k_stem7x7_split(const StemParams P) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int pix = 4 * j + op, oy = oy0 + (pix >> 3), ox = ox0 + (pix & 7);
-        f32x4 v = *reinterpret_cast<const f32x4*>(lds + pix * 64 + 4 * (oc ^ (pix & 15))) + b4;
+        f32x4 v = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(lds + pix * 64 + 4 * (oc ^ (pix & 15))), inv, b4);
         if (P.relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (oy < P.Ho && ox < P.Wo) *reinterpret_cast<f32x4*>(P.y + ((int64_t)oy * P.Wo + ox) * 64 + 4 * oc) = v;
+        if (oy < P.Ho && ox < P.Wo) {
+            *reinterpret_cast<f32x4*>(P.y + ((int64_t)oy * P.Wo + ox) * 64 + 4 * oc) = v;
+            lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
     }
+    if (P.out_amax) wino_publish_amax(P.out_amax, lmax);
 }
 
 // max_pool2d(kernel 3, stride 2, padding 1) of a channels-last map: 16 B (4 channels) per lane, the window's taps that lie inside the map
@@ -195,14 +205,18 @@ __global__ void __launch_bounds__(256) k_maxpool3x3s2_cl(const float* __restrict
 
 extern "C" int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream) {
     if (!weight || !Ws || (reinterpret_cast<uintptr_t>(Ws) & 15u) != 0) return POD_E_INVALID;
-    hipLaunchKernelGGL(pod::k_stem_filter_split, dim3((64 * 96 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<uint16_t*>(Ws));
+    float* amax = reinterpret_cast<float*>(reinterpret_cast<char*>(Ws) + 64 * 192 * 4);        // the 16-byte trailer behind the 2 x 64 x 192 f16 terms
+    if (hipMemsetAsync(amax, 0, 16, (hipStream_t)stream) != hipSuccess) return POD_E_LAUNCH;
+    hipLaunchKernelGGL(pod::k_stem_filter_amax, dim3(8), dim3(256), 0, (hipStream_t)stream, weight, amax);
+    POD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pod::k_stem_filter_split, dim3((64 * 96 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<uint16_t*>(Ws), amax);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }
 
 extern "C" int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, int32_t W_img, const float* mean, const float* stddev, float* y, const void* Ws,
-                                 const float* bias, int32_t H, int32_t W, int32_t relu, pod_stream_t stream) {
-    if (!x || !y || !Ws || x == static_cast<const void*>(y) || H < 1 || W < 1 || H > 16384 || W > 16384 || H_img < 1 || W_img < 1 || H_img > H || W_img > W)
+                                 const float* bias, int32_t H, int32_t W, int32_t relu, const float* in_amax, float* out_amax, pod_stream_t stream) {
+    if (!x || !y || !Ws || !in_amax || ((reinterpret_cast<uintptr_t>(in_amax) | reinterpret_cast<uintptr_t>(out_amax)) & 3u) != 0 || x == static_cast<const void*>(y) || H < 1 || W < 1 || H > 16384 || W > 16384 || H_img < 1 || W_img < 1 || H_img > H || W_img > W)
         return POD_E_INVALID;
     if ((mean == nullptr) != (stddev == nullptr)) return POD_E_INVALID;
     if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias)) & 15u) != 0 ||
@@ -210,7 +224,7 @@ extern "C" int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, 
         return POD_E_INVALID;
     pod::StemParams P;
     P.x = x; P.x_u8 = x_is_u8 ? 1 : 0; P.Hi = H_img; P.Wi = W_img; P.mean = mean; P.std_ = stddev;
-    P.y = y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.H = H; P.W = W; P.relu = relu;
+    P.y = y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.H = H; P.W = W; P.relu = relu; P.in_amax = in_amax; P.out_amax = out_amax;
     P.Ho = (H - 1) / 2 + 1; P.Wo = (W - 1) / 2 + 1;
     P.tiles_x = (P.Wo + 7) / 8;
     const int64_t grid = (int64_t)P.tiles_x * ((P.Ho + 7) / 8);

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) k_wino_reduce(const float* __restrict__ p
         tile[r][c4 + 0] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
         lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));     // (padded channels: 0 + 0)
     }
-    if (out_amax) wino_publish_amax(out_amax, lmax);
+    if (out_amax) wino_publish_amax_block(out_amax, lmax);
     __syncthreads();
     const bool vec = (HW & 3) == 0;
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, int
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     for (; i < n; ++i) m = fmaxf(m, fabsf(x[i]));        // (the tail of an n that is not a multiple of 4: one thread)
-    wino_publish_amax(amax, m);
+    wino_publish_amax_block(amax, m);
 }
 }  // namespace pod
 
@@ -337,7 +337,7 @@ extern "C" int pod_absmax(const float* x, int64_t n, float* amax, pod_stream_t s
     if (!x || !amax || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(amax) & 3u) != 0) return POD_E_INVALID;
     if (n == 0) return POD_OK;
     int64_t blocks = (n / 4 + 255) / 256;
-    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
     hipLaunchKernelGGL(pod::k_absmax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, amax);
     POD_CHECK_LAUNCH();
     return POD_OK;

@@ -210,12 +210,51 @@ __device__ __forceinline__ void wino_f16_split2(float lo, float hi, float s, uin
     wino_f16_residual_scaled(w[0], lo, hi, s);
     w[1] = wino_f16_pair(lo, hi);
 }
-// the abs-max of what a launch stored -> its out_amax word (floats >= 0 order like their bit patterns)
-__device__ __forceinline__ void wino_publish_amax(float* word, float lmax) {
+// ---- operand abs-max RECORDS (include/pod_mi355x.h).  The abs-max of a tensor lives in POD_AMAX_SLOTS words POD_AMAX_STRIDE floats apart
+// (one 128-byte line each); a producer max'es into slot (workgroup + wavefront) mod 16, a consumer takes the largest of the 16.  One word
+// would do for the arithmetic -- but thousands of same-address atomics serialise in the L2 at ~10 ns each, and the wavefronts of a
+// streaming launch all finish together (measured with one word: pod_absmax of 22 MB 109 us, a 5-us reduce launch 47 us).
+// (POD_AMAX_SLOTS = 16, POD_AMAX_STRIDE = 32, POD_AMAX_FLOATS = 512: include/pod_mi355x.h)
+// floats >= 0 order like their bit patterns: an integer atomic max.  One atomic per wavefront at most, skipped when the slot already holds more.
+__device__ __forceinline__ void wino_publish_amax1(float* word, float lmax) {      // one wavefront's maximum into ONE word (a filter's trailer)
 #pragma unroll
     for (int o = 32; o; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-    if ((threadIdx.x & 63) == 0 && lmax > 0.0f) atomicMax(reinterpret_cast<uint32_t*>(word), __float_as_uint(lmax));
+    if ((threadIdx.x & 63) == 0 && lmax > 0.0f) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(word);
+        const uint32_t bits = __float_as_uint(lmax);
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w, bits);
+    }
 }
+__device__ __forceinline__ void wino_publish_amax(float* rec, float lmax) {        // ... into its slot of a record
+    const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+    wino_publish_amax1(rec + ((wg * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (POD_AMAX_SLOTS - 1)) * POD_AMAX_STRIDE, lmax);
+}
+// the same for a whole workgroup (every thread calls it; <= 16 wavefronts): ONE atomic per workgroup
+__device__ __forceinline__ void wino_publish_amax_block(float* rec, float lmax) {
+    __shared__ float wave_max[16];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x >> 6); ++w) lmax = fmaxf(lmax, wave_max[w]);
+        if (lmax > 0.0f) {
+            uint32_t* word = reinterpret_cast<uint32_t*>(rec + ((blockIdx.x + blockIdx.y * gridDim.x) & (POD_AMAX_SLOTS - 1)) * POD_AMAX_STRIDE);
+            const uint32_t bits = __float_as_uint(lmax);
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(word, bits);
+        }
+    }
+}
+__device__ __forceinline__ float wino_load_amax(const float* rec) {                // this lane's slot of the record (ask early, reduce late)
+    const int lane = threadIdx.x & 63;
+    return lane < POD_AMAX_SLOTS ? rec[lane * POD_AMAX_STRIDE] : 0.0f;
+}
+__device__ __forceinline__ float wino_reduce_amax(float v) {                       // the record's value, wave-uniform (a scalar register)
+#pragma unroll
+    for (int o = POD_AMAX_SLOTS / 2; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float wino_read_amax(const float* rec) { return wino_reduce_amax(wino_load_amax(rec)); }
 
 template <typename F, int... Js>
 __device__ __forceinline__ void wino_static_for(F&& f, std::integer_sequence<int, Js...>) {

@@ -28,7 +28,7 @@ EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_scor
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_bf16_split3", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_wino_reduce", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
+           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_bf16_split3", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -134,10 +134,12 @@ def load() -> ctypes.CDLL:
     lib.pod_wino_reduce.argtypes = [P, c_int32, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P, P]
     lib.pod_reduce_partials.argtypes = [P, c_int32, c_int64, P, P, P, c_int64, c_int32, c_int32, P, P]
     lib.pod_stem7x7_filter_split.argtypes = [P, P, P]
-    lib.pod_stem7x7_split.argtypes = [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32, c_int32, c_int32, P]
+    lib.pod_stem7x7_split.argtypes = [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32, c_int32, c_int32, P, P, P]
     lib.pod_maxpool3x3s2_cl.argtypes = [P, P, c_int32, c_int32, c_int32, P]
     lib.pod_conv1x1_filter_split.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, P]
+    lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, P, P, P]
+    lib.pod_conv1x1_filter_split_bytes.argtypes = [c_int32, c_int32]
+    lib.pod_conv1x1_filter_split_bytes.restype = c_int64
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_dump_cls_normals.argtypes = [POINTER(PodConfig), POINTER(PodLevel), c_int32, P, P]
     lib.pod_dump_box_normals.argtypes = [POINTER(PodConfig), P, c_int32, P, P]
@@ -145,7 +147,7 @@ def load() -> ctypes.CDLL:
     lib.pod_run_image.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
     for name in EXPORTS:
-        if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words", "pod_wino_filter_split_bytes"):
+        if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words", "pod_wino_filter_split_bytes", "pod_conv1x1_filter_split_bytes"):
             getattr(lib, name).restype = ctypes.c_int
     if lib.pod_abi_version() != POD_ABI_VERSION:
         raise PodError("ABI version mismatch: library {} vs binding {}".format(lib.pod_abi_version(), POD_ABI_VERSION))

@@ -191,14 +191,23 @@ def _wino_conv3x3(src, U, bias, blocks, K, out_elements, planes=False, relu=Fals
     return out
 
 
+def _absmax_word(t: torch.Tensor) -> torch.Tensor:
+    """The operand abs-max word of a stateless operator call (include/pod_mi355x.h): pod_absmax of the whole tensor, every call -- the
+    model's own path (pod_compare_amd/amax.py) takes the word the producing kernel published instead."""
+    w = torch.zeros(512, dtype=torch.float32, device=t.device)          # POD_AMAX_FLOATS
+    with torch.cuda.device(t.device):
+        hip.check(hip.load().pod_absmax(hip.ptr(t), t.numel(), hip.ptr(w), hip.current_stream()), "pod_absmax")
+    return w
+
+
 def _conv1x1_filter_split(weight) -> torch.Tensor:
-    """pod_conv1x1_filter_split: a (Cout, Cin, 1, 1) / (Cout, Cin) fp32 weight as its three exact bf16 terms per value, in the order the kernel
-    loads them (3 * Cout * Cin int16 words).  Cout % 64 == 0, Cin % 16 == 0."""
+    """pod_conv1x1_filter_split: a (Cout, Cin, 1, 1) / (Cout, Cin) fp32 weight as two f16 terms per (power-of-two-scaled) value, in the order the
+    kernel loads them, + the abs-max trailer (2 * Cout * Cin + 8 int16 words).  Cout % 64 == 0, Cin % 16 == 0."""
     torch._check(weight.is_cuda and weight.dtype == torch.float32 and weight.dim() in (2, 4) and weight.numel() == weight.shape[0] * weight.shape[1],
                  lambda: "weight: CUDA fp32 (Cout, Cin) or (Cout, Cin, 1, 1)")
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     torch._check(cout >= 64 and cout % 64 == 0 and cin >= 16 and cin % 16 == 0, lambda: "Cout % 64 == 0 and Cin % 16 == 0 required")
-    ws = torch.empty(3 * cout * cin, dtype=torch.int16, device=weight.device)
+    ws = torch.empty(2 * cout * cin + 8, dtype=torch.int16, device=weight.device)
     with torch.cuda.device(weight.device):
         hip.check(hip.load().pod_conv1x1_filter_split(hip.ptr(weight.contiguous()), hip.ptr(ws), cout, cin, hip.current_stream()), "pod_conv1x1_filter_split")
     return ws
@@ -209,7 +218,7 @@ def _conv1x1_split(x, Ws, bias, residual, h, w, stride, cout, relu=False, n_spli
     torch._check(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[0] == h * w, lambda: "x: contiguous CUDA fp32 (h * w, Cin)")
     cin = int(x.shape[1])
     torch._check(stride in (1, 2) and cout >= 64 and cout % 64 == 0 and cin >= 16 and cin % 16 == 0, lambda: "stride 1 or 2, cout % 64 == 0, Cin % 16 == 0")
-    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 3 * cout * cin, lambda: "Ws: conv1x1_filter_split of a (cout, Cin) weight")
+    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 2 * cout * cin + 8, lambda: "Ws: conv1x1_filter_split of a (cout, Cin) weight")
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()), lambda: "bias: cout fp32 values")
     torch._check(residual is None or (residual.is_cuda and residual.dtype == torch.float32 and residual.is_contiguous() and tuple(residual.shape) == (ho * wo, cout)),
@@ -220,13 +229,13 @@ def _conv1x1_split(x, Ws, bias, residual, h, w, stride, cout, relu=False, n_spli
     partials = torch.empty((n_splits, ho * wo, cout), dtype=torch.float32, device=x.device) if n_splits > 1 else None
     with torch.cuda.device(x.device):
         hip.check(hip.load().pod_conv1x1_split(hip.ptr(x), hip.ptr(y), hip.ptr(Ws), hip.ptr(bias), hip.ptr(residual), ho, wo, int(h), int(w), int(stride), cin, int(cout),
-                                               1 if relu else 0, int(n_splits), hip.ptr(partials), hip.current_stream()), "pod_conv1x1_split")
+                                               1 if relu else 0, int(n_splits), hip.ptr(partials), hip.ptr(_absmax_word(x)), None, hip.current_stream()), "pod_conv1x1_split")
     return y
 
 
 def _stem7x7_filter_split(weight) -> torch.Tensor:
     torch._check(weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape) == (64, 3, 7, 7), lambda: "weight: CUDA fp32 (64, 3, 7, 7)")
-    ws = torch.empty(3 * 64 * 192, dtype=torch.int16, device=weight.device)
+    ws = torch.empty(2 * 64 * 192 + 8, dtype=torch.int16, device=weight.device)
     with torch.cuda.device(weight.device):
         hip.check(hip.load().pod_stem7x7_filter_split(hip.ptr(weight.contiguous()), hip.ptr(ws), hip.current_stream()), "pod_stem7x7_filter_split")
     return ws
@@ -239,16 +248,20 @@ def _stem7x7_split(frame, Ws, bias, mean, std, padded_h, padded_w, relu=True) ->
                  lambda: "frame: contiguous CUDA uint8 / fp32 (3, H, W)")
     hi, wi = int(frame.shape[1]), int(frame.shape[2])
     torch._check(padded_h >= hi and padded_w >= wi and padded_h <= 16384 and padded_w <= 16384, lambda: "padded extent must contain the frame (<= 16384)")
-    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 3 * 64 * 192, lambda: "Ws: stem7x7_filter_split of the (64, 3, 7, 7) weight")
+    torch._check(Ws.is_cuda and Ws.dtype == torch.int16 and Ws.numel() == 2 * 64 * 192 + 8, lambda: "Ws: stem7x7_filter_split of the (64, 3, 7, 7) weight")
     torch._check((mean is None) == (std is None), lambda: "mean and std: both or neither")
     for t in (mean, std):
         torch._check(t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == 3 and t.is_contiguous()), lambda: "mean / std: 3 contiguous CUDA fp32 values")
     torch._check(bias is None or (bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == 64 and bias.is_contiguous()), lambda: "bias: 64 fp32 values")
     ho, wo = (int(padded_h) - 1) // 2 + 1, (int(padded_w) - 1) // 2 + 1
     y = torch.empty((ho * wo, 64), dtype=torch.float32, device=frame.device)
+    # in_amax >= max |(x - mean) / std|: (max |x| + max |mean|) / min |std|, max |x| = 255 for a uint8 frame
+    bound = torch.full((512,), 255.0, dtype=torch.float32, device=frame.device) if frame.dtype == torch.uint8 else _absmax_word(frame)
+    if mean is not None:
+        bound = (bound + mean.abs().max()) / std.abs().min()
     with torch.cuda.device(frame.device):
         hip.check(hip.load().pod_stem7x7_split(hip.ptr(frame), 1 if frame.dtype == torch.uint8 else 0, hi, wi, hip.ptr(mean), hip.ptr(std), hip.ptr(y), hip.ptr(Ws),
-                                               hip.ptr(bias), int(padded_h), int(padded_w), 1 if relu else 0, hip.current_stream()), "pod_stem7x7_split")
+                                               hip.ptr(bias), int(padded_h), int(padded_w), 1 if relu else 0, hip.ptr(bound), None, hip.current_stream()), "pod_stem7x7_split")
     return y
 
 

@@ -68,9 +68,12 @@ def test_invalid_arguments_are_rejected():
     lib = hip.load()
     x = torch.zeros(64, 32, device="cuda")
     y = torch.zeros(64, 64, device="cuda")
-    ws = torch.zeros(3 * 64 * 32, dtype=torch.int16, device="cuda")
+    ws = torch.zeros(2 * 64 * 32 + 8, dtype=torch.int16, device="cuda")
     s = hip.current_stream()
-    ok = lambda *a: lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, *a, None, s)
+    am = torch.zeros(2 * 512, device="cuda")                       # two abs-max records
+    ok = lambda *a: lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, *a, None, am.data_ptr(), am[512:].data_ptr(), s)
+    assert lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, 8, 8, 8, 8, 1, 32, 64, 0, 1, None, None, None, s) == -1     # no in_amax word
+    assert lib.pod_conv1x1_filter_split_bytes(64, 32) == ws.numel() * 2
     assert ok(8, 8, 8, 8, 1, 32, 64, 0, 1) == 0
     assert ok(8, 8, 8, 8, 1, 24, 64, 0, 1) == -1        # Cin % 16
     assert ok(8, 8, 8, 8, 1, 32, 96, 0, 1) == -1        # Cout % 64
