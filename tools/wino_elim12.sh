@@ -15,6 +15,6 @@ else
   for b in $bits; do
     L=pod_compare_amd/lib/s12e$b/libpod_mi355x.so
     echo "== build $b: $(POD_WINO_SPLIT=1 POD_MI355X_LIB=$L python tools/wino_only.py 20 19 bench 2>&1 | grep wino)" | tee -a $out
-    POD_WINO_SPLIT=1 POD_MI355X_LIB=$L python tools/wino_trace.py 19 bench 2>&1 | grep -E "K loop|workgroup total|shader clock|first loads|store pass|dump" | tee -a $out
+    POD_WINO_SPLIT=1 POD_MI355X_LIB=$L python tools/wino_trace.py 19 bench 2>&1 | grep -E "K loop|workgroup total|shader clock|first loads|prologue|store pass|dump" | tee -a $out
   done
 fi
