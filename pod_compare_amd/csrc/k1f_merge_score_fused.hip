@@ -190,8 +190,10 @@ struct K1fLds {
     int32_t lvl_count[POD_MAX_LEVELS], lvl_base[POD_MAX_LEVELS];
 };
 
+// Occupancy target: POD_K1F_WPE wavefronts per SIMD for K <= 8 classes (2K accumulators + 2 runs x 2K loads in flight fit 170 registers);
+// K > 8 (KP = 16) needs twice the registers per lane -- at 3 per SIMD it spilled 153 VGPRs to scratch (round 4) -- and runs 2 per SIMD.
 template <int KP, int WAVES, int CPL, bool VAR>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(POD_K1F_WPE, POD_K1F_WPE))) k1f_merge_score(const K1fParams P) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(KP <= 8 ? POD_K1F_WPE : 2, KP <= 8 ? POD_K1F_WPE : 2))) k1f_merge_score(const K1fParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k1f_lds_raw[];
     K1fLds<KP, WAVES, CPL>& S = *reinterpret_cast<K1fLds<KP, WAVES, CPL>*>(k1f_lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
