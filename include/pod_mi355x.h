@@ -408,11 +408,25 @@ typedef struct PodWinoConv {
     int32_t n_splits;       /* <= 1: off */
     int32_t reserved;
     int64_t split_stride;
+    const int32_t* live_blocks; /* NULL, or pod_sparse_live_blocks' device list {count, record indices ...}: only those records are computed */
     PodConvSet sets[4];
 } PodWinoConv;
 int64_t pod_wino_filter_split_bytes(int32_t K, int32_t C);
 int pod_wino_filter_transform_split(const float* weight, void* Us, int32_t K, int32_t C, pod_stream_t stream);
 int pod_wino_conv3x3_split(const PodWinoConv* conv, pod_stream_t stream);
+
+/* ---- sparse bbox tower (round 5; csrc/k15_sparse_blocks.hip) ------------------------------------------------------------------------
+ * probabilistic_inference.py:310-331 reads box_delta / box_reg_var only at the candidates of :300-308, while the head
+ * (probabilistic_retinanet.py:518-537) evaluates bbox_subnet / bbox_pred / bbox_cov densely for every run.  With the cls tower evaluated
+ * first: pod_sparse_reach turns pod_level_topk's selection into a per-cell map (one byte per cell of every level, level after level;
+ * `scratch` as large) of how many convolution layers below the predictors a cell is still needed (0: a candidate's own cell .. 5; 255:
+ * never -- Winograd tiles taken into account); pod_sparse_live_blocks lists the records of a pod_wino_conv3x3 table that hold a cell of
+ * reach <= max_reach (rec_level[r] = FPN level of record r) as {count, indices ...} for PodWinoConv.live_blocks.  Needed cells depend on
+ * needed cells only: the detections equal the dense tower's (to the last bits where an abs-max record differs in its binade). */
+int pod_sparse_reach(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cat_keys, const int32_t* cat_level, const int32_t* n_total,
+                     uint8_t* reach, uint8_t* scratch, pod_stream_t stream);
+int pod_sparse_live_blocks(const PodConfig* cfg, const PodLevel* levels, const int32_t* records, const int32_t* rec_level, int32_t n_records,
+                           const uint8_t* reach, int32_t max_reach, int32_t* live, pod_stream_t stream);
 /* pod_wino_reduce: the partial sums of an n_splits launch -> bias (K values, zero-padded) + ReLU -> the k_real planes of ONE NCHW image (HW =
  * out_pixels).  Replaces the same reference lines as pod_wino_conv3x3 (detectron2 BottleneckBlock.conv2, FPN.output_convs). */
 int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,
@@ -522,6 +536,12 @@ typedef struct PodWorkspace {
 int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
                   int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
                   int32_t out_h, int32_t out_w, const PodDetections* out, pod_stream_t stream);
+/* The same in two parts (round 5): parts = 1 SELECT (merge + score + per-level top-k, PI:211-308: the candidates stand in ws->cat_keys /
+ * cat_level / n_total afterwards; levels[l].delta / reg_var are not read and may be NULL, `out` too), 2 FINISH (gather + decode + NMS / fusion +
+ * finalize, PI:310-636), 3 both.  The sparse bbox tower runs between 1 and 2. */
+int pod_run_image_part(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
+                  int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
+                  int32_t out_h, int32_t out_w, const PodDetections* out, int32_t parts, pod_stream_t stream);
 
 #ifdef __cplusplus
 }

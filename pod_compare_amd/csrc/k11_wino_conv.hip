@@ -546,7 +546,7 @@ extern "C" int pod_wino_conv3x3(const float* in, float* out, const float* U, con
     P.thresh = POD_DROPOUT_THRESH16(p);
     P.scale = 1.0f / (1.0f - p);
     P.seed = seed; P.offset = offset;
-    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 1;
+    P.c_split = 0; P.split_out_stride = 0; P.epoch = epoch; P.replicas = 1; P.live = nullptr;
     const int64_t grid = pod::wino_grid(KS, n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3, dim3((unsigned)grid), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);

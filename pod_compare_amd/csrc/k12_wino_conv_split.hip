@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     int ks, tb;
     wino_schedule(P.KS, P.n_blocks, ks, tb);
     if (tb >= P.n_blocks) return;
+    if (P.live) {                                                         // sparse launch: slot -> live record (uniform: scalar loads)
+        if (tb >= P.live[0]) return;
+        tb = P.live[1 + tb];
+    }
     // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
     // both (reads outside an image return 0.0), and 16x16 blocks are cut from the canvas without regard to image boundaries -- the
@@ -119,15 +123,18 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(set_U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
                                                           nchunk * WINO_US_BYTES, 0x00020000);
     const int u_off = (a * 6 * 4 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*2 + term) KB, + chunk * 96 KB
-    vu32x4 uP[3][4];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
+#ifndef POD_WINO_U_LEAD
+#define POD_WINO_U_LEAD 3      // positions the filter loads run ahead of their MFMAs (a position's 6 MFMAs last 192 cycles, an L2 round trip under load ~3x that)
+#endif
+    vu32x4 uP[6][4];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
                                                                           // 6 MFMAs last 192 cycles, an L2 round trip under load longer)
     auto filter_piece = [&](int q16, int p, vu32x4(&u)[4], int i) {       // i = kb*2 + term: one buffer_load_dwordx4 (8 f16) each
         u[i] = __builtin_bit_cast(vu32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, q16 * WINO_US_BYTES + (p * 4 + i) * 1024, 0));
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) filter_piece(0, 0, uP[0], i);
+    for (int pp = 0; pp < POD_WINO_U_LEAD; ++pp)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) filter_piece(0, 1, uP[1], i);
+        for (int i = 0; i < 4; ++i) filter_piece(0, pp, uP[pp], i);
     const int4 desc = P.blocks[tb];
     const int64_t base_px = desc.x, out_px = desc.y;                      // first pixel of image 0 in `in` / `out`
     const int gcols = (desc.z >> 24) & 0xFF, H = (desc.z >> 12) & 0xFFF, W = desc.z & 0xFFF, n_img = (desc.w >> 24) & 0xFF;
@@ -278,60 +285,76 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // The pieces of that work, so that they can be slotted behind MFMAs one small unit at a time (`unit` below) or run back to back
     // (`make_v`: the first two chunks).  A unit PINS its inputs when it starts and its results when it ends (empty volatile asm): pure
     // arithmetic otherwise floats to wherever instruction selection likes it, i.e. away from the MFMA it was meant to hide behind.
+#ifndef POD_WINO_XFORM_PINS
+#define POD_WINO_XFORM_PINS 0      // (the same: the slots keep their units through sched_barrier alone)
+#endif
+#if POD_WINO_XFORM_PINS
+#define WINO_XFORM_PIN(...) wino_pin(__VA_ARGS__)
+#else
+#define WINO_XFORM_PIN(...)
+#endif
     auto rows_combine = [&](int c0, int c1) __attribute__((always_inline)) {              // tN[c] = x0[c] + s x1[c]
 #pragma unroll
         for (int c = c0; c < c1; ++c) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) tN[c][e] = __builtin_fmaf(sgn, x[6 + c][e], x[c][e]);
-            wino_pin(tN[c][0], tN[c][1], tN[c][2], tN[c][3]);
+            WINO_XFORM_PIN(tN[c][0], tN[c][1], tN[c][2], tN[c][3]);
         }
     };
     float w0s[4], w1s[4], evs[4], ods[4], fs[4], gs[4];                                   // column transform, first level (per channel e)
     auto columns_level1 = [&](int e) __attribute__((always_inline)) {
-        wino_pin(tN[1][e], tN[2][e], tN[3][e], tN[4][e], tN[5][e]);
+        WINO_XFORM_PIN(tN[1][e], tN[2][e], tN[3][e], tN[4][e], tN[5][e]);
         w0s[e] = __builtin_fmaf(-5.0f, tN[2][e], tN[4][e]);
         w1s[e] = __builtin_fmaf(-5.0f, tN[3][e], tN[5][e]);
         evs[e] = __builtin_fmaf(-4.0f, tN[2][e], tN[4][e]);
         ods[e] = __builtin_fmaf(-4.0f, tN[1][e], tN[3][e]);
         fs[e] = tN[4][e] - tN[2][e];
         gs[e] = tN[3][e] - tN[1][e];
-        wino_pin(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e]);
+        WINO_XFORM_PIN(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e]);
     };
     auto columns_level2 = [&](int hf, int e) __attribute__((always_inline)) {
-        wino_pin(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e], tN[0][e], tN[1][e]);
+        WINO_XFORM_PIN(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e], tN[0][e], tN[1][e]);
         vN[hf][0][e] = __builtin_fmaf(4.0f, tN[0][e], w0s[e]);
         vN[hf][5][e] = __builtin_fmaf(4.0f, tN[1][e], w1s[e]);
         vN[hf][1][e] = evs[e] + ods[e];
         vN[hf][2][e] = evs[e] - ods[e];
         vN[hf][3][e] = __builtin_fmaf(2.0f, gs[e], fs[e]);
         vN[hf][4][e] = __builtin_fmaf(-2.0f, gs[e], fs[e]);
-        wino_pin(vN[hf][0][e], vN[hf][1][e], vN[hf][2][e], vN[hf][3][e], vN[hf][4][e], vN[hf][5][e]);
+        WINO_XFORM_PIN(vN[hf][0][e], vN[hf][1][e], vN[hf][2][e], vN[hf][3][e], vN[hf][4][e], vN[hf][5][e]);
     };
     // The two f16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in three steps whose
     // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert):
     // w = nearest-even f16 pair of (v s) (v_fma_mixlo/hi_f16), residual r = v s - w exactly (v_fma_mix_f32, in place: vN is dead
     // afterwards), second term = nearest-even f16 pair of r (v_cvt_pk_f16_f32).
+#ifndef POD_WINO_SPLIT_PINS
+#define POD_WINO_SPLIT_PINS 0      // (each pin next to a dst-sel producer costs an s_nop: 85 -> 20 per chunk without them, placement unchanged)
+#endif
+#if POD_WINO_SPLIT_PINS
+#define WINO_SPLIT_PIN(...) wino_pin(__VA_ARGS__)
+#else
+#define WINO_SPLIT_PIN(...)
+#endif
     const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_reduce_amax(in_amax_slot), WINO_V_TOP))));
     auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
         vu32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                                      // i = 2 hf + pair: regs 0-1 channels 0-3, 2-3 channels 4-7
-            wino_pin(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
+            WINO_SPLIT_PIN(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
             w[i] = term == 0 ? wino_f16_pair_scaled(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1], sv)
                              : wino_f16_pair(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
         }
         Vb[p][term] = w;
-        wino_pin(Vb[p][term]);
+        WINO_SPLIT_PIN(Vb[p][term]);
     };
     auto split_residual = [&](int p, int i0, int i1) __attribute__((always_inline)) {      // v <- v s - the first term, exactly
-        wino_pin(Vb[p][0]);
+        WINO_SPLIT_PIN(Vb[p][0]);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             float& lo = vN[i >> 1][p][2 * (i & 1)];
             float& hi = vN[i >> 1][p][2 * (i & 1) + 1];
-            wino_pin(lo, hi);
+            WINO_SPLIT_PIN(lo, hi);
             wino_f16_residual_scaled(Vb[p][0][i], lo, hi, sv);
-            wino_pin(lo, hi);
+            WINO_SPLIT_PIN(lo, hi);
         }
     };
     auto split_position = [&](int p) __attribute__((always_inline)) {                      // all three steps back to back
@@ -455,10 +478,10 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
             constexpr int sa = prod == 1 ? 1 : 0;      // filter term of the product
             constexpr int sb = prod == 0 ? 1 : 0;      // patch term:  x1 u0, x0 u1, x0 u0
             if constexpr (mode == 0 && prod == 0)
-                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p % 3][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), zero16, 0, 0, 0);
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), zero16, 0, 0, 0);
             else
-                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p % 3][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
-            if constexpr (m < 4) { if (!(POD_WINO_ELIM & 2)) filter_piece(p >= 4 ? qn : q, (p + 2) % 6, uP[(p + 2) % 3], m); }
+                acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
+            if constexpr (m < 4) { if (!(POD_WINO_ELIM & 2)) filter_piece(p + POD_WINO_U_LEAD >= 6 ? qn : q, (p + POD_WINO_U_LEAD) % 6, uP[(p + POD_WINO_U_LEAD) % 6], m); }
             else if constexpr (m == 4) { if (!(POD_WINO_ELIM & 4)) stage_write(c16 == 0 ? par ^ 1 : par, p, c16 == 0 ? 6 + p : p); }
             if constexpr (p == 5 && m >= 4) {                    // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
                 if (!(POD_WINO_ELIM & 4)) {                      // order, and every filter term ahead is needed soon
@@ -771,6 +794,7 @@ extern "C" int pod_wino_conv3x3_split(const PodWinoConv* d, pod_stream_t stream)
     P.scale = 1.0f / (1.0f - d->p);
     P.seed = d->seed; P.offset = q0.offset;
     P.c_split = partial ? C / 16 / d->n_splits : 0; P.split_out_stride = partial ? d->split_stride : 0; P.epoch = d->epoch; P.replicas = q0.replicas;
+    P.live = d->live_blocks;
     const int64_t grid = pod::wino_grid(KS, d->n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, partial ? (unsigned)d->n_splits : 1u), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);

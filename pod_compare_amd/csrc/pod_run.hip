@@ -17,10 +17,13 @@
         if (rc_ != POD_OK) return rc_; \
     } while (0)
 
-extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
-                             int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
-                             int32_t out_h, int32_t out_w, const PodDetections* out, pod_stream_t stream) {
-    if (!cfg || !levels || !ws || !out) return POD_E_INVALID;
+// parts: 1 = SELECT (merge + score + per-level top-k: PI:211-308 -- the candidates stand in ws->cat_keys / cat_level / n_total afterwards and
+// levels[l].delta / reg_var are not read), 2 = FINISH (gather + decode + NMS / fusion + finalize: PI:310-636), 3 = both = pod_run_image.
+// The sparse bbox tower (pod_sparse_reach / pod_sparse_live_blocks) runs between 1 and 2.
+extern "C" int pod_run_image_part(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
+                                  int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
+                                  int32_t out_h, int32_t out_w, const PodDetections* out, int32_t parts, pod_stream_t stream) {
+    if (!cfg || !levels || !ws || (!out && (parts & 2)) || parts < 1 || parts > 3) return POD_E_INVALID;
     if (mode != POD_MODE_STANDARD_NMS && mode != POD_MODE_BAYES_OD && mode != POD_MODE_ANCHOR_STATISTICS) return POD_E_INVALID;
     if (image_h < 1 || image_w < 1 || out_h < 1 || out_w < 1) return POD_E_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > POD_MAX_LEVELS) return POD_E_INVALID;
@@ -37,9 +40,12 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
     // merge + score in one streaming launch (round 4; k1f_merge_score_fused.hip).  The merged class planes are not stored: nothing
     // downstream reads them (the gather kernel merges the box channels at the candidates and takes the class probabilities from
     // probs_dense, or evaluates them itself when there is no variance head).
-    POD_TRY(pod_merge_score_fused(cfg, levels, nullptr, nullptr, ws->cand_keys, ws->cand_count, prune ? ws->probs_dense : nullptr, stream));
-    POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, ws->cat_keys, ws->cat_level,
-                           ws->n_total, stream));
+    if (parts & 1) {
+        POD_TRY(pod_merge_score_fused(cfg, levels, nullptr, nullptr, ws->cand_keys, ws->cand_count, prune ? ws->probs_dense : nullptr, stream));
+        POD_TRY(pod_level_topk(cfg, levels, ws->cand_keys, ws->cand_count, ws->sel_keys, ws->sel_count, ws->cat_keys, ws->cat_level,
+                               ws->n_total, stream));
+    }
+    if (!(parts & 2)) return POD_OK;
     POD_TRY(pod_gather_decode(cfg, levels, ws->anchors, ws->cat_keys, ws->cat_level, ws->n_total, ws->cand_count,
                               prune ? ws->probs_dense : nullptr, ws->cand_anchor_idx, ws->cand_level,
                               ws->cand_score, ws->cand_class, ws->cand_probs, ws->cand_delta,
@@ -66,4 +72,10 @@ extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const
                             oh, ow, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records, out->n_det, stream);
     return pod_finalize(cfg, nullptr, ws->n_keep, ws->m_boxes, ws->m_cov, ws->m_scores, ws->m_classes, ws->m_probs, sx, sy,
                         oh, ow, out->boxes, out->cov, out->scores, out->classes, out->probs, out->records, out->n_det, stream);
+}
+
+extern "C" int pod_run_image(const PodConfig* cfg, const PodLevel* levels, const PodWorkspace* ws, int32_t mode,
+                             int32_t box_merge_mode, int32_t cls_merge_mode, int32_t image_h, int32_t image_w,
+                             int32_t out_h, int32_t out_w, const PodDetections* out, pod_stream_t stream) {
+    return pod_run_image_part(cfg, levels, ws, mode, box_merge_mode, cls_merge_mode, image_h, image_w, out_h, out_w, out, 3, stream);
 }

@@ -66,6 +66,9 @@ struct WinoParams {
     // dropout masks of a REPLAYED launch (HIP graph): the Philox key is seed ^ mix(*epoch), epoch a device word the graph itself bumps
     // at the start of every replay -- seed and offset are launch arguments, i.e. constants of a captured launch.  null: key = seed.
     const uint64_t* epoch;
+    // Sparse launch (round 5, k15_sparse_blocks.hip): null, or a device list {count, record indices ...} of the LIVE blocks: workgroup slot t
+    // takes record live[1 + t] and slots >= live[0] exit at once (the grid is sized for the whole table: the count never visits the host).
+    const int32_t* live;
     // the store pass writes `replicas` copies of the image (pod_wino_conv3x3_split_replicas: channels-last, one input image per record),
     // replica r as image r of the output canvas, each under its own dropout mask -- the mask pod_expand_dropout would draw for it.  1: off.
     int32_t replicas;

@@ -27,8 +27,8 @@ POD_MAX_DETECTIONS = 128
 EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_score_maybe", "pod_merge_score_fused", "pod_reset_counters", "pod_level_topk", "pod_gather_candidates", "pod_gather_decode",
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
-           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_bf16_split3", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
+           "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image", "pod_run_image_part",
+           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_bf16_split3", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -69,7 +69,7 @@ class PodConvSet(Structure):
 class PodWinoConv(Structure):
     """include/pod_mi355x.h: PodWinoConv."""
     _fields_ = [("blocks", c_void_p), ("n_blocks", c_int32), ("n_sets", c_int32), ("C", c_int32), ("K", c_int32), ("relu", c_int32), ("p", c_float),
-                ("seed", c_uint64), ("epoch", c_void_p), ("n_splits", c_int32), ("reserved", c_int32), ("split_stride", c_int64),
+                ("seed", c_uint64), ("epoch", c_void_p), ("n_splits", c_int32), ("reserved", c_int32), ("split_stride", c_int64), ("live_blocks", c_void_p),
                 ("sets", PodConvSet * 4)]
 
 
@@ -130,6 +130,8 @@ def load() -> ctypes.CDLL:
     lib.pod_wino_filter_transform_split.argtypes = [P, P, c_int32, c_int32, P]
     lib.pod_wino_conv3x3_split.argtypes = [POINTER(PodWinoConv), P]
     lib.pod_absmax.argtypes = [P, c_int64, P, P]
+    lib.pod_sparse_reach.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P]
+    lib.pod_sparse_live_blocks.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, c_int32, P, c_int32, P, P]
     lib.pod_debug_f16_split2.argtypes = [P, c_float, P, c_int64, P]
     lib.pod_wino_reduce.argtypes = [P, c_int32, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P, P]
     lib.pod_reduce_partials.argtypes = [P, c_int32, c_int64, P, P, P, c_int64, c_int32, c_int32, P, P]
@@ -146,6 +148,8 @@ def load() -> ctypes.CDLL:
     lib.pod_debug_bf16_split3.argtypes = [P, P, c_int64, P]
     lib.pod_run_image.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
+    lib.pod_run_image_part.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), c_int32, P]
     for name in EXPORTS:
         if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words", "pod_wino_filter_split_bytes", "pod_conv1x1_filter_split_bytes"):
             getattr(lib, name).restype = ctypes.c_int

@@ -256,20 +256,21 @@ class HotPath:
                 name, l, shape, self.device, t.dtype, tuple(t.shape), tuple(t.stride()), t.device))
         return t.data_ptr(), (t.stride(0) if self.n_runs > 1 else shape[1] * h * w)
 
-    def _levels(self, cls, delta, cls_var, reg_var, eps_cls):
+    def _levels(self, cls, delta, cls_var, reg_var, eps_cls, cls_only: bool = False):
+        """cls_only: the SELECT part of the path alone (pod_run_image_part, parts = 1): delta / reg_var do not exist yet."""
         A, K, D = self.p.num_anchors, self.p.num_classes, self.cov_dims
         arr = self._levels_t()
         for l, (h, w) in enumerate(self.shapes):
             lv = arr[l]
             lv.cls, lv.run_stride_cls = self._run_strided("cls", l, cls[l], K)
-            lv.delta, lv.run_stride_delta = self._run_strided("delta", l, delta[l], 4)
+            lv.delta, lv.run_stride_delta = (None, 0) if cls_only else self._run_strided("delta", l, delta[l], 4)
             lv.cls_var = lv.reg_var = lv.eps_cls = None
             lv.run_stride_reg = 0
             if self.has_cls_var:
                 lv.cls_var, rs = self._run_strided("cls_var", l, cls_var[l], K)
                 if rs != lv.run_stride_cls:
                     raise hip.PodError("cls_var[{}] must share the run stride of cls".format(l))
-            if D > 0:
+            if D > 0 and not cls_only:
                 lv.reg_var, lv.run_stride_reg = self._run_strided("reg_var", l, reg_var[l], D)
             if eps_cls is not None:
                 e = eps_cls[l]
@@ -450,6 +451,38 @@ class HotPath:
         self._dirty = True       # a failure between K1 and K2 leaves counters / bitmap non-zero
         hip.check(self.lib.pod_run_image(self.cfg, lv, self.ws, self._MODE_ID[mode], bm, cm, int(image_size[0]), int(image_size[1]),
                                          int(out_size[0]), int(out_size[1]), d, hip.current_stream()), "pod_run_image")
+        self._dirty = False
+        return out
+
+    # -- the path in two parts, for the sparse bbox tower between them (pod_compare_amd/sparse.py) -------------------------------------
+    def select(self, cls, cls_var=None, draw_id: Optional[int] = None) -> None:
+        """PI:211-308 on the class side alone (pod_run_image_part, parts = 1): merge + score + per-level top-k.  Afterwards the image's
+        candidates stand in cat_keys / cat_level / n_total on the device; box_delta / box_reg_var have not been looked at."""
+        self._clean()
+        self._begin_draw(draw_id)
+        lv = self._levels(cls, None, cls_var, None, None, cls_only=True)
+        self._lv_keepalive = (lv, None)
+        self._dirty = True
+        hip.check(self.lib.pod_run_image_part(self.cfg, lv, self.ws, hip.POD_MODE_STANDARD_NMS, 0, 0, 1, 1, 1, 1, None, 1, hip.current_stream()),
+                  "pod_run_image_part(select)")
+
+    def finish(self, mode: str, cls, delta, cls_var, reg_var, image_size, out_size, box_merge_mode: str = "bayesian_inference",
+               cls_merge_mode: str = "max_score") -> DeviceDetections:
+        """PI:310-636 for the candidates `select` left (parts = 2): gather + decode + NMS / fusion + finalize.  delta / reg_var need to be
+        defined at the candidates' cells only."""
+        if mode not in MODES:
+            raise ValueError("Invalid inference mode {}.".format(mode))   # PI:100-103
+        if mode == "bayes_od" and not self.has_covariance:
+            raise hip.PodError("bayes_od needs box covariances (a reg_var head or MC runs)")
+        lv = self._levels(cls, delta, cls_var, reg_var, None)
+        self._lv_keepalive = (lv, None)
+        out = self.new_detections(out_size)
+        d = hip.PodDetections(out.ptr("boxes"), out.ptr("cov"), out.ptr("scores"), out.ptr("classes"), out.ptr("probs"),
+                              out.ptr("records"), out.ptr("n_det"))
+        bm = {"bayesian_inference": 0, "covariance_intersection": 1}[box_merge_mode]
+        cm = {"max_score": 0, "bayesian_inference": 1}[cls_merge_mode]
+        hip.check(self.lib.pod_run_image_part(self.cfg, lv, self.ws, self._MODE_ID[mode], bm, cm, int(image_size[0]), int(image_size[1]),
+                                              int(out_size[0]), int(out_size[1]), d, 2, hip.current_stream()), "pod_run_image_part(finish)")
         self._dirty = False
         return out
 

@@ -471,6 +471,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         # device word folded into the Philox key of every dropout mask of the Winograd head path (include/pod_mi355x.h: `epoch`): a
         # forward replayed from a HIP graph bumps it (the launch arguments seed / offset are constants of a captured launch)
         self.register_buffer("_epoch", torch.zeros(1, dtype=torch.int64), persistent=False)
+        self._sparse_pool = {}
         self.compute_cls_var, self.compute_bbox_cov, self.bbox_cov_dims = compute_cls_var, compute_bbox_cov, bbox_cov_dims
         self.cls_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
         self.bbox_subnet = nn.ModuleList(nn.Conv2d(in_channels, in_channels, 3, padding=1) for _ in range(num_convs))
@@ -538,25 +539,31 @@ class ProbabilisticRetinaNetHead(nn.Module):
     def _wino(self, conv: nn.Conv2d):
         return wino_of(conv)
 
-    def _trunk_all_levels(self, convs, x0: torch.Tensor, levels, copies: int, dropout: bool):
+    def _trunk_all_levels(self, convs, x0: torch.Tensor, levels, copies: int, dropout: bool, live=None, bufs=None):
         """`copies` evaluations of a subnet on ALL levels: one pod_wino_conv3x3 launch per conv layer (fp32 Winograd on the
         matrix cores, bias + ReLU + dropout in its store) instead of one MIOpen call + one element-wise pass per level and
         layer.  x0: (pixels of all levels, C) channels-last, level after level.  Returns (buffer, images per level): the last
         activation as (pixels of all levels x images, C) channels-last, level after level -- `copies` images per level with
-        dropout, one without (every copy would be identical)."""
+        dropout, one without (every copy would be identical).
+        live (sparse bbox tower, pod_compare_amd/sparse.py): a LiveBlocks -- layer j is launched over the blocks of reach L - j only;
+        bufs: `new(key, shape)` handing out PERSISTENT zero-initialised buffers (what a dead block holds must be finite: it may stand in
+        a live block's patch)."""
         from . import hip
+        from .sparse import reach_of_subnet_layer
         from .wino import block_table, level_pixel_offsets
-        lib, C = hip.load(), x0.shape[1]
+        lib, C, L = hip.load(), x0.shape[1], len(convs)
         t1 = block_table(levels, 1, x0.device)
         off1 = level_pixel_offsets(levels, 1)
         first = self._wino(convs[0])
+        lv = (lambda table, layer: None) if live is None else (lambda table, layer: live(table, reach_of_subnet_layer(layer, L)))
+        new = (lambda key, shape: torch.empty(shape, dtype=x0.dtype, device=x0.device)) if bufs is None else bufs
         if not dropout:
-            y = first(x0, torch.empty_like(x0), t1, relu=True)
-            for conv in convs[1:]:
-                y = self._wino(conv)(y, torch.empty_like(y), t1, relu=True)
+            y = first(x0, new("t0", tuple(x0.shape)), t1, relu=True, live=lv(t1, 0))
+            for j, conv in enumerate(convs[1:], 1):
+                y = self._wino(conv)(y, new("t%d" % (j & 1), tuple(y.shape)), t1, relu=True, live=lv(t1, j))
             return y, 1
         offn = level_pixel_offsets(levels, copies)
-        a = torch.empty((offn[-1], C), dtype=x0.dtype, device=x0.device)
+        a = new("a", (offn[-1], C))
         replay = self.dropout_replay is not None
         sid = 0 if convs is self.cls_subnet else 1
         # The first activation is identical for every copy: computed once, stored `copies` times under the copies' dropout masks.  One
@@ -565,9 +572,11 @@ class ProbabilisticRetinaNetHead(nn.Module):
         p_first = 0.0 if replay else float(self.dropout_rate)
         if first.split and copies <= 127 and FUSED_REPLICAS:
             # ... by the conv's own store pass (pod_wino_conv3x3_split_replicas)
-            first.replicas(x0, a, block_table(levels, 1, x0.device, out_copies=copies), copies, relu=True, dropout_p=p_first,
-                           seed=self.dropout_seed, offset=self._drop_calls << 34, epoch=self._epoch)
+            tr = block_table(levels, 1, x0.device, out_copies=copies)
+            first.replicas(x0, a, tr, copies, relu=True, dropout_p=p_first, seed=self.dropout_seed, offset=self._drop_calls << 34, epoch=self._epoch,
+                           live=lv(tr, 0))
         else:
+            assert live is None, "the sparse tower needs the split kernel's replica store"
             # ... or by a pass of its own per level (the fp32-MFMA kernel; the same masks)
             y = first(x0, torch.empty_like(x0), t1, relu=True)
             for i, (h, w) in enumerate(levels):
@@ -583,11 +592,11 @@ class ProbabilisticRetinaNetHead(nn.Module):
         if replay:
             mask_in_place(a, 0)
         tn = block_table(levels, copies, x0.device)
-        b = torch.empty_like(a)
+        b = new("b", tuple(a.shape))
         for j, conv in enumerate(convs[1:], 1):
             self._drop_calls += 1
             self._wino(conv)(a, b, tn, relu=True, dropout_p=0.0 if replay else self.dropout_rate, seed=self.dropout_seed,
-                             offset=self._drop_calls << 34, epoch=self._epoch)
+                             offset=self._drop_calls << 34, epoch=self._epoch, live=lv(tn, j))
             if replay:
                 mask_in_place(b, j)
             a, b = b, a
@@ -641,19 +650,23 @@ class ProbabilisticRetinaNetHead(nn.Module):
             a, b = b, a
         return a[0], copies_c, a[1], copies_b
 
-    def _predict_grouped(self, jobs, levels):
+    def _predict_grouped(self, jobs, levels, live=None, bufs=None):
         """The predictor convs in ONE launch.  jobs: (conv, buffer, images in the buffer per level, first image, image count, output images)
-        as `_predict_all_levels` takes them; returns its result for each job."""
+        as `_predict_all_levels` takes them; returns its result for each job.  live / bufs: the sparse bbox tower (`_trunk_all_levels`)."""
+        from .sparse import REACH_PREDICTOR
         from .wino import block_table, grouped_launch, level_pixel_offsets
         sets, outs = [], []
-        for conv, buf, buf_copies, first, count, out_copies in jobs:
+        for ji, (conv, buf, buf_copies, first, count, out_copies) in enumerate(jobs):
             K = conv.out_channels
             offs = level_pixel_offsets(levels, out_copies)
-            out = (torch.zeros if out_copies > count else torch.empty)(offs[-1] * K, dtype=buf.dtype, device=buf.device)
+            if bufs is not None:
+                out = bufs("p%d" % ji, (offs[-1] * K,))
+            else:
+                out = (torch.zeros if out_copies > count else torch.empty)(offs[-1] * K, dtype=buf.dtype, device=buf.device)
             sets.append({"conv": self._wino(conv), "src": buf, "dst": out, "planes": True,
                          "table": block_table(levels, count, buf.device, in_copies=buf_copies, in_first=first, out_copies=out_copies)})
             outs.append([out[offs[i] * K:offs[i + 1] * K].view(out_copies, K, h, w) for i, (h, w) in enumerate(levels)])
-        grouped_launch(sets)
+        grouped_launch(sets, live=None if live is None else (lambda table: live(table, REACH_PREDICTOR)))
         return outs
 
     def _predict_all_levels(self, conv, buf: torch.Tensor, levels, buf_copies: int, first: int, count: int, out_copies: int):
@@ -686,15 +699,32 @@ class ProbabilisticRetinaNetHead(nn.Module):
                                        self._drop_calls << 34, hip.current_stream()), "pod_relu_dropout")
         return x
 
+    def sparse_buffers(self, key):
+        """Persistent zero-initialised activation buffers of the sparse bbox tower, per (stream, geometry): new(name, shape)."""
+        pool = self._sparse_pool.setdefault(key, {})
+
+        def new(name, shape):
+            t = pool.get(name)
+            if t is None or tuple(t.shape) != tuple(shape):
+                t = pool[name] = torch.zeros(shape, dtype=torch.float32, device=self.cls_score.weight.device)
+            return t
+        return new
+
     def forward(self, features: List[torch.Tensor], num_runs: int = 1, mc_dropout: bool = False,
-                skip_unused_last_run: bool = False):
+                skip_unused_last_run: bool = False, sparse_bbox=None):
         """features: per-level (1, 256, H, W).  Returns per-level lists of (num_runs, A*C, H, W).
 
         skip_unused_last_run: the reference's merge (PI:216-222) never reads run N-1 of box_cls,
         box_cls_var and box_reg_var (only box_delta's last run is used, by the epistemic covariance PI:325-331).
         With the flag set those three evaluations of the last run are not computed (their slab in the returned
         tensors is zero): 3 of the 4N subnet evaluations, 7.5 % of the head at N = 10.  Only valid
-        together with `merge_quirk=True` in the hot path."""
+        together with `merge_quirk=True` in the hot path.
+
+        sparse_bbox (round 5): None, or a callable (logits, logit_vars) -> sparse.LiveBlocks.  The cls side is then evaluated FIRST, the
+        callable selects the image's candidates from it (K1f + K2 of the hot path, PI:283-308) and the bbox side -- bbox_subnet,
+        bbox_pred, bbox_cov: PR:518-537 evaluates them densely although PI:310-331 reads them at the candidates only -- runs over the
+        blocks that can reach a candidate.  Its outputs are defined at the candidates' cells and stale elsewhere; same Philox offsets, so
+        the same dropout masks as the dense evaluation."""
         dropout = mc_dropout and self.dropout_rate > 0.0
         n = num_runs
         skip = 1 if (skip_unused_last_run and dropout and n > 1) else 0
@@ -718,6 +748,27 @@ class ProbabilisticRetinaNetHead(nn.Module):
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
             x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
             grouped = self._grouped_ok(cls_copies, box_copies)
+            if sparse_bbox is not None:
+                if not grouped:
+                    raise RuntimeError("the sparse bbox tower needs the split kernels (POD_WINO_SPLIT=1, grouped head)")
+                tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
+                cj = [(self.cls_score, tc, nc, 0, m, n)] if dropout else [(self.cls_score, tc, 1, 0, 1, 1)]
+                if self.compute_cls_var:
+                    cj += [(self.cls_var, tc, nc, m, m, n)] if dropout else [(self.cls_var, tc, 1, 0, 1, 1)]
+                res = self._predict_grouped(cj, levels)
+                if not dropout and n > 1:
+                    res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
+                logits, logit_vars = res[0], (res[1] if self.compute_cls_var else None)
+                live = sparse_bbox(logits, logit_vars)
+                bufs = self.sparse_buffers((torch.cuda.current_stream(x0.device).cuda_stream, tuple(levels), n, dropout, skip))
+                tb, nb = self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout, live=live, bufs=bufs)
+                bj = [(self.bbox_pred, tb, nb, 0, n, n)] if dropout else [(self.bbox_pred, tb, 1, 0, 1, 1)]
+                if self.compute_bbox_cov:
+                    bj += [(self.bbox_cov, tb, nb, n, m, n)] if dropout else [(self.bbox_cov, tb, 1, 0, 1, 1)]
+                res = self._predict_grouped(bj, levels, live=live, bufs=bufs)
+                if not dropout and n > 1:
+                    res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
+                return logits, res[0], logit_vars, (res[1] if self.compute_bbox_cov else None)
             if grouped:
                 tc, nc, tb, nb = self._trunks_grouped(x0, levels, cls_copies, box_copies, dropout)
             else:
@@ -943,15 +994,19 @@ class ProbabilisticRetinaNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False,
-                mc_dropout: Optional[bool] = None) -> HeadOutputs:
+                mc_dropout: Optional[bool] = None, sparse_bbox=None) -> HeadOutputs:
         """Raw anchor-wise output (`return_anchorwise_output=True`, PR:352-361) in NCHW plane layout.
         num_mc_dropout_runs > 1 batches that many dropout-perturbed head evaluations (PR:103-108).
         mc_dropout: dropout active in the head subnets -- the reference's `model.train()` (PI:53-56), which it sets
-        whenever MC_DROPOUT.ENABLE is true, also for a single run; default: active iff several runs are requested."""
+        whenever MC_DROPOUT.ENABLE is true, also for a single run; default: active iff several runs are requested.
+        sparse_bbox: callable (partial HeadOutputs: cls / cls_var set, delta = reg_var = None) -> sparse.LiveBlocks: the bbox side of the
+        head is evaluated only where it can reach a candidate (ProbabilisticRetinaNetHead.forward); not captured into HIP graphs yet."""
         n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
         if mc_dropout is None:
             mc_dropout = n > 1
         dropout = bool(mc_dropout) and self.use_dropout
+        if sparse_bbox is not None:
+            return self._forward_eager(image, n, dropout, skip_unused_last_run, sparse_bbox)
         if (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
                 and (not dropout or self.head.takes_wino_path())):
             return self._forward_graphed(image, n, dropout, skip_unused_last_run)
@@ -983,17 +1038,21 @@ class ProbabilisticRetinaNet(nn.Module):
             padded = tuple(x.shape[-2:])
         return feats, padded
 
-    def _head_eager(self, feats, padded, image_hw, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
-        cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
-                                                 skip_unused_last_run=skip_unused_last_run)
+    def _head_eager(self, feats, padded, image_hw, n: int, mc_dropout: bool, skip_unused_last_run: bool, sparse_bbox=None) -> HeadOutputs:
         shapes = [tuple(f.shape[-2:]) for f in feats]
         skipped = skip_unused_last_run and n > 1 and bool(mc_dropout) and self.use_dropout
+        hook = None
+        if sparse_bbox is not None:
+            hook = lambda logits, logit_vars: sparse_bbox(HeadOutputs(logits, None, logit_vars, None, self.anchors_for(padded), shapes, self.num_anchors,
+                                                                      self.num_classes, tuple(image_hw), last_run_valid=not skipped))
+        cls, delta, cls_var, reg_var = self.head(feats, n, mc_dropout=bool(mc_dropout) and self.use_dropout,
+                                                 skip_unused_last_run=skip_unused_last_run, sparse_bbox=hook)
         return HeadOutputs(cls, delta, cls_var, reg_var, self.anchors_for(padded), shapes, self.num_anchors,
                            self.num_classes, tuple(image_hw), last_run_valid=not skipped)
 
-    def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool) -> HeadOutputs:
+    def _forward_eager(self, image: torch.Tensor, n: int, mc_dropout: bool, skip_unused_last_run: bool, sparse_bbox=None) -> HeadOutputs:
         feats, padded = self._trunk_eager(image)
-        return self._head_eager(feats, padded, image.shape[-2:], n, mc_dropout, skip_unused_last_run)
+        return self._head_eager(feats, padded, image.shape[-2:], n, mc_dropout, skip_unused_last_run, sparse_bbox)
 
 
 def resize_test_image(image: torch.Tensor, min_size: int = 800, max_size: int = 1333) -> torch.Tensor:

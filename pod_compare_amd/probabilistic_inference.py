@@ -153,10 +153,15 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         # True: predictor(input_im) returns the fixed-capacity DeviceDetections (no host sync at all: the count stays on
         # the GPU) instead of an `Instances`; the image-sharded driver uses it so the host can run ahead of the device
         self.return_device = False
+        # Sparse bbox tower (round 5, pod_compare_amd/sparse.py): evaluate the cls side of the head first, select the candidates
+        # (PI:283-308), then run bbox_subnet / bbox_pred / bbox_cov only over the blocks that can reach a candidate (PI:310-331 reads
+        # nothing else).  Own model, native draws, single-model modes; POD_SPARSE_BBOX=1 switches it on for a process.
+        self.sparse_bbox_tower = os.environ.get("POD_SPARSE_BBOX", "0") == "1"
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _path_for(self, ho: HeadOutputs) -> hotpath.HotPath:
-        cov_dims = 0 if ho.reg_var is None else ho.reg_var[0].shape[1] // ho.num_anchors
+    def _path_for(self, ho: HeadOutputs, cov_dims: Optional[int] = None) -> hotpath.HotPath:
+        if cov_dims is None:
+            cov_dims = 0 if ho.reg_var is None else ho.reg_var[0].shape[1] // ho.num_anchors
         dev = ho.cls[0].device
         # one workspace per (geometry, stream): a driver may keep several images in flight on different HIP streams
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
@@ -204,6 +209,33 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         out = (input_im[0].get("height", image_size[0]), input_im[0].get("width", image_size[1]))   # PI:106-107
         return image_size, out
 
+    def _sparse_ok(self) -> bool:
+        m = self.model
+        return (self.sparse_bbox_tower and self.eps_fn is None and isinstance(m, modeling.ProbabilisticRetinaNet) and m.head.takes_wino_path()
+                and input_is_cuda(m))
+
+    def _run_sparse(self, mode, input_im) -> Instances:
+        """`_run` with the model's bbox side evaluated between the two parts of the path (hotpath.select / finish)."""
+        from . import sparse
+        m, image, state = self.model, input_im[0]["image"], {}
+        cov_dims = m.bbox_cov_dims if m.compute_bbox_cov else 0
+
+        def hook(partial: HeadOutputs):
+            hp = self._path_for(partial, cov_dims=cov_dims)
+            hp.select(partial.cls, partial.cls_var, draw_id=self._draw_id(input_im))
+            state["hp"] = hp
+            return sparse.LiveBlocks(hp)
+
+        mc = self.mc_dropout_enabled and self.num_mc_dropout_runs > 1
+        ho = m(image, num_mc_dropout_runs=self.num_mc_dropout_runs if mc else -1, mc_dropout=bool(self.mc_dropout_enabled),
+               skip_unused_last_run=mc and self.merge_quirk, sparse_bbox=hook)
+        hp = self.last_path = state["hp"]
+        image_size, out = self._sizes(input_im, ho)
+        bo = self.cfg.PROBABILISTIC_INFERENCE.BAYES_OD
+        det = hp.finish(mode, ho.cls, ho.delta, ho.cls_var, ho.reg_var, image_size, out, bo.BOX_MERGE_MODE, bo.CLS_MERGE_MODE)
+        self.last_detections = det
+        return det if self.return_device else detections_to_instances(det)
+
     def _run(self, mode, input_im, ho: HeadOutputs) -> Instances:
         hp = self._path_for(ho)
         self.last_path = hp
@@ -250,13 +282,19 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         return hp.boxes[:n], cov, hp.cand_score[:n], hp.cand_class[:n].long(), hp.cand_probs[:n]
 
     def post_processing_standard_nms(self, input_im):
+        if self._sparse_ok():
+            return self._run_sparse("standard_nms", input_im)
         return self._run("standard_nms", input_im, self._head_outputs(input_im))
 
     def post_processing_anchor_statistics(self, input_im):
+        if self._sparse_ok():
+            return self._run_sparse("anchor_statistics", input_im)
         return self._run("anchor_statistics", input_im, self._head_outputs(input_im))
 
     def post_processing_mc_dropout_ensembles(self, input_im):
         if self.cfg.PROBABILISTIC_INFERENCE.ENSEMBLES_DROPOUT.BOX_MERGE_MODE == "pre_nms":     # PI:442-443
+            if self._sparse_ok():
+                return self._run_sparse("standard_nms", input_im)
             return self._run("standard_nms", input_im, self._head_outputs(input_im))
         ho = self._head_outputs(input_im, need_all_runs=True)                                  # PI:445-451: N runs, merged post-NMS
         return self._run_post_nms(input_im, [run_slice(ho, r) for r in range(ho.num_runs)])
@@ -268,7 +306,13 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         return self._run_post_nms(input_im, [m(input_im[0]["image"]) for m in model_dict])     # PI:506-534
 
     def post_processing_bayes_od(self, input_im):
+        if self._sparse_ok():
+            return self._run_sparse("bayes_od", input_im)
         return self._run("bayes_od", input_im, self._head_outputs(input_im))
+
+
+def input_is_cuda(model) -> bool:
+    return model.device.type == "cuda"
 
 
 def run_slice(ho: HeadOutputs, run: int) -> HeadOutputs:

@@ -71,8 +71,8 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
     t = _TABLES.get(key)
     if t is None:
         ioffs, ooffs = level_pixel_offsets(levels, in_copies), level_pixel_offsets(levels, out_copies)
-        rows = []
-        for (h, w), ioff, ooff in zip(levels, ioffs, ooffs):
+        rows, rec_levels = [], []
+        for li, ((h, w), ioff, ooff) in enumerate(zip(levels, ioffs, ooffs)):
             assert 0 < h < 4096 and 0 < w < 4096
             if h * w * channels * 4 > MAX_CANVAS_BYTES:
                 raise ValueError("pod_wino_conv3x3: one %d x %d image of %d channels exceeds the kernel's 32-bit canvas offsets" % (h, w, channels))
@@ -87,12 +87,14 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
                 rec = torch.tensor([[ioff + (in_first + done) * h * w, ooff + done * h * w, (gcols << 24) | (h << 12) | w, (n << 24) | (r << 12) | c]
                                     for r, c in blocks], dtype=torch.int64)
                 rows.append(rec)
+                rec_levels.extend([li] * len(blocks))
                 done += n
         assert max(ioffs[-1], ooffs[-1]) < 2 ** 31
         t = torch.cat(rows).to(torch.int32).to(device).contiguous()
         t.pod_pixels = copies * sum(h * w for h, w in levels)          # output pixels of a launch with this table
         t.pod_levels = len(levels)
         t.pod_channels = channels
+        t.pod_rec_level = torch.tensor(rec_levels, dtype=torch.int32).to(device)       # FPN level of every record (pod_sparse_live_blocks)
         if t.is_cuda and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(t.device).synchronize()           # made once, then read from any stream
         _TABLES[key] = t
@@ -108,13 +110,13 @@ SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"      # (the name is ro
 
 
 def _launch_split(sets, table: torch.Tensor, firsts, C: int, Kpad: int, relu: bool, dropout_p: float, seed: int, epoch, n_splits: int = 0,
-                  split_stride: int = 0, what: str = "pod_wino_conv3x3_split") -> None:
+                  split_stride: int = 0, what: str = "pod_wino_conv3x3_split", live: Optional[torch.Tensor] = None) -> None:
     """sets: dicts {conv, src, dst, offset, replicas, planes, out_amax: bool}.  Fills a PodWinoConv and launches it; the input abs-max words
     come from pod_compare_amd.amax (the producer's, or pod_absmax), the outputs' are published by the store pass."""
     d = hip.PodWinoConv()
     d.blocks, d.n_blocks, d.n_sets = table.data_ptr(), int(table.shape[0]), len(sets)
     d.C, d.K, d.relu, d.p, d.seed, d.epoch = C, Kpad, 1 if relu else 0, float(dropout_p), int(seed), hip.ptr(epoch)
-    d.n_splits, d.split_stride = int(n_splits), int(split_stride)
+    d.n_splits, d.split_stride, d.live_blocks = int(n_splits), int(split_stride), hip.ptr(live)
     for i, s in enumerate(sets):
         q, conv = d.sets[i], s["conv"]
         planes = bool(s.get("planes", False))
@@ -125,7 +127,7 @@ def _launch_split(sets, table: torch.Tensor, firsts, C: int, Kpad: int, relu: bo
     hip.check(hip.load().pod_wino_conv3x3_split(ctypes.byref(d), hip.current_stream()), what)
 
 
-def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int = 0, epoch: Optional[torch.Tensor] = None) -> None:
+def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int = 0, epoch: Optional[torch.Tensor] = None, live=None) -> None:
     """Up to four convolutions of one shape in ONE grid (pod_wino_conv3x3_split, n_sets > 1).  sets: dicts {conv: WinoConv (split kernel),
     src, dst, table, offset = 0, replicas = 0 (r >= 1: WinoConv.replicas' store pass), planes = False}; every set keeps its own buffers, table, filter, bias, Philox offset.
     Bit for bit the separate launches conv(src, dst, table, ...) / conv.replicas(...)."""
@@ -148,9 +150,11 @@ def grouped_launch(sets, relu: bool = False, dropout_p: float = 0.0, seed: int =
         if len(_GROUPED_TABLES) >= 64:
             _GROUPED_TABLES.pop(next(iter(_GROUPED_TABLES)))
         cat = _GROUPED_TABLES[key] = (torch.cat(tabs).contiguous(), tabs)          # (keeps the parts alive: their addresses are the key)
+        cat[0].pod_rec_level = torch.cat([t.pod_rec_level for t in tabs]).contiguous()
         if not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(tabs[0].device).synchronize()               # made once, then read from any stream
-    _launch_split(sets, cat[0], firsts, c0.C, c0.Kpad, relu, dropout_p, seed, epoch)
+    # live: a callable (concatenated table) -> device list of its live records (sparse launch), or None
+    _launch_split(sets, cat[0], firsts, c0.C, c0.Kpad, relu, dropout_p, seed, epoch, live=None if live is None else live(cat[0]))
 
 
 _GROUPED_TABLES = {}
@@ -183,7 +187,7 @@ class WinoConv:
         self.version = (weight._version, None if bias is None else bias._version, weight.data_ptr())
 
     def __call__(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, relu: bool = False, dropout_p: float = 0.0,
-                 seed: int = 0, offset: int = 0, planes: bool = False, epoch: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 seed: int = 0, offset: int = 0, planes: bool = False, epoch: Optional[torch.Tensor] = None, live: Optional[torch.Tensor] = None) -> torch.Tensor:
         """src: (pixels, C) channels-last.  dst: (pixels, Kpad) channels-last, or with planes=True any contiguous buffer of
         NCHW images with K (real) planes each, level-major like the table's output side.  epoch: a device int64 word folded into
         the dropout masks' Philox key (launches replayed from a HIP graph, include/pod_mi355x.h)."""
@@ -191,8 +195,10 @@ class WinoConv:
         assert planes or dst.shape[-1] == self.Kpad
         assert getattr(table, "pod_channels", 512) >= max(self.C, self.K if planes else self.Kpad), "block_table(channels=...) below this conv's channel count"
         if self.split:
-            _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "planes": planes}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch)
+            _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "planes": planes}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch,
+                          live=live)
             return dst
+        assert live is None, "sparse launches need the split kernel"
         hip.check(hip.load().pod_wino_conv3x3(src.data_ptr(), dst.data_ptr(), self.U.data_ptr(), hip.ptr(self.bias), table.data_ptr(),
                                               table.shape[0], self.C, self.Kpad, self.K if planes else 0, 1 if relu else 0, float(dropout_p),
                                               seed, offset, hip.ptr(epoch), hip.current_stream()), "pod_wino_conv3x3")
@@ -200,13 +206,14 @@ class WinoConv:
         return dst
 
     def replicas(self, src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, replicas: int, relu: bool = False, dropout_p: float = 0.0,
-                 seed: int = 0, offset: int = 0, epoch: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 seed: int = 0, offset: int = 0, epoch: Optional[torch.Tensor] = None, live: Optional[torch.Tensor] = None) -> torch.Tensor:
         """conv + bias (+ ReLU) of ONE image per level, stored `replicas` times with a dropout mask each (pod_wino_conv3x3_split_replicas):
         table = block_table(levels, 1, out_copies=replicas); dst: the `replicas` images per level, channels-last.  The masks are those
         of pod_expand_dropout called per level with offset + (first float of the level in dst) / 8 (`expand_offset`)."""
         assert self.split and self.K == self.Kpad and 1 <= replicas <= 127
         assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == self.C and dst.shape[-1] == self.Kpad and src.dtype == dst.dtype == torch.float32
-        _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "replicas": int(replicas)}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch)
+        _launch_split([{"conv": self, "src": src, "dst": dst, "offset": offset, "replicas": int(replicas)}], table, [0], self.C, self.Kpad, relu, dropout_p, seed, epoch,
+                      live=live)
         return dst
 
     def splits_for(self, n_blocks: int, cus: int = 256) -> int:

@@ -1,0 +1,148 @@
+"""Sparse bbox tower (csrc/k15_sparse_blocks.hip, pod_compare_amd/sparse.py): PI:310-331 reads box_delta / box_reg_var only at the candidates
+of PI:300-308, so bbox_subnet / bbox_pred / bbox_cov (PR:518-537) are evaluated over the blocks that can reach one -- and the detections
+must be those of the dense evaluation."""
+import numpy as np
+import pytest
+import torch
+
+from pod_compare_amd import hip, hotpath, modeling, sparse, synthetic
+from pod_compare_amd.wino import block_table
+
+pytestmark = pytest.mark.gpu
+
+
+def build(**kw):
+    torch.manual_seed(0)
+    m = modeling.ProbabilisticRetinaNet(cls_var_loss="loss_attenuation", cls_var_num_samples=10, bbox_cov_loss="negative_log_likelihood", **kw).cuda().eval()
+    modeling.fold_frozen_bn(m)
+    for q in m.parameters():
+        q.requires_grad_(False)
+    return m
+
+
+def planted(padded, runs, seed, mode="planted"):
+    return synthetic.planted_head_outputs(padded, runs, seed=seed, num_boxes=6, mode=mode).to("cuda")
+
+
+def reach_reference(hp, n_total, cat_keys, cat_level):
+    """needed(j) = candidates (+) box(2 j rows, 4 j columns), brute force."""
+    A = hp.p.num_anchors
+    out = []
+    for l, (h, w) in enumerate(hp.shapes):
+        r = np.full((h, w), 255, dtype=np.int64)
+        idx = [(0xFFFFFFFF - (int(k) & 0xFFFFFFFF)) // A for k, lv in zip(cat_keys[:n_total], cat_level[:n_total]) if lv == l]
+        ys, xs = np.arange(h)[:, None], np.arange(w)[None, :]
+        for c in set(idx):
+            cy, cx = divmod(c, w)
+            j = np.maximum((np.abs(ys - cy) + 1) // 2, (np.abs(xs - cx) + 3) // 4)
+            r = np.minimum(r, np.where(j <= 5, j, 255))
+        out.append(r.reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("mode,runs", [("planted", 3), ("worst", 1)])
+def test_reach_map_and_live_lists_equal_a_brute_force_evaluation(mode, runs):
+    padded = (256, 384)
+    ho = planted(padded, runs, seed=5, mode=mode)
+    hp = hotpath.HotPath(ho.shapes, ho.anchors, hotpath.PathParams(), n_runs=runs, has_cls_var=True, cov_dims=4, device="cuda:0")
+    hp.select(ho.cls, ho.cls_var, draw_id=3)
+    live = sparse.LiveBlocks(hp)
+    n = int(hp.n_total.item())
+    assert n > 0
+    want = reach_reference(hp, n, hp.cat_keys.cpu().tolist(), hp.cat_level.cpu().tolist())
+    got = live.reach.cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, want)
+    levels = [tuple(s) for s in hp.shapes]
+    for copies, reach in ((1, 4), (5, 2), (5, 0)):
+        table = block_table(levels, copies, "cuda")
+        lst = live(table, reach).cpu().numpy()
+        recs, rl = table.cpu().numpy(), table.pod_rec_level.cpu().numpy()
+        base = np.cumsum([0] + [h * w for h, w in levels])
+        expect = set()
+        for r, (d, l) in enumerate(zip(recs, rl)):
+            gcols, H, W, n_img = (d[2] >> 24) & 0xFF, (d[2] >> 12) & 0xFFF, d[2] & 0xFFF, (d[3] >> 24) & 0xFF
+            by, bx = (d[3] >> 12) & 0xFFF, d[3] & 0xFFF
+            vy, vx = np.meshgrid(16 * by + np.arange(16), 16 * bx + np.arange(16), indexing="ij")
+            m_, gy, n_, gx = vy // (H + 1), vy % (H + 1), vx // (W + 1), vx % (W + 1)
+            ok = (gy < H) & (gx < W) & (n_ < gcols) & (m_ * gcols + n_ < n_img)
+            cells = base[l] + np.where(ok, gy * W + gx, 0)
+            if bool((ok & (want[cells] <= reach)).any()):
+                expect.add(r)
+        assert set(lst[1:1 + lst[0]].tolist()) == expect and lst[0] == len(expect)
+        if mode == "planted" and reach == 0:
+            assert lst[0] < 0.6 * len(recs)                    # a handful of objects: most blocks are dead
+
+
+@pytest.mark.parametrize("dropout,runs", [(0.2, 4), (0.0, 1)])
+def test_sparse_tower_gives_the_dense_towers_detections(dropout, runs):
+    """The whole model twice on one frame, dense and sparse, with the SAME planted class tensors selecting the candidates (a random-init
+    head has none): identical candidates and masks, box deltas / variances at the candidates equal to the last bits (the abs-max record
+    of a sparse launch covers the live blocks only: another binade moves the f16 splits' roundings), identical detections."""
+    m = build(dropout_rate=dropout)
+    frame = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    pl = planted((256, 384), runs, seed=9)
+    mc = dropout > 0
+    kw = dict(num_mc_dropout_runs=runs if mc else -1, mc_dropout=mc, skip_unused_last_run=mc)
+    m.head._drop_calls = 0
+    dense = m(frame, **kw)
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=runs if mc else 1, has_cls_var=True, cov_dims=4, device="cuda:0")
+    cls = pl.cls if mc else [t[:1] for t in pl.cls]
+    cls_var = pl.cls_var if mc else [t[:1] for t in pl.cls_var]
+    want = hp.run_image("bayes_od", cls, dense.delta, cls_var, dense.reg_var, (256, 384), (256, 384), draw_id=11)
+    n = int(hp.n_total.item())
+    ref = [t[:n].clone() for t in (hp.cand_delta, hp.cand_reg_var, hp.cand_anchor_idx, hp.boxes, hp.cov)]
+    shares = {}
+
+    def hook(partial):
+        hp.select(cls, cls_var, draw_id=11)
+        lb = sparse.LiveBlocks(hp)
+        shares["lb"] = lb
+        return lb
+
+    m.head._drop_calls = 0
+    sp = m(frame, sparse_bbox=hook, **kw)
+    for a, b in zip(sp.cls + sp.cls_var, dense.cls + dense.cls_var):
+        # the cls side is the dense one (MIOpen's p6 / p7 kernels accumulate with atomics: two forwards agree to rounding, not bit for bit)
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+    got = hp.finish("bayes_od", cls, sp.delta, cls_var, sp.reg_var, (256, 384), (256, 384))
+    assert int(hp.n_total.item()) == n and n > 20
+    assert torch.equal(hp.cand_anchor_idx[:n], ref[2])
+    for name, a, b in (("delta", hp.cand_delta[:n], ref[0]), ("reg_var", hp.cand_reg_var[:n], ref[1])):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), name
+    assert float((hp.boxes[:n] - ref[3]).abs().max()) <= 1e-4 * max(1.0, float(ref[3].abs().max()))
+    k = got.count()
+    assert k == want.count() and k > 0
+    assert torch.equal(got.classes[:k], want.classes[:k])
+    assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
+    assert float((got.cov[:k] - want.cov[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.cov[:k].abs().max()))
+    # and the tower really was sparse
+    lv = [tuple(s) for s in pl.shapes]
+    assert shares["lb"].fraction(block_table(lv, 1, "cuda"), 0) < 0.7
+
+
+def test_predictor_switch_gives_the_same_instances():
+    """build_predictor(...)(input_im) with and without `sparse_bbox_tower`, a model whose class bias lets every level fill its top-k
+    (all blocks live: the switch must not change a thing beyond the last bits)."""
+    import os
+    from pod_compare_amd import config
+    from pod_compare_amd.probabilistic_inference import build_predictor
+    root = os.path.join(os.path.dirname(os.path.abspath(config.__file__)), "configs")
+    cfg = config.setup_config(os.path.join(root, "BDD-Detection", "retinanet", "retinanet_R_50_FPN_1x_reg_cls_var.yaml"),
+                              os.path.join(root, "Inference", "bayes_od.yaml"))
+    cfg.MODEL.DEVICE = "cuda"
+    m = build()
+    with torch.no_grad():
+        m.head.cls_score.weight.mul_(40.0)
+        m.head.cls_score.bias.fill_(-2.5)
+    frame = torch.randint(0, 256, (3, 200, 300), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    inp = [{"image": frame, "height": 200, "width": 300, "image_id": 7}]
+    outs = []
+    for on in (False, True):
+        p = build_predictor(cfg, model=m)
+        p.sparse_bbox_tower = on
+        outs.append(p(inp))
+    a, b = outs
+    assert len(a) == len(b) and len(a) > 0
+    assert torch.equal(a.pred_classes, b.pred_classes)
+    assert float((a.pred_boxes.tensor - b.pred_boxes.tensor).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes.tensor.abs().max()))
+    assert float((a.pred_boxes_covariance - b.pred_boxes_covariance).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes_covariance.abs().max()))
