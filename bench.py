@@ -95,6 +95,9 @@ def parse_args():
     ap.add_argument("--split-bf16", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of the model forward from Python instead of replaying a HIP graph "
                                                              "per (stream, shape)")
+    ap.add_argument("--sparse-bbox", action="store_true",
+                    help="time the SPARSE bbox tower as the step (never the headline `value` of a default run, which stays the dense head and carries the "
+                         "sparse figures beside it): cls side first, candidates selected, bbox side over the blocks that can reach one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the K1 / conv / NLL / worst-case legs after the timed region")
     ap.add_argument("--cpu-images", type=int, default=256, help="upper bound; the CPU leg stops after ~12 s of CPU work")
@@ -452,7 +455,29 @@ def main():
     R = hp.R
     mc = N > 1 and spec["dropout"] > 0.0
 
+    sparse_state = {"on": bool(args.sparse_bbox), "heads": heads}
+    if args.sparse_bbox and (len(members) > 1 or args.no_cnn):
+        raise SystemExit("--sparse-bbox: single-model configurations with the conv net in the step")
+
+    def step_sparse(i):
+        """The step with the sparse bbox tower (pod_compare_amd/sparse.py): backbone + cls side (timed, output discarded as in the dense
+        step), the candidates selected from the planted class tensors, the bbox side over the blocks that can reach one (timed, output
+        discarded), the rest of the path on the planted tensors."""
+        from pod_compare_amd import sparse
+        s = i % n_streams
+        hs = sparse_state["heads"]
+        with torch.cuda.stream(streams[s]):
+            h = hs[i % len(hs)]
+
+            def hook(partial):
+                hps[s].select(h.cls, h.cls_var)
+                return sparse.LiveBlocks(hps[s])
+            model(modeling.resize_test_image(frames[i % n_img]), num_mc_dropout_runs=N, skip_unused_last_run=params.merge_quirk, sparse_bbox=hook)
+            return hps[s].finish(spec["mode"], h.cls, h.delta, h.cls_var, h.reg_var, net_hw, FRAME_HW)
+
     def step(i):
+        if sparse_state["on"]:
+            return step_sparse(i)
         s = i % n_streams
         with torch.cuda.stream(streams[s]):
             if not args.no_cnn:
@@ -543,11 +568,43 @@ def main():
                       "value": k2 / (time.perf_counter() - t2), "unit": "images/s"}
         wino.SPLIT_BF16 = bool(args.split_bf16)
 
+    sparse_leg = None
+    if world == 1 and not args.no_diagnostics and not args.no_cnn and len(members) == 1 and not args.sparse_bbox and args.split_bf16:
+        # third leg (never `value`): the same step with the sparse bbox tower, on the planted heads and on the adversarial "worst" heads
+        # (every level fills its top-k with candidates all over the map: every block live -- the sparse order of evaluation then only costs)
+        k3 = max(10, min(args.steps, 60))
+        sparse_leg = {"what": "the step with the bbox side of the head evaluated only over the blocks that can reach a candidate (PI:310-331 reads "
+                              "box_delta / box_reg_var nowhere else); detections equal the dense tower's (tests/test_sparse_tower_gpu.py)", "steps": k3, "unit": "images/s"}
+        sparse_state["on"] = True
+        worst = [synthetic.planted_head_outputs(padded, N, seed=77, num_boxes=args.boxes, with_cls_var=spec["cls_var"], with_reg_var=spec["reg_var"], mode="worst", device=dev)]
+        with torch.no_grad():
+            for name, hs in (("planted", heads), ("worst", worst)):
+                sparse_state["heads"] = hs
+                for i in range(2 * n_streams + 4):
+                    step(i)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for i in range(k3):
+                    step(i)
+                torch.cuda.synchronize()
+                sparse_leg["value_" + name] = k3 / (time.perf_counter() - t3)
+            from pod_compare_amd import sparse as _sp
+            from pod_compare_amd.wino import block_table as _bt
+            lv_shapes = [tuple(sh) for sh in heads[0].shapes]
+            for name, hs in (("planted", heads), ("worst", worst)):
+                hps[0].select(hs[0].cls, hs[0].cls_var)
+                lb = _sp.LiveBlocks(hps[0])
+                sparse_leg["live_blocks_" + name] = {"predictors": lb.fraction(_bt(lv_shapes, 1, dev), 0), "subnet_first_conv": lb.fraction(_bt(lv_shapes, 1, dev), 4)}
+                hps[0]._dirty = True
+                hps[0]._clean()
+        del worst
+        sparse_state["on"], sparse_state["heads"] = False, heads
+
     out = {
         "metric": "images/sec (BayesOD+MC-dropout, 1280x720)" if args.config == "cfg3" else "images/sec (%s, 1280x720)" % spec["mode"],
         "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if not args.split_bf16 else "f32 (3x3 convolutions: products from exact 3xbf16 splits of both fp32 operands, fp32 accumulate)",
+        "dtype": "f32" if not args.split_bf16 else "f32 (convolutions: every fp32 product from 2-way f16 splits of the power-of-two-scaled fp32 operands, 3 partial products, fp32 accumulate; closer to fp64 than the fp32 MFMA: profiles/r05_f16_split_numerics.txt)",
         "data": "synthetic (seeded 1280x720 uint8 frames; random-init weights; planted-object head tensors, SURVEY 8d)",
         "config": {"workload": spec["name"], "frame": "1280x720 -> 750x1333 -> padded 768x1344", "anchors_R": R, "mc_runs": N,
                    "classes": params.num_classes, "synthetic_mode": args.synth, "planted_boxes": args.boxes, "conv_net_in_timed_region": not args.no_cnn,
@@ -560,7 +617,7 @@ def main():
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
                    "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices,
                    "ranks_share_one_gpu": bool(share and world > 1),
-                   "conv3x3_kernel": "pod_wino_conv3x3_split (fp32 Winograd; every product from exact 3xbf16 splits on the bf16 matrix cores, 6 partial "
+                   "conv3x3_kernel": "pod_wino_conv3x3_split (fp32 Winograd; every product from 2-way f16 splits of the scaled operands on the f16 matrix cores, 3 partial "
                                      "products, fp32 accumulate; per shape at least as close to fp64 as the fp32-MFMA kernel: tests/test_wino_conv_gpu.py); "
                                      "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
                                      "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
@@ -574,6 +631,9 @@ def main():
     }
     if second is not None:
         out["split_bf16" if second["kernel"].endswith("_split") else "fp32_mfma"] = second
+    if sparse_leg is not None:
+        out["sparse_bbox_tower"] = sparse_leg
+    out["config"]["bbox_tower"] = "sparse (--sparse-bbox)" if args.sparse_bbox else "dense (the reference's evaluation order; the sparse tower's figures: `sparse_bbox_tower`)"
     if rank == 0 and not args.no_diagnostics:
         diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev, R, N, D, mc)
     if rank == 0:

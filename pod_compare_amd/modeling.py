@@ -710,6 +710,44 @@ class ProbabilisticRetinaNetHead(nn.Module):
             return t
         return new
 
+    def forward_cls(self, features: List[torch.Tensor], num_runs: int = 1, mc_dropout: bool = False, skip_unused_last_run: bool = False) -> dict:
+        """First half of the sparse evaluation (`forward`, sparse_bbox): the cls subnet + cls_score (+ cls_var) of all levels and runs.
+        Returns the state `forward_bbox` continues from (the level features as one channels-last buffer among it)."""
+        dropout = mc_dropout and self.dropout_rate > 0.0
+        n = num_runs
+        skip = 1 if (skip_unused_last_run and dropout and n > 1) else 0
+        m = n - skip
+        cls_copies = m * (2 if self.compute_cls_var else 1)
+        box_copies = n + (m if self.compute_bbox_cov else 0)
+        ok = (self.takes_wino_path() and features[0].is_cuda and features[0].dtype == torch.float32 and features[0].shape[0] == 1
+              and features[0].shape[1] == self.cls_subnet[0].in_channels and self._grouped_ok(cls_copies, box_copies))
+        if not ok:
+            raise RuntimeError("the sparse bbox tower needs the split kernels on the GPU (POD_WINO_SPLIT=1, one fp32 image, grouped head)")
+        levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
+        x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
+        tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
+        cj = [(self.cls_score, tc, nc, 0, m, n)] if dropout else [(self.cls_score, tc, 1, 0, 1, 1)]
+        if self.compute_cls_var:
+            cj += [(self.cls_var, tc, nc, m, m, n)] if dropout else [(self.cls_var, tc, 1, 0, 1, 1)]
+        res = self._predict_grouped(cj, levels)
+        if not dropout and n > 1:
+            res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
+        return {"x0": x0, "levels": levels, "n": n, "m": m, "dropout": dropout, "skip": skip, "box_copies": box_copies,
+                "logits": res[0], "logit_vars": res[1] if self.compute_cls_var else None}
+
+    def forward_bbox(self, st: dict, live):
+        """Second half: bbox_subnet + bbox_pred (+ bbox_cov) over the blocks `live` (sparse.LiveBlocks) lists; None = all of them."""
+        x0, levels, n, m, dropout = st["x0"], st["levels"], st["n"], st["m"], st["dropout"]
+        bufs = None if live is None else self.sparse_buffers((torch.cuda.current_stream(x0.device).cuda_stream, tuple(levels), n, dropout, st["skip"]))
+        tb, nb = self._trunk_all_levels(self.bbox_subnet, x0, levels, st["box_copies"], dropout, live=live, bufs=bufs)
+        bj = [(self.bbox_pred, tb, nb, 0, n, n)] if dropout else [(self.bbox_pred, tb, 1, 0, 1, 1)]
+        if self.compute_bbox_cov:
+            bj += [(self.bbox_cov, tb, nb, n, m, n)] if dropout else [(self.bbox_cov, tb, 1, 0, 1, 1)]
+        res = self._predict_grouped(bj, levels, live=live, bufs=bufs)
+        if not dropout and n > 1:
+            res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
+        return res[0], (res[1] if self.compute_bbox_cov else None)
+
     def forward(self, features: List[torch.Tensor], num_runs: int = 1, mc_dropout: bool = False,
                 skip_unused_last_run: bool = False, sparse_bbox=None):
         """features: per-level (1, 256, H, W).  Returns per-level lists of (num_runs, A*C, H, W).
@@ -749,26 +787,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
             x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
             grouped = self._grouped_ok(cls_copies, box_copies)
             if sparse_bbox is not None:
-                if not grouped:
-                    raise RuntimeError("the sparse bbox tower needs the split kernels (POD_WINO_SPLIT=1, grouped head)")
-                tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
-                cj = [(self.cls_score, tc, nc, 0, m, n)] if dropout else [(self.cls_score, tc, 1, 0, 1, 1)]
-                if self.compute_cls_var:
-                    cj += [(self.cls_var, tc, nc, m, m, n)] if dropout else [(self.cls_var, tc, 1, 0, 1, 1)]
-                res = self._predict_grouped(cj, levels)
-                if not dropout and n > 1:
-                    res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
-                logits, logit_vars = res[0], (res[1] if self.compute_cls_var else None)
-                live = sparse_bbox(logits, logit_vars)
-                bufs = self.sparse_buffers((torch.cuda.current_stream(x0.device).cuda_stream, tuple(levels), n, dropout, skip))
-                tb, nb = self._trunk_all_levels(self.bbox_subnet, x0, levels, box_copies, dropout, live=live, bufs=bufs)
-                bj = [(self.bbox_pred, tb, nb, 0, n, n)] if dropout else [(self.bbox_pred, tb, 1, 0, 1, 1)]
-                if self.compute_bbox_cov:
-                    bj += [(self.bbox_cov, tb, nb, n, m, n)] if dropout else [(self.bbox_cov, tb, 1, 0, 1, 1)]
-                res = self._predict_grouped(bj, levels, live=live, bufs=bufs)
-                if not dropout and n > 1:
-                    res = [[t.expand(n, -1, -1, -1).contiguous() for t in ts] for ts in res]
-                return logits, res[0], logit_vars, (res[1] if self.compute_bbox_cov else None)
+                st = self.forward_cls(features, num_runs, mc_dropout, skip_unused_last_run)
+                deltas, delta_covs = self.forward_bbox(st, sparse_bbox(st["logits"], st["logit_vars"]))
+                return st["logits"], deltas, st["logit_vars"], delta_covs
             if grouped:
                 tc, nc, tb, nb = self._trunks_grouped(x0, levels, cls_copies, box_copies, dropout)
             else:
@@ -924,8 +945,22 @@ class ProbabilisticRetinaNet(nn.Module):
             ts = self._fingerprint_tensors = (gen, [t for t in list(self.parameters()) + list(self.buffers()) if t is not self.head._epoch])
         return gen, len(ts[1]), sum(t._version for t in ts[1])
 
-    def _forward_graphed(self, image: torch.Tensor, n: int, dropout: bool, skip: bool) -> HeadOutputs:
+    def _cls_eager(self, image: torch.Tensor, n: int, dropout: bool, skip: bool) -> dict:
+        feats, padded = self._trunk_eager(image)
+        st = self.head.forward_cls(feats, n, mc_dropout=dropout, skip_unused_last_run=skip)
+        st.update(padded=padded, image_hw=tuple(image.shape[-2:]), shapes=[tuple(f.shape[-2:]) for f in feats])
+        return st
+
+    def _bbox_eager(self, st: dict, sparse_bbox) -> HeadOutputs:
+        skipped = bool(st["skip"])
+        mk = lambda delta, reg_var: HeadOutputs(st["logits"], delta, st["logit_vars"], reg_var, self.anchors_for(st["padded"]), st["shapes"], self.num_anchors,
+                                                self.num_classes, st["image_hw"], last_run_valid=not skipped)
+        delta, reg_var = self.head.forward_bbox(st, sparse_bbox(mk(None, None)))
+        return mk(delta, reg_var)
+
+    def _forward_graphed(self, image: torch.Tensor, n: int, dropout: bool, skip: bool, part: str = "all"):
         stream = torch.cuda.current_stream(image.device)
+        run = self._forward_eager if part == "all" else self._cls_eager
         from . import wino
         fp = self._param_fingerprint()
         if fp != self._graphs_fingerprint:
@@ -933,7 +968,7 @@ class ProbabilisticRetinaNet(nn.Module):
             self._fingerprint_tensors = None                   # (module surgery -- fold_frozen_bn -- also changes WHICH tensors there are)
             self._graphs_fingerprint = self._param_fingerprint()
         # (the kernel selection is part of the key: a graph captured with one convolution kernel must not answer for the other)
-        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip, bool(wino.SPLIT_BF16), CL_BACKBONE, WINO_BACKBONE)
+        key = (stream.cuda_stream, tuple(image.shape), image.dtype, n, dropout, skip, bool(wino.SPLIT_BF16), CL_BACKBONE, WINO_BACKBONE, part)
         ent = self._graphs.get(key)
         if ent is None:
             # graphs are for (stream, shape) pairs that come back: the first GRAPH_AFTER_SEEN forwards of a key run eagerly (a data set of
@@ -943,7 +978,7 @@ class ProbabilisticRetinaNet(nn.Module):
                 self._graph_seen.clear()
             self._graph_seen[key] = seen
             if seen <= self.graph_after_seen:
-                return self._forward_eager(image, n, dropout, skip)
+                return run(image, n, dropout, skip)
             static_in = image.clone()
             shared_epoch = self.head._epoch
             # every graph owns its epoch word: replays of two graphs on two streams must not read-modify-write one word (the masks
@@ -955,7 +990,7 @@ class ProbabilisticRetinaNet(nn.Module):
             from . import amax
             try:
                 for _ in range(2):                       # eager: MIOpen's solver search, filter transforms, block tables, anchors
-                    self._forward_eager(static_in, n, dropout, skip)
+                    run(static_in, n, dropout, skip)
                 stream.synchronize()
                 side = torch.cuda.Stream(device=image.device)          # (capture is not allowed on the legacy default stream)
                 side.wait_stream(stream)
@@ -966,7 +1001,7 @@ class ProbabilisticRetinaNet(nn.Module):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):      # capture: every replay starts from zeroed words
                     if dropout:
                         epoch.add_(1)                      # (captured: every replay starts by moving on to the next set of masks)
-                    out = self._forward_eager(static_in, n, dropout, skip)
+                    out = run(static_in, n, dropout, skip)
                 stream.wait_stream(side)
             finally:
                 amax.reset()                               # (eager launches never max into a graph's words)
@@ -1005,8 +1040,13 @@ class ProbabilisticRetinaNet(nn.Module):
         if mc_dropout is None:
             mc_dropout = n > 1
         dropout = bool(mc_dropout) and self.use_dropout
+        graphs = (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
+                  and (not dropout or self.head.takes_wino_path()))
         if sparse_bbox is not None:
-            return self._forward_eager(image, n, dropout, skip_unused_last_run, sparse_bbox)
+            # trunk + cls side (captured into a HIP graph like a whole forward), the caller's candidate selection, then the bbox side over
+            # the live blocks (eager launches: their tables' live lists are made per image)
+            st = self._forward_graphed(image, n, dropout, skip_unused_last_run, part="cls") if graphs else self._cls_eager(image, n, dropout, skip_unused_last_run)
+            return self._bbox_eager(st, sparse_bbox)
         if (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
                 and (not dropout or self.head.takes_wino_path())):
             return self._forward_graphed(image, n, dropout, skip_unused_last_run)
