@@ -20,7 +20,37 @@ import torch.distributed as dist
 
 from .inference_utils import record_width, records_to_json
 
-BDD_CAT_MAP = {i: i + 1 for i in range(7)}   # contiguous id -> dataset id (core/datasets/metadata.py, ids 1..7)
+# core/datasets/metadata.py as DATA: the thing classes of the data sets the reference registers (setup_datasets.py:36-117); dataset ids are
+# 1 .. len(classes) in this order (metadata.py:9-15), contiguous ids 0 .. len - 1.  Lyft re-uses BDD's map (setup_datasets.py:117).
+THING_CLASSES = {"bdd": ["car", "bus", "truck", "person", "rider", "bike", "motor"], "kitti": ["car", "person"]}
+THING_CLASSES["lyft"] = THING_CLASSES["bdd"]
+
+
+def _family(dataset: str) -> str:
+    for fam in THING_CLASSES:
+        if dataset.startswith(fam + "_") or dataset == fam:
+            return fam
+    raise ValueError("Unknown data set {!r}: known families are {} (e.g. bdd_val, kitti_val).".format(dataset, sorted(THING_CLASSES)))
+
+
+def category_mapping(train_dataset: str, test_dataset: str) -> Dict[int, int]:
+    """AN:52-80: model (contiguous, TRAIN data set) class id -> category_id of the TEST data set's annotations.
+    Same classes (BDD -> BDD, BDD -> Lyft): the test set's contiguous -> dataset id map flipped (AN:60-63).  BDD -> KITTI: only the classes
+    KITTI annotates survive, through metadata.BDD_TO_KITTI_CONTIGUOUS_ID (AN:70-73, 78-79); a detection of any other class gets -1 and is
+    dropped by instances_to_json (IU:466-471).  Any other pair: the reference BUILDS a ValueError without raising it (AN:76-77)
+    and then fails on an undefined name; here it is raised.  (COCO / VOC: their 80- / 20-class tables are not carried -- out of BASELINE's
+    scope -- and are reported as such.)"""
+    train, test = _family(train_dataset), _family(test_dataset)
+    test_ids = {i: i + 1 for i in range(len(THING_CLASSES[test]))}               # contiguous -> dataset id of the test set
+    if THING_CLASSES[train] == THING_CLASSES[test]:
+        return test_ids
+    if train == "bdd" and test == "kitti":
+        to_kitti = {THING_CLASSES["bdd"].index(c): THING_CLASSES["kitti"].index(c) for c in THING_CLASSES["kitti"]}    # BDD_TO_KITTI_CONTIGUOUS_ID
+        return {bdd: test_ids[kitti] for bdd, kitti in to_kitti.items()}
+    raise ValueError("Cannot generate category mapping dictionary. Please check if training and inference datasets are compatible.")
+
+
+BDD_CAT_MAP = category_mapping("bdd_train", "bdd_val")   # contiguous id -> dataset id (ids 1..7)
 
 
 def shard_indices(num_images: int, rank: int, world: int) -> List[int]:
@@ -186,6 +216,10 @@ def main(argv=None):
     ap.add_argument("--num-images", type=int, default=8, help="synthetic 1280x720 frames (ignored with --coco-json)")
     ap.add_argument("--coco-json", default="", help="COCO-format json whose `images` are run (the reference's test data loader, AN:83-84)")
     ap.add_argument("--image-root", default="", help="directory of the files named in --coco-json")
+    ap.add_argument("--train-dataset", default="bdd_train", help="cfg.DATASETS.TRAIN[0] of the model (AN:53): with --test-dataset it fixes the category map (AN:52-80)")
+    ap.add_argument("--test-dataset", default="bdd_val", help="the data set the detections are written for (AN:55, args.test_dataset)")
+    ap.add_argument("--sparse-bbox", action="store_true", help="evaluate the bbox side of the head only over the blocks that can reach a candidate "
+                                                                "(pod_compare_amd/sparse.py; same detections, single-model modes)")
     ap.add_argument("--random-seed", type=int, default=0)
     ap.add_argument("--output", default="coco_instances_results.json")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of a forward from Python instead of replaying a HIP graph per (stream, frame shape)")
@@ -238,6 +272,7 @@ def main(argv=None):
     predictor = build_predictor(cfg) if not args.ensemble_per_gpu else None
     if predictor is not None:
         predictor.return_device = True      # no per-image host sync: records and counts stay in HBM until the gather
+        predictor.sparse_bbox_tower = predictor.sparse_bbox_tower or bool(getattr(args, "sparse_bbox", False))
         for m in [predictor.model] + list(predictor.model_list):
             if isinstance(m, modeling.ProbabilisticRetinaNet):
                 m.enable_graphs(not getattr(args, "no_graphs", False))      # one host call per forward instead of ~200 launches
@@ -302,7 +337,7 @@ def main(argv=None):
         ids = [dataset.image_id(i) for i in ids]
     if rank == 0:
         with open(args.output, "w") as fp:
-            json.dump(results_json(ids, cnt, rec, K, BDD_CAT_MAP), fp, indent=4, separators=(",", ": "))
+            json.dump(results_json(ids, cnt, rec, K, category_mapping(args.train_dataset, args.test_dataset)), fp, indent=4, separators=(",", ": "))
         if args.binary_output:
             from .inference_utils import write_binary_results
             write_binary_results(args.binary_output, ids, cnt, rec, K)

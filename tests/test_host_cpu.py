@@ -340,3 +340,27 @@ def test_wino_block_table_canvases():
     assert big.shape[0] == 1624
     got = decode(big)
     assert len(got) == big.pod_pixels and len({p for _, p in got}) == big.pod_pixels and all(a == b for a, b in got)
+
+
+def test_category_mapping_follows_the_reference_tables():
+    """AN:52-80 + core/datasets/metadata.py: BDD -> BDD / Lyft is the identity + 1, BDD -> KITTI keeps car and person only, an
+    incompatible pair raises (the reference builds the ValueError and forgets to raise it)."""
+    import pytest
+    from pod_compare_amd.apply_net import category_mapping
+    from pod_compare_amd.inference_utils import records_to_json
+    assert category_mapping("bdd_train", "bdd_val") == {i: i + 1 for i in range(7)}
+    assert category_mapping("bdd_train", "lyft_val") == {i: i + 1 for i in range(7)}
+    assert category_mapping("bdd_train", "kitti_val") == {0: 1, 3: 2}           # car -> 1, person -> 2; bus / truck / rider / bike / motor: dropped
+    assert category_mapping("kitti_train", "kitti_val") == {0: 1, 1: 2}
+    with pytest.raises(ValueError):
+        category_mapping("kitti_train", "bdd_val")
+    with pytest.raises(ValueError):
+        category_mapping("coco_2017_train", "voc_2012_val")
+    # a KITTI run drops the classes KITTI does not annotate (IU:466-471: category -1 is skipped)
+    import torch
+    rec = torch.zeros(3, 4 + 1 + 1 + 7 + 16)
+    rec[:, 2:4] = 10.0
+    rec[:, 4] = torch.tensor([0.9, 0.8, 0.7])
+    rec[:, 5] = torch.tensor([0.0, 1.0, 3.0])                                   # car, bus, person
+    out = records_to_json(rec, 3, 5, 7, category_mapping("bdd_train", "kitti_val"))
+    assert [d["category_id"] for d in out] == [1, 2]
