@@ -492,14 +492,16 @@ int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, po
  * Ws = pod_conv1x1_filter_split(weight (Cout, Cin) fp32): pod_conv1x1_filter_split_bytes(Cout, Cin) bytes (2 * Cout * Cin f16 terms + a 16-byte trailer: the
  * weight's abs-max), 16-byte aligned.
  * n_splits > 1 (small maps): the input channels cut over workgroup sets, partial sums in `partials` (n_splits * H_out * W_out * Cout
- * floats), added in a fixed order with bias / residual / ReLU by a second launch. */
+ * floats), added in a fixed order with bias / residual / ReLU by a second launch.  waves (round 5): 1, 2 or 4 wavefronts of ONE workgroup
+ * share a tile's K range and add their accumulators in LDS in a fixed order -- split-K without the partial sums' trip through HBM or a
+ * second launch, to the bit the result of the same cut over workgroup sets; 0: chosen by the library (what the model uses). */
 int64_t pod_conv1x1_filter_split_bytes(int32_t Cout, int32_t Cin);
 int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
 int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y,
                         int64_t n, int32_t Cout, int32_t relu, float* out_amax, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
 int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
                       int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
-                      const float* in_amax, float* out_amax, pod_stream_t stream);
+                      int32_t waves, const float* in_amax, float* out_amax, pod_stream_t stream);
 
 /* ---- one image, one call --------------------------------------------------------------------
  * Replaces: everything `RetinaNetProbabilisticPredictor.__call__` does after the conv net

@@ -39,17 +39,27 @@ class Conv1x1:
         tiles = ((p_out + 63) // 64) * (self.K // 64)
         nks = self.C // 16
         out_mb = p_out * self.K * 4 / 1e6
-        best, best_t = 1, nks * 0.68
+        step = 0.38                                              # us per k-step of a lone wavefront with the 2-way f16 split (round 5)
+        best, best_t = 1, (nks // self.auto_waves(tiles, nks)) * step
         for s in (2, 4, 8, 16):
             if nks % s or nks // s < 4 or tiles * s > simds:
                 continue
-            t = (nks // s) * 0.68 + 3.0 + (s + 1) * out_mb / 4.0
+            t = (nks // s // self.auto_waves(tiles * s, nks // s)) * step + 3.0 + (s + 1) * out_mb / 4.0
             if t < best_t:
                 best, best_t = s, t
         return best
 
+    @staticmethod
+    def auto_waves(tiles: int, per_split: int) -> int:
+        """The library's choice of wavefronts per workgroup (pod_conv1x1_split, waves = 0): split-K inside the workgroup, accumulators added in
+        LDS -- as many as keep the launch within one wavefront per SIMD and leave every wavefront at least 16 k-steps, in whole pairs."""
+        waves = 1
+        while waves < 4 and per_split % (waves * 4) == 0 and per_split // (waves * 2) >= 16 and tiles * waves * 2 <= 1024:
+            waves *= 2
+        return waves
+
     def __call__(self, x: torch.Tensor, h: int, w: int, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                 n_splits: Optional[int] = None) -> torch.Tensor:
+                 n_splits: Optional[int] = None, waves: int = 0) -> torch.Tensor:
         """x: (h * w, Cin) channels-last of ONE image -> (h_out * w_out, Cout) channels-last = act(conv(x) + bias [+ residual])."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
         ho, wo = self.out_hw(h, w)
@@ -59,7 +69,7 @@ class Conv1x1:
         s = self.splits_for(ho * wo) if n_splits is None else int(n_splits)
         partials = torch.empty((s, ho * wo, self.K), dtype=torch.float32, device=x.device) if s > 1 else None
         hip.check(hip.load().pod_conv1x1_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), hip.ptr(residual), ho, wo, h, w, self.stride,
-                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), amax.of(x).data_ptr(), amax.produced(y).data_ptr(),
+                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), int(waves), amax.of(x).data_ptr(), amax.produced(y).data_ptr(),
                                                hip.current_stream()), "pod_conv1x1_split")
         return y
 

@@ -315,16 +315,25 @@ __device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_
 // + 3, key(p) = (p >> 1) & 7 (the swizzle is applied to the SOURCE address, the LDS write is lane-linear): the 16 lanes of a
 // ds_read_b128 group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md, LDS) then hit 16 different bank quads.
 // One wavefront per workgroup still: no barrier anywhere, the LDS is a transposing buffer of this wavefront alone (two pairs, 16 KB).
-// Arithmetic, channel order and accumulation order are those of k_conv1x1_split: the results are bit-identical.
-template <int NCB>
-__global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
-    __shared__ __attribute__((aligned(16))) float lds_a[2][64 * 32];
+// Arithmetic, channel order and accumulation order are those of k_conv1x1_split: the results are bit-identical (WAVES = 1).
+//
+// WAVES > 1 (round 5): SPLIT-K INSIDE THE WORKGROUP.  From res3 down a launch is 60 .. 500 tiles for 1024 SIMDs and every lone wavefront
+// walks its whole K chain at 0.3-0.4 us per 16 channels (profiles/r05_conv_classes.md: 0.06-0.25 of the classes' own bounds); cutting K
+// over workgroup SETS (grid.y) costs the partial sums' trip through HBM and a reduce launch.  Here the tile's K range is cut over the
+// WAVES wavefronts of one workgroup -- each with its own LDS transposing buffer and filter ring, no barrier in the loop -- and their
+// accumulators meet in LDS once at the end, added in a FIXED order (wavefront 0 + 1 + 2 + 3: the result does not depend on scheduling);
+// wavefront 0 runs the epilogue.  The k-steps a wavefront accumulates stay in order, so WAVES = w equals a grid.y split of w to the bit.
+template <int NCB, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES > 1 ? 1 : 2) k_conv1x1_split_lds(const C1Params P) {
+    __shared__ __attribute__((aligned(16))) float lds_all[WAVES][2][64 * 32];
+    const int wave = threadIdx.x >> 6;
+    float (*const lds_a)[64 * 32] = lds_all[wave];
     const int lane = threadIdx.x & 63, i32 = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, wi = (int)(blockIdx.x >> 3);
     const int tp = (wi / P.n_ct) * 8 + xcd, tc = wi % P.n_ct;
     if (tp >= P.n_pt) return;
     C1_STAMP(0);
-    const int nks_all = P.Cin >> 4, ks0 = (int)blockIdx.y * P.ks_per_split, nks = P.ks_per_split;
+    const int nks_all = P.Cin >> 4, nks = P.ks_per_split / WAVES, ks0 = (int)blockIdx.y * P.ks_per_split + wave * nks;
     // staging: instruction j loads pixels 8 j .. 8 j + 7 of the tile, this lane chunk position lane & 7 of pixel 8 j + (lane >> 3)
     int32_t soff[8];
 #pragma unroll
@@ -437,6 +446,31 @@ __global__ void __launch_bounds__(64, 2) k_conv1x1_split_lds(const C1Params P) {
     for (int j0 = 0; j0 < nks; j0 += 6) trip(trip, c1_ic<0>{}, j0);
     C1_STAMP(2);
 
+    if constexpr (WAVES > 1) {
+        // the other wavefronts park their accumulators (lane-contiguous: [register][lane]) in their own transposing buffer -- nobody else
+        // ever touched it --, wavefront 0 adds them in order
+        if (wave > 0) {
+            float* o = &lds_a[0][0];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[((cb * 2 + pb) * 16 + r) * 64 + lane] = acc[cb][pb][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const float* o = &lds_all[w][0][0];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[cb][pb][r] += o[((cb * 2 + pb) * 16 + r) * 64 + lane];
+        }
+    }
     c1_epilogue(P, &lds_a[0][0], acc, tp, tc, lane, i32, h, sx);
 #ifdef POD_C1_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -485,8 +519,8 @@ extern "C" int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t C
 }
 
 extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out, int32_t H_in,
-                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, const float* in_amax,
-                                 float* out_amax, pod_stream_t stream) {
+                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, int32_t waves,
+                                 const float* in_amax, float* out_amax, pod_stream_t stream) {
     if (!x || !y || !Ws || !in_amax || x == y || H_out < 1 || W_out < 1 || (stride != 1 && stride != 2) || Cin < 16 || (Cin & 15) != 0 || Cout < 64 || (Cout & 63) != 0)
         return POD_E_INVALID;
     if (H_in < (H_out - 1) * stride + 1 || W_in < (W_out - 1) * stride + 1 || (stride == 1 && (H_in != H_out || W_in != W_out))) return POD_E_INVALID;
@@ -494,6 +528,19 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     if (P_out * (Cout > Cin ? Cout : Cin) >= ((int64_t)1 << 31) || (int64_t)H_in * W_in * Cin >= ((int64_t)1 << 31)) return POD_E_INVALID;
     const int nks = Cin / 16;
     if (n_splits < 1 || n_splits > 16 || nks % n_splits != 0 || (n_splits > 1 && !partials)) return POD_E_INVALID;
+    // waves: wavefronts of a workgroup sharing a tile's K range (1, 2 or 4; each takes whole PAIRS of k-steps); 0 = choose here: as many as
+    // keep the launch within ONE wavefront per SIMD and leave every wavefront at least 16 k-steps (measured per class, profiles/r05_conv_classes.md:
+    // shorter chains or fuller launches lose more to the LDS meeting and the halved occupancy than the shorter chain wins)
+    if (waves < 0 || waves > 4 || waves == 3) return POD_E_INVALID;
+    {
+        const int per_split = nks / n_splits;
+        if (waves == 0) {
+            const int64_t tiles = ((P_out + 63) / 64) * (Cout / 64) * n_splits;
+            waves = 1;
+            while (waves < 4 && per_split % (waves * 4) == 0 && per_split / (waves * 2) >= 16 && tiles * waves * 2 <= 1024) waves *= 2;
+        }
+        if (waves > 1 && (per_split % (2 * waves) != 0)) return POD_E_INVALID;
+    }
     if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(Ws) | reinterpret_cast<uintptr_t>(bias) |
           reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(partials)) & 15u) != 0 ||
         ((reinterpret_cast<uintptr_t>(in_amax) | reinterpret_cast<uintptr_t>(out_amax)) & 3u) != 0)
@@ -513,7 +560,12 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
 #define POD_C1_RING 3
 #endif
 #ifndef POD_C1_DIRECT       // (experiment builds: the direct-fragment kernel everywhere, tools/conv1x1_ab.py, tools/conv1x1_elim.py)
-    if ((P.ks_per_split & 1) == 0) hipLaunchKernelGGL(pod::k_conv1x1_split_lds<2>, dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
+    if ((P.ks_per_split & 1) == 0 && waves == 4)
+        hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 4>), dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
+    else if ((P.ks_per_split & 1) == 0 && waves == 2)
+        hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 2>), dim3((unsigned)grid, (unsigned)n_splits), dim3(128), 0, (hipStream_t)stream, P);
+    else if ((P.ks_per_split & 1) == 0)
+        hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 1>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
     else
 #endif
         hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);

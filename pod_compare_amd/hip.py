@@ -139,7 +139,7 @@ def load() -> ctypes.CDLL:
     lib.pod_stem7x7_split.argtypes = [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32, c_int32, c_int32, P, P, P]
     lib.pod_maxpool3x3s2_cl.argtypes = [P, P, c_int32, c_int32, c_int32, P]
     lib.pod_conv1x1_filter_split.argtypes = [P, P, c_int32, c_int32, P]
-    lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, P, P, P]
+    lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, c_int32, P, P, P]
     lib.pod_conv1x1_filter_split_bytes.argtypes = [c_int32, c_int32]
     lib.pod_conv1x1_filter_split_bytes.restype = c_int64
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]

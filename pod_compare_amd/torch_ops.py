@@ -229,7 +229,7 @@ def _conv1x1_split(x, Ws, bias, residual, h, w, stride, cout, relu=False, n_spli
     partials = torch.empty((n_splits, ho * wo, cout), dtype=torch.float32, device=x.device) if n_splits > 1 else None
     with torch.cuda.device(x.device):
         hip.check(hip.load().pod_conv1x1_split(hip.ptr(x), hip.ptr(y), hip.ptr(Ws), hip.ptr(bias), hip.ptr(residual), ho, wo, int(h), int(w), int(stride), cin, int(cout),
-                                               1 if relu else 0, int(n_splits), hip.ptr(partials), hip.ptr(_absmax_word(x)), None, hip.current_stream()), "pod_conv1x1_split")
+                                               1 if relu else 0, int(n_splits), hip.ptr(partials), 0, hip.ptr(_absmax_word(x)), None, hip.current_stream()), "pod_conv1x1_split")
     return y
 
 

@@ -71,8 +71,8 @@ def test_invalid_arguments_are_rejected():
     ws = torch.zeros(2 * 64 * 32 + 8, dtype=torch.int16, device="cuda")
     s = hip.current_stream()
     am = torch.zeros(2 * 512, device="cuda")                       # two abs-max records
-    ok = lambda *a: lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, *a, None, am.data_ptr(), am[512:].data_ptr(), s)
-    assert lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, 8, 8, 8, 8, 1, 32, 64, 0, 1, None, None, None, s) == -1     # no in_amax word
+    ok = lambda *a: lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, *a, None, 0, am.data_ptr(), am[512:].data_ptr(), s)
+    assert lib.pod_conv1x1_split(x.data_ptr(), y.data_ptr(), ws.data_ptr(), None, None, 8, 8, 8, 8, 1, 32, 64, 0, 1, None, 0, None, None, s) == -1     # no in_amax word
     assert lib.pod_conv1x1_filter_split_bytes(64, 32) == ws.numel() * 2
     assert ok(8, 8, 8, 8, 1, 32, 64, 0, 1) == 0
     assert ok(8, 8, 8, 8, 1, 24, 64, 0, 1) == -1        # Cin % 16
@@ -110,3 +110,32 @@ def test_channels_last_backbone_equals_the_nchw_backbone():
             assert a.shape == b.shape
             assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), (hw, tuple(a.shape))
 
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(1024, 256, 48, 84, 1), (2048, 512, 24, 42, 1), (512, 128, 96, 168, 1), (512, 1024, 96, 168, 2), (256, 64, 20, 30, 1)])
+def test_split_k_inside_the_workgroup_equals_the_cut_over_workgroup_sets_to_the_bit(cin, cout, h, w, stride):
+    """waves = 2 / 4 (round 5): the wavefronts of one workgroup share a tile's K range and add their accumulators in LDS in a fixed order --
+    the k-steps of a wavefront stay in order, so the result IS that of the same cut over workgroup sets (grid.y partial sums + reduce
+    launch), bit for bit, without the partial sums' trip through HBM; reproducible; the library's own choice (waves = 0) is one of them."""
+    wt, b, x = make(cin, cout, h, w, 11)
+    conv = Conv1x1(wt, b, stride)
+    ho, wo = conv.out_hw(h, w)
+    xcl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+    res = torch.randn(ho * wo, cout, device="cuda")
+    outs = {}
+    for wv in (1, 2, 4):
+        if (cin // 16) % (2 * wv):
+            continue
+        a = conv(xcl, h, w, relu=True, residual=res, n_splits=1, waves=wv)
+        assert torch.equal(a, conv(xcl, h, w, relu=True, residual=res, n_splits=1, waves=wv))
+        assert torch.equal(a, conv(xcl, h, w, relu=True, residual=res, n_splits=wv, waves=1)), wv
+        outs[wv] = a
+    auto = conv(xcl, h, w, relu=True, residual=res, n_splits=1)
+    assert any(torch.equal(auto, o) for o in outs.values())
+    assert float((outs[1] - outs[max(outs)]).abs().max()) <= 4e-6 * max(1.0, float(outs[1].abs().max()))
+    lib = hip.load()
+    am = torch.full((512,), 8.0, device="cuda")
+    y = torch.empty(ho * wo, cout, device="cuda")
+    bad = lambda wv: lib.pod_conv1x1_split(xcl.data_ptr(), y.data_ptr(), conv.Ws.data_ptr(), None, None, ho, wo, h, w, stride, cin, cout, 0, 1, None, wv, am.data_ptr(), None,
+                                          hip.current_stream())
+    assert bad(3) == -1 and bad(5) == -1 and bad(-1) == -1
