@@ -951,6 +951,29 @@ class ProbabilisticRetinaNet(nn.Module):
         st.update(padded=padded, image_hw=tuple(image.shape[-2:]), shapes=[tuple(f.shape[-2:]) for f in feats])
         return st
 
+    @torch.no_grad()
+    def cls_part(self, image: torch.Tensor, num_mc_dropout_runs: int = -1, skip_unused_last_run: bool = False, mc_dropout: Optional[bool] = None) -> dict:
+        """First part of a forward with the sparse bbox tower: trunk + the cls side of the head (captured into a HIP graph like a whole forward
+        when graphs are enabled).  Returns the state `bbox_part` continues from; state["partial"] is the HeadOutputs with cls / cls_var set."""
+        n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
+        if mc_dropout is None:
+            mc_dropout = n > 1
+        dropout = bool(mc_dropout) and self.use_dropout
+        graphs = (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
+                  and (not dropout or self.head.takes_wino_path()))
+        st = self._forward_graphed(image, n, dropout, skip_unused_last_run, part="cls") if graphs else self._cls_eager(image, n, dropout, skip_unused_last_run)
+        return st
+
+    def partial_outputs(self, st: dict, delta=None, reg_var=None) -> HeadOutputs:
+        return HeadOutputs(st["logits"], delta, st["logit_vars"], reg_var, self.anchors_for(st["padded"]), st["shapes"], self.num_anchors,
+                           self.num_classes, st["image_hw"], last_run_valid=not bool(st["skip"]))
+
+    @torch.no_grad()
+    def bbox_part(self, st: dict, live) -> HeadOutputs:
+        """Second part: the bbox side over the blocks `live` (sparse.LiveBlocks, made from the candidates the caller selected) lists."""
+        delta, reg_var = self.head.forward_bbox(st, live)
+        return self.partial_outputs(st, delta, reg_var)
+
     def _bbox_eager(self, st: dict, sparse_bbox) -> HeadOutputs:
         skipped = bool(st["skip"])
         mk = lambda delta, reg_var: HeadOutputs(st["logits"], delta, st["logit_vars"], reg_var, self.anchors_for(st["padded"]), st["shapes"], self.num_anchors,
@@ -1043,10 +1066,7 @@ class ProbabilisticRetinaNet(nn.Module):
         graphs = (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
                   and (not dropout or self.head.takes_wino_path()))
         if sparse_bbox is not None:
-            # trunk + cls side (captured into a HIP graph like a whole forward), the caller's candidate selection, then the bbox side over
-            # the live blocks (eager launches: their tables' live lists are made per image)
-            st = self._forward_graphed(image, n, dropout, skip_unused_last_run, part="cls") if graphs else self._cls_eager(image, n, dropout, skip_unused_last_run)
-            return self._bbox_eager(st, sparse_bbox)
+            return self._bbox_eager(self.cls_part(image, num_mc_dropout_runs, skip_unused_last_run, mc_dropout), sparse_bbox)
         if (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
                 and (not dropout or self.head.takes_wino_path())):
             return self._forward_graphed(image, n, dropout, skip_unused_last_run)

@@ -249,6 +249,24 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
         self.last_detections = det
         return det if self.return_device else detections_to_instances(det)
 
+    def _run_sparse_ensemble(self, input_im, models) -> Instances:
+        """PI:495-505 (pre-NMS ensembles) with the sparse bbox tower: every member's trunk + cls side first (PI:498-500's forwards, cut in two),
+        the candidates selected from the members' merged class outputs, then every member's bbox side over the SAME live blocks."""
+        from . import sparse
+        image = input_im[0]["image"]
+        sts = [m.cls_part(image) for m in models]
+        first = models[0]
+        cov_dims = first.bbox_cov_dims if first.compute_bbox_cov else 0
+        partial = stack_members([m.partial_outputs(st) for m, st in zip(models, sts)])
+        hp = self.last_path = self._path_for(partial, cov_dims=cov_dims)
+        hp.select(partial.cls, partial.cls_var, draw_id=self._draw_id(input_im))
+        live = sparse.LiveBlocks(hp)
+        ho = stack_members([m.bbox_part(st, live) for m, st in zip(models, sts)])
+        image_size, out = self._sizes(input_im, ho)
+        det = hp.finish("standard_nms", ho.cls, ho.delta, ho.cls_var, ho.reg_var, image_size, out)
+        self.last_detections = det
+        return det if self.return_device else detections_to_instances(det)
+
     def _run_post_nms(self, input_im, members: List[HeadOutputs]) -> Instances:
         """Per-member standard NMS, then general_black_box_ensembles_post_processing (IU:165-289)."""
         hp = self._path_for(members[0])
@@ -301,6 +319,9 @@ class RetinaNetProbabilisticPredictor(ProbabilisticPredictor):
 
     def post_processing_ensembles(self, input_im, model_dict):
         if self.cfg.PROBABILISTIC_INFERENCE.ENSEMBLES.BOX_MERGE_MODE == "pre_nms":             # PI:495-505
+            if (self.sparse_bbox_tower and self.eps_fn is None and all(isinstance(m, modeling.ProbabilisticRetinaNet) and m.head.takes_wino_path()
+                                                                        and input_is_cuda(m) for m in model_dict)):
+                return self._run_sparse_ensemble(input_im, model_dict)
             members = [m(input_im[0]["image"]) for m in model_dict]
             return self._run("standard_nms", input_im, stack_members(members))
         return self._run_post_nms(input_im, [m(input_im[0]["image"]) for m in model_dict])     # PI:506-534

@@ -146,3 +146,36 @@ def test_predictor_switch_gives_the_same_instances():
     assert torch.equal(a.pred_classes, b.pred_classes)
     assert float((a.pred_boxes.tensor - b.pred_boxes.tensor).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes.tensor.abs().max()))
     assert float((a.pred_boxes_covariance - b.pred_boxes_covariance).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes_covariance.abs().max()))
+
+
+def test_ensemble_members_share_one_set_of_live_blocks():
+    """BASELINE configs[4] in process (PI:495-505): every member's cls side first, ONE candidate selection on the merged class outputs, every
+    member's bbox side over the same live blocks -- the same Instances as the dense members."""
+    import os
+    from pod_compare_amd import config
+    from pod_compare_amd.probabilistic_inference import build_predictor
+    root = os.path.join(os.path.dirname(os.path.abspath(config.__file__)), "configs")
+    cfg = config.setup_config(os.path.join(root, "BDD-Detection", "retinanet", "retinanet_R_50_FPN_1x_reg_cls_var.yaml"),
+                              os.path.join(root, "Inference", "ensembles_pre_nms.yaml"))
+    cfg.MODEL.DEVICE = "cuda"
+    members = []
+    for seed in (0, 1000, 2000):
+        torch.manual_seed(seed)
+        m = modeling.ProbabilisticRetinaNet(cls_var_loss="loss_attenuation", cls_var_num_samples=10, bbox_cov_loss="negative_log_likelihood").cuda().eval()
+        modeling.fold_frozen_bn(m)
+        with torch.no_grad():
+            m.head.cls_score.weight.mul_(40.0)
+            m.head.cls_score.bias.fill_(-2.5)
+        members.append(m)
+    frame = torch.randint(0, 256, (3, 200, 300), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    inp = [{"image": frame, "height": 200, "width": 300, "image_id": 3}]
+    outs = []
+    for on in (False, True):
+        p = build_predictor(cfg, model=members[0], model_list=members)
+        p.sparse_bbox_tower = on
+        outs.append(p(inp))
+    a, b = outs
+    assert len(a) == len(b) and len(a) > 0
+    assert torch.equal(a.pred_classes, b.pred_classes)
+    assert float((a.pred_boxes.tensor - b.pred_boxes.tensor).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes.tensor.abs().max()))
+    assert float((a.pred_boxes_covariance - b.pred_boxes_covariance).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes_covariance.abs().max()))
