@@ -629,70 +629,82 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         const bool col_ok = n < gcols && gx < W;
         int m, gy = cell(y0 + odd, Hv, rHv, m) - 2;                                   // canvas row y0 + 2 it + odd: grid row m, image row gy (H: the separator)
         const float* rbase = lds + (ox >> 2) * TS + (ox & 3) * 64 + k8 + (odd ? ZA : 0);      // Z[a][tile][ox & 3][k8] of row a = odd
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            gy += 2;
-            if (gy >= Hv) {
-                gy -= Hv;
-                ++m;
-            }
-            const int img = m * gcols + n;
-            if (!col_ok || gy >= H || img >= n_img) continue;
-            const float* r = rbase + it * 4 * TS;                                     // tile (it, ox >> 2)
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r), a1 = *reinterpret_cast<const f32x4*>(r + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(r + ZA), b1 = *reinterpret_cast<const f32x4*>(r + ZA + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(r + 2 * ZA), c1 = *reinterpret_cast<const f32x4*>(r + 2 * ZA + 4);
-            f32x4 v0 = __builtin_elementwise_fma(odd ? (a0 - b0) - c0 : (a0 + b0) + c0, inv, bias0);
-            f32x4 v1 = __builtin_elementwise_fma(odd ? (a1 - b1) - c1 : (a1 + b1) + c1, inv, bias1);
-            if (P.relu) {
-                v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
-                v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
-            }
-            int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy * W + gx) * P.out_stride + kg;      // a multiple of 8
-            if (set_out_amax) {                                      // (a masked value is 0 or v * scale: v * scale bounds both, whatever the masks)
-                const f32x4 a0v = __builtin_elementwise_abs(v0), a1v = __builtin_elementwise_abs(v1);
-                const float mx = fmaxf(fmaxf(fmaxf(a0v.x, a0v.y), fmaxf(a0v.z, a0v.w)), fmaxf(fmaxf(a1v.x, a1v.y), fmaxf(a1v.z, a1v.w)));
-                lmax = fmaxf(lmax, P.thresh ? mx * P.scale : mx);
-            }
-            if (set_replicas > 0) {                                  // (0: an ordinary launch; 1: one "replica" under the replicas' mask)
-                // The first conv of an MC-dropout subnet: its output is the same for every run, so the store pass writes the runs'
-                // masked replicas itself (replica r = image r of the output canvas) -- the separate expand pass read this tensor back
-                // and wrote them in a launch of its own.  Mask of replica r = pod_expand_dropout's: counter word 2, 16 bits per element.
-                for (int rep = 0; rep < set_replicas; ++rep, e += (int64_t)HWi * P.out_stride) {
-                    f32x4 w0 = v0, w1 = v1;
-                    if (P.thresh) {
-                        const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
-                        const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
-                                                       (uint32_t)(drop_key >> 32));
-                        w0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
-                        w0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
-                        w0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
-                        w0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
-                        w1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
-                        w1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
-                        w1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
-                        w1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
-                    }
-                    *reinterpret_cast<f32x4*>(out_base + e) = w0;
-                    *reinterpret_cast<f32x4*>(out_base + e + 4) = w1;
+        // Rows in BATCHES of four: the 24 LDS reads of a batch are issued together (one round trip, not four behind four branches), then
+        // the four rows' arithmetic, Philox calls and stores run as independent chains (round 5: 12.6 k -> cycles of the workgroup's 81 k)
+#pragma unroll 1
+        for (int g = 0; g < 2; ++g) {
+            f32x4 z[4][6];
+            int gyi[4], imgi[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                gy += 2;
+                if (gy >= Hv) {
+                    gy -= Hv;
+                    ++m;
                 }
-                continue;
+                gyi[it] = gy;
+                imgi[it] = m * gcols + n;
+                const float* r = rbase + (4 * g + it) * 4 * TS;                          // tile (4 g + it, ox >> 2)
+                z[it][0] = *reinterpret_cast<const f32x4*>(r); z[it][1] = *reinterpret_cast<const f32x4*>(r + 4);
+                z[it][2] = *reinterpret_cast<const f32x4*>(r + ZA); z[it][3] = *reinterpret_cast<const f32x4*>(r + ZA + 4);
+                z[it][4] = *reinterpret_cast<const f32x4*>(r + 2 * ZA); z[it][5] = *reinterpret_cast<const f32x4*>(r + 2 * ZA + 4);
             }
-            if (P.thresh && !(POD_WINO_ELIM & 64)) {
-                const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
-                const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
-                                               (uint32_t)(drop_key >> 32));
-                v0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
-                v0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
-                v0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
-                v0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
-                v1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
-                v1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
-                v1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
-                v1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gy_ = gyi[it], img = imgi[it];
+                if (!col_ok || gy_ >= H || img >= n_img) continue;
+                f32x4 v0 = __builtin_elementwise_fma(odd ? (z[it][0] - z[it][2]) - z[it][4] : (z[it][0] + z[it][2]) + z[it][4], inv, bias0);
+                f32x4 v1 = __builtin_elementwise_fma(odd ? (z[it][1] - z[it][3]) - z[it][5] : (z[it][1] + z[it][3]) + z[it][5], inv, bias1);
+                if (P.relu) {
+                    v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                    v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                }
+                int64_t e = (out_px + (int64_t)img * HWi + (int64_t)gy_ * W + gx) * P.out_stride + kg;      // a multiple of 8
+                if (set_out_amax) {                                      // (a masked value is 0 or v * scale: v * scale bounds both, whatever the masks)
+                    const f32x4 a0v = __builtin_elementwise_abs(v0), a1v = __builtin_elementwise_abs(v1);
+                    const float mx = fmaxf(fmaxf(fmaxf(a0v.x, a0v.y), fmaxf(a0v.z, a0v.w)), fmaxf(fmaxf(a1v.x, a1v.y), fmaxf(a1v.z, a1v.w)));
+                    lmax = fmaxf(lmax, P.thresh ? mx * P.scale : mx);
+                }
+                if (set_replicas > 0) {                                  // (0: an ordinary launch; 1: one "replica" under the replicas' mask)
+                    // The first conv of an MC-dropout subnet: its output is the same for every run, so the store pass writes the runs'
+                    // masked replicas itself (replica r = image r of the output canvas) -- the separate expand pass read this tensor back
+                    // and wrote them in a launch of its own.  Mask of replica r = pod_expand_dropout's: counter word 2, 16 bits per element.
+                    for (int rep = 0; rep < set_replicas; ++rep, e += (int64_t)HWi * P.out_stride) {
+                        f32x4 w0 = v0, w1 = v1;
+                        if (P.thresh) {
+                            const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
+                            const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
+                                                           (uint32_t)(drop_key >> 32));
+                            w0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
+                            w0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
+                            w0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
+                            w0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
+                            w1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
+                            w1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
+                            w1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
+                            w1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(out_base + e) = w0;
+                        *reinterpret_cast<f32x4*>(out_base + e + 4) = w1;
+                    }
+                    continue;
+                }
+                if (P.thresh && !(POD_WINO_ELIM & 64)) {
+                    const uint64_t ctr = set_offset + (uint64_t)(e >> 3);
+                    const u32x4 r4 = philox4x32_10(u32x4{(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, STREAM_DROPOUT_CONV}, (uint32_t)drop_key,
+                                                   (uint32_t)(drop_key >> 32));
+                    v0.x = (r4.x & 0xFFFFu) >= P.thresh ? v0.x * P.scale : 0.f;
+                    v0.y = (r4.x >> 16) >= P.thresh ? v0.y * P.scale : 0.f;
+                    v0.z = (r4.y & 0xFFFFu) >= P.thresh ? v0.z * P.scale : 0.f;
+                    v0.w = (r4.y >> 16) >= P.thresh ? v0.w * P.scale : 0.f;
+                    v1.x = (r4.z & 0xFFFFu) >= P.thresh ? v1.x * P.scale : 0.f;
+                    v1.y = (r4.z >> 16) >= P.thresh ? v1.y * P.scale : 0.f;
+                    v1.z = (r4.w & 0xFFFFu) >= P.thresh ? v1.z * P.scale : 0.f;
+                    v1.w = (r4.w >> 16) >= P.thresh ? v1.w * P.scale : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out_base + e) = v0;
+                *reinterpret_cast<f32x4*>(out_base + e + 4) = v1;
             }
-            *reinterpret_cast<f32x4*>(out_base + e) = v0;
-            *reinterpret_cast<f32x4*>(out_base + e + 4) = v1;
         }
     }
     if (set_out_amax) wino_publish_amax_block(set_out_amax, lmax);          // (set: uniform over the workgroup)
