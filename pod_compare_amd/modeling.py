@@ -555,12 +555,13 @@ class ProbabilisticRetinaNetHead(nn.Module):
         t1 = block_table(levels, 1, x0.device)
         off1 = level_pixel_offsets(levels, 1)
         first = self._wino(convs[0])
-        lv = (lambda table, layer: None) if live is None else (lambda table, layer: live(table, reach_of_subnet_layer(layer, L)))
+        # (keyword only when sparse: the convolution objects of the dense path -- a test's fp64 double among them -- need not know it)
+        lv = (lambda table, layer: {}) if live is None else (lambda table, layer: {"live": live(table, reach_of_subnet_layer(layer, L))})
         new = (lambda key, shape: torch.empty(shape, dtype=x0.dtype, device=x0.device)) if bufs is None else bufs
         if not dropout:
-            y = first(x0, new("t0", tuple(x0.shape)), t1, relu=True, live=lv(t1, 0))
+            y = first(x0, new("t0", tuple(x0.shape)), t1, relu=True, **lv(t1, 0))
             for j, conv in enumerate(convs[1:], 1):
-                y = self._wino(conv)(y, new("t%d" % (j & 1), tuple(y.shape)), t1, relu=True, live=lv(t1, j))
+                y = self._wino(conv)(y, new("t%d" % (j & 1), tuple(y.shape)), t1, relu=True, **lv(t1, j))
             return y, 1
         offn = level_pixel_offsets(levels, copies)
         a = new("a", (offn[-1], C))
@@ -574,7 +575,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
             # ... by the conv's own store pass (pod_wino_conv3x3_split_replicas)
             tr = block_table(levels, 1, x0.device, out_copies=copies)
             first.replicas(x0, a, tr, copies, relu=True, dropout_p=p_first, seed=self.dropout_seed, offset=self._drop_calls << 34, epoch=self._epoch,
-                           live=lv(tr, 0))
+                           **lv(tr, 0))
         else:
             assert live is None, "the sparse tower needs the split kernel's replica store"
             # ... or by a pass of its own per level (the fp32-MFMA kernel; the same masks)
@@ -596,7 +597,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         for j, conv in enumerate(convs[1:], 1):
             self._drop_calls += 1
             self._wino(conv)(a, b, tn, relu=True, dropout_p=0.0 if replay else self.dropout_rate, seed=self.dropout_seed,
-                             offset=self._drop_calls << 34, epoch=self._epoch, live=lv(tn, j))
+                             offset=self._drop_calls << 34, epoch=self._epoch, **lv(tn, j))
             if replay:
                 mask_in_place(b, j)
             a, b = b, a

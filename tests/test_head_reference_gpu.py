@@ -14,7 +14,7 @@ from tests.head_fixture import EVAL_NAMES, FIELDS, VARIANT_NAMES, HeadFixture, p
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 KERNELS = [False, True]
-IDS = ["K11-fp32-mfma", "K12-bf16x6"]
+IDS = ["K11-fp32-mfma", "K12-f16x3"]
 
 
 @pytest.fixture(params=KERNELS, ids=IDS)

@@ -204,7 +204,7 @@ class Fp64Conv:
         return dst
 
 
-@pytest.mark.parametrize("split", [True, False], ids=["K12-bf16x6", "K11-fp32-mfma"])
+@pytest.mark.parametrize("split", [True, False], ids=["K12-f16x3", "K11-fp32-mfma"])
 def test_detections_through_the_winograd_head_equal_those_through_an_fp64_head(tmp_path, split, monkeypatch):
     """(both convolution kernels: the production split kernel and the fp32-MFMA kernel)
     Detection level, model -> hot path: a calibrated checkpoint with the head sharpened so that detections exist, N = 10 MC

@@ -47,4 +47,8 @@ for c in cfg2 cfg4 cfg5; do python bench.py --config $c --steps 120 --warmup 10 
 for c in cfg2 cfg4; do python bench.py --config $c --steps 120 --warmup 10 --no-cpu-baseline --no-diagnostics --no-graphs > "$OUT/bench_${c}_no_graphs.json" 2>> "$OUT/bench_default.err"; done
 POD_BENCH_BACKEND=gloo POD_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-diagnostics > "$OUT/bench_gloo2_shared_gpu.json" 2>> "$OUT/bench_default.err"
 POD_BENCH_BACKEND=gloo POD_BENCH_SHARE_GPU=1 python bench.py --gpus 6 --config cfg5 --ensemble-per-gpu --steps 12 --warmup 2 > "$OUT/bench_cfg5_gloo6_shared_gpu.json" 2>> "$OUT/bench_default.err"
+# (6) round 5: the sparse bbox tower as the step (planted / worst), one-stream steady state of it, the trunk's convolution classes
+python bench.py --sparse-bbox --steps 60 --warmup 10 --no-cpu-baseline --no-diagnostics > "$OUT/bench_sparse_planted.json" 2>> "$OUT/bench_default.err"
+python bench.py --sparse-bbox --synth worst --steps 60 --warmup 10 --no-cpu-baseline --no-diagnostics > "$OUT/bench_sparse_worst.json" 2>> "$OUT/bench_default.err"
+for st in 1 3; do python bench.py --streams $st --steps 60 --warmup 10 --no-cpu-baseline --no-diagnostics > "$OUT/bench_streams$st.json" 2>> "$OUT/bench_default.err"; done
 ls "$OUT"

@@ -110,14 +110,14 @@ for j in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
 if bench:
     open(os.path.join(dst, "%s_bench_lines.jsonl" % tag), "w").write("\n".join(bench) + "\n")
     lines += ["## bench lines (`profiles/%s_bench_lines.jsonl`)" % tag, "",
-              "| file | n_gpus | value | unit | ms/step | hot path ms | worst ms | K1 frac | conv frac |", "|---|---|---|---|---|---|---|---|---|"]
+              "| file | n_gpus | value | unit | ms/step | hot path ms | worst ms | K1 frac | conv net TFLOP/s (direct-equivalent) |", "|---|---|---|---|---|---|---|---|---|"]
     for b in bench:
         d = json.loads(b)
         l = d["line"]
         f = lambda x: "" if x is None else ("%.4g" % x)
         lines.append("| %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (d["file"], l.get("n_gpus"), f(l.get("value")), l.get("unit"), f(l.get("ms_per_step")),
                      f(l.get("hot_path_ms_per_image")), f(l.get("hot_path_worst_ms")), f((l.get("roofline_k1") or l.get("roofline") or {}).get("frac")),
-                     f((l.get("conv_roofline") or {}).get("frac"))))
+                     f((l.get("conv_census") or l.get("conv_roofline") or {}).get("direct_equivalent_tflops"))))
     lines.append("")
 # ---- pod_wino_conv3x3 (tools/profile_wino.sh <tag>w) and pod_wino_conv3x3_split (POD_WINO_SPLIT=1 tools/profile_wino.sh <tag>ws)
 import re
@@ -125,7 +125,7 @@ for suffix, split in (("w", False), ("ws", True)):
     wsrc = "gpurun_out/%s%s" % (tag, suffix)
     if not os.path.exists(os.path.join(wsrc, "wino_stats.csv")):
         continue
-    name = "pod_wino_conv3x3_split (fp32 products from 3-way bf16 splits, bf16 matrix cores)" if split else "pod_wino_conv3x3 (fp32 matrix cores)"
+    name = "pod_wino_conv3x3_split (fp32 products from 2-way f16 splits of the scaled operands, f16 matrix cores)" if split else "pod_wino_conv3x3 (fp32 matrix cores)"
     lines += ["## %s, the launch bench.py times (`tools/profile_wino.sh`: 19 runs x 5 FPN levels of the 768x1344 frame, C = K = 256)" % name, "",
               "`%srocprofv3 --kernel-trace --stats -- python tools/wino_only.py 20 19 bench`:" % ("POD_WINO_SPLIT=1 " if split else ""), "",
               "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
@@ -145,10 +145,10 @@ for suffix, split in (("w", False), ("ws", True)):
     tiles, padded = (int(m.group(1)), int(m.group(2))) if m else (51243, 51968)                      # 2 x 4 output tiles of the bench launch
     fetch, write = 2 * pm.get("FETCH_SIZE", 0) * 1024, pm.get("WRITE_SIZE", 0) * 1024
     mfma_busy = pm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (pm.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024)
-    products, peak, unit = (6, 2500.0, "bf16") if split else (1, 157.3, "fp32")
+    products, peak, unit = (3, 2500.0, "f16") if split else (1, 157.3, "fp32")
     flop = 2 * 24 * tiles * 65536 * products
     lines += ["", "Derived: executed MFMA FLOPs of the real 2x4 tiles %s2*24*%d*256*256 = %.1f GFLOP -> %.1f TFLOP/s = %.2f of the %.1f TFLOP/s %s MFMA peak;" % (
-                  "6 partial products x " if split else "", tiles, flop / 1e9, flop / avg_ns / 1e3, flop / avg_ns / 1e3 / peak, peak, unit),
+                  "3 partial products x " if split else "", tiles, flop / 1e9, flop / avg_ns / 1e3, flop / avg_ns / 1e3 / peak, peak, unit),
               "matrix pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = %.2f (it also works on the %d padding tiles of partial 16x16 blocks);" % (mfma_busy, padded - tiles),
               "LDS bank conflicts SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.2f;" % (pm.get("SQ_LDS_BANK_CONFLICT", 0) / max(pm.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
               "direct-convolution rate 2*9*pixels*256*256 / t = %.1f TFLOP/s.  HBM-side traffic (FETCH_SIZE x 2 on gfx950, KB units) %.2f GB read + %.2f GB written" % (
