@@ -1,5 +1,6 @@
-"""GPU box: pod_conv1x1_split per shape of the ResNet-50-FPN and per number of input-channel splits (the policy of Conv1x1.splits_for is read off
-this table).   python tools/conv1x1_splits.py"""
+"""GPU box: pod_conv1x1_split per shape of the ResNet-50-FPN, per number of input-channel splits over workgroup sets (grid.y) and per number of
+wavefronts sharing a tile's K range inside the workgroup (round 5) -- the policy of Conv1x1.splits_for / auto_waves is read off this table.
+python tools/conv1x1_splits.py"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -29,16 +30,25 @@ for name, cin, cout, h, w, s, res, calls in SHAPES:
     ho, wo = conv.out_hw(h, w)
     r = torch.randn(ho * wo, cout, device="cuda") if res else None
     tiles = ((ho * wo + 63) // 64) * (cout // 64)
-    row = []
+    row, best = [], None
     for splits in (1, 2, 4, 8, 16):
         if (cin // 16) % splits or (cin // 16) // splits < 2 or tiles * splits > 5000:
             continue
-        g = torch.cuda.CUDAGraph()          # replayed as a graph: no host time in the figure
-        st = torch.cuda.Stream()
-        with torch.cuda.stream(st):
-            conv(x, h, w, relu=True, residual=r, n_splits=splits)
-            with torch.cuda.graph(g, stream=st):
-                for _ in range(10):
-                    conv(x, h, w, relu=True, residual=r, n_splits=splits)
-        row.append("%2d: %5.1f" % (splits, timed(g.replay) / 10))
-    print("%-20s %4d->%4d %5d px %5d tiles (policy %d) | %s" % (name, cin, cout, ho * wo, tiles, conv.splits_for(ho * wo), "  ".join(row)), flush=True)
+        for waves in (1, 2, 4):
+            per = (cin // 16) // splits
+            if waves > 1 and (per % (2 * waves) or tiles * splits * waves > 4096):
+                continue
+            g = torch.cuda.CUDAGraph()          # replayed as a graph: no host time in the figure
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                conv(x, h, w, relu=True, residual=r, n_splits=splits, waves=waves)
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(10):
+                        conv(x, h, w, relu=True, residual=r, n_splits=splits, waves=waves)
+            t = timed(g.replay) / 10
+            row.append("%dx%d: %5.1f" % (splits, waves, t))
+            if best is None or t < best[0]:
+                best = (t, splits, waves)
+    pol_s = conv.splits_for(ho * wo)
+    pol_w = Conv1x1.auto_waves(tiles * pol_s, (cin // 16) // pol_s)
+    print("%-20s %4d->%4d %5d px %5d tiles (policy %dx%d, best %dx%d %.1f us) | %s" % (name, cin, cout, ho * wo, tiles, pol_s, pol_w, best[1], best[2], best[0], "  ".join(row)), flush=True)
