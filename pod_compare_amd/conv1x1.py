@@ -52,9 +52,9 @@ class Conv1x1:
     @staticmethod
     def auto_waves(tiles: int, per_split: int) -> int:
         """The library's choice of wavefronts per workgroup (pod_conv1x1_split, waves = 0): split-K inside the workgroup, accumulators added in
-        LDS -- as many as keep the launch within one wavefront per SIMD and leave every wavefront at least 16 k-steps, in whole pairs."""
+        LDS -- as many as keep the launch within one wavefront per SIMD and leave every wavefront at least 8 k-steps, in whole pairs."""
         waves = 1
-        while waves < 4 and per_split % (waves * 4) == 0 and per_split // (waves * 2) >= 16 and tiles * waves * 2 <= 1024:
+        while waves < 4 and per_split % (waves * 4) == 0 and per_split // (waves * 2) >= 8 and tiles * waves * 2 <= 1024:
             waves *= 2
         return waves
 

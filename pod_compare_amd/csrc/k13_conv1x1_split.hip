@@ -529,7 +529,7 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     const int nks = Cin / 16;
     if (n_splits < 1 || n_splits > 16 || nks % n_splits != 0 || (n_splits > 1 && !partials)) return POD_E_INVALID;
     // waves: wavefronts of a workgroup sharing a tile's K range (1, 2 or 4; each takes whole PAIRS of k-steps); 0 = choose here: as many as
-    // keep the launch within ONE wavefront per SIMD and leave every wavefront at least 16 k-steps (measured per class, profiles/r05_conv_classes.md:
+    // keep the launch within ONE wavefront per SIMD and leave every wavefront at least 8 k-steps (measured per shape, splits x wavefronts: tools/conv1x1_splits.py, profiles/r05_conv1x1_splits.txt:
     // shorter chains or fuller launches lose more to the LDS meeting and the halved occupancy than the shorter chain wins)
     if (waves < 0 || waves > 4 || waves == 3) return POD_E_INVALID;
     {
@@ -537,7 +537,7 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
         if (waves == 0) {
             const int64_t tiles = ((P_out + 63) / 64) * (Cout / 64) * n_splits;
             waves = 1;
-            while (waves < 4 && per_split % (waves * 4) == 0 && per_split / (waves * 2) >= 16 && tiles * waves * 2 <= 1024) waves *= 2;
+            while (waves < 4 && per_split % (waves * 4) == 0 && per_split / (waves * 2) >= 8 && tiles * waves * 2 <= 1024) waves *= 2;
         }
         if (waves > 1 && (per_split % (2 * waves) != 0)) return POD_E_INVALID;
     }
