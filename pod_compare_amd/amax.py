@@ -42,10 +42,20 @@ def attach(t: torch.Tensor, w: Optional[torch.Tensor]) -> torch.Tensor:
 
 
 def produced(t: torch.Tensor) -> torch.Tensor:
-    """A fresh word for a launch about to write t (pass it as the launch's out_amax), attached to t."""
-    w = word(t.device)
+    """The record a launch about to write t max'es into (its out_amax), attached to t: a fresh zeroed one -- or, for a PERSISTENT buffer that
+    is only partly rewritten per image (the sparse bbox tower's activations: dead blocks keep an earlier image's values, and they may stand
+    in a live block's patch), the buffer's own never-zeroed record: the maximum over everything ever stored there bounds what is there."""
+    w = getattr(t, "_pod_amax_persistent", None)
+    if w is None:
+        w = word(t.device)
     attach(t, w)
     return w
+
+
+def persistent(t: torch.Tensor) -> torch.Tensor:
+    """Marks t as a persistent, partly rewritten buffer (see `produced`); t must be zero-filled now."""
+    t._pod_amax_persistent = torch.zeros(RECORD, dtype=torch.float32, device=t.device)
+    return t
 
 
 def forget(t: torch.Tensor) -> None:

@@ -707,7 +707,9 @@ class ProbabilisticRetinaNetHead(nn.Module):
         def new(name, shape):
             t = pool.get(name)
             if t is None or tuple(t.shape) != tuple(shape):
-                t = pool[name] = torch.zeros(shape, dtype=torch.float32, device=self.cls_score.weight.device)
+                from . import amax
+                # zeroed once; its abs-max record is never zeroed either: it bounds the stale values dead blocks keep (amax.produced)
+                t = pool[name] = amax.persistent(torch.zeros(shape, dtype=torch.float32, device=self.cls_score.weight.device))
             return t
         return new
 

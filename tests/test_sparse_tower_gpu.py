@@ -17,6 +17,16 @@ def build(**kw):
     modeling.fold_frozen_bn(m)
     for q in m.parameters():
         q.requires_grad_(False)
+    return generic_deltas(m)
+
+
+def generic_deltas(m):
+    """A random-init bbox_pred (std 0.01) leaves every box ON its anchor, where IoUs between neighbouring anchors sit exactly on the NMS /
+    affinity thresholds and a last-bit difference flips a keep decision: give the deltas a generic size (std 0.25)."""
+    with torch.no_grad():
+        probe = torch.randint(0, 256, (3, 128, 192), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(77))
+        std = float(torch.cat([t.reshape(-1) for t in m(probe).delta]).std())
+        m.head.bbox_pred.weight.mul_(0.25 / max(std, 1e-12))
     return m
 
 
@@ -166,7 +176,7 @@ def test_ensemble_members_share_one_set_of_live_blocks():
         with torch.no_grad():
             m.head.cls_score.weight.mul_(40.0)
             m.head.cls_score.bias.fill_(-2.5)
-        members.append(m)
+        members.append(generic_deltas(m))
     frame = torch.randint(0, 256, (3, 200, 300), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
     inp = [{"image": frame, "height": 200, "width": 300, "image_id": 3}]
     outs = []
@@ -179,3 +189,35 @@ def test_ensemble_members_share_one_set_of_live_blocks():
     assert torch.equal(a.pred_classes, b.pred_classes)
     assert float((a.pred_boxes.tensor - b.pred_boxes.tensor).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes.tensor.abs().max()))
     assert float((a.pred_boxes_covariance - b.pred_boxes_covariance).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes_covariance.abs().max()))
+
+
+def test_stale_blocks_of_a_louder_image_cannot_overflow_the_next_images_scale():
+    """The sparse tower's activation buffers are persistent and only their live blocks are rewritten per image.  A frame whose activations
+    are 50 x larger leaves such values in the blocks that are dead for the NEXT frame -- inside live blocks' patches.  The buffers' abs-max
+    records are never zeroed (they bound everything ever stored), so the quiet frame's detections are finite and equal its dense ones."""
+    m = build(dropout_rate=0.0)
+    pl = planted((256, 384), 1, seed=9)
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=1, has_cls_var=True, cov_dims=4, device="cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    quiet = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=g).float()
+    loud = quiet * 50.0
+    outs = {}
+
+    def run(frame, sparse_on, who):
+        def hook(partial):
+            hp.select(who.cls, who.cls_var, draw_id=5)
+            return sparse.LiveBlocks(hp)
+        if sparse_on:
+            ho = m(frame, sparse_bbox=hook)
+            return hp.finish("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384)), ho
+        ho = m(frame)
+        return hp.run_image("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384), draw_id=5), ho
+
+    other = planted((256, 384), 1, seed=21)              # the loud frame's candidates lie elsewhere: its live blocks are the quiet frame's dead ones
+    run(loud, True, other)
+    got, ho = run(quiet, True, pl)
+    want, _ = run(quiet, False, pl)
+    assert all(bool(torch.isfinite(t).all()) for t in ho.delta + ho.reg_var)
+    k = got.count()
+    assert k == want.count() and k > 0 and torch.equal(got.classes[:k], want.classes[:k])
+    assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
