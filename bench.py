@@ -90,9 +90,9 @@ def parse_args():
                     help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
     ap.add_argument("--fp32-mfma", action="store_true",
                     help="3x3 convolutions on pod_wino_conv3x3 (fp32 matrix instructions) instead of pod_wino_conv3x3_split (every fp32 product "
-                         "formed from EXACT 3-way bf16 splits of both operands on the bf16 matrix cores, fp32 accumulate: the production kernel "
+                         "formed from 2-way f16 splits of the scaled operands on the f16 matrix cores, fp32 accumulate: the production kernel "
                          "since round 4, contract in tests/test_wino_conv_gpu.py); the other kernel is always measured as a second leg "
-                         "(`fp32_mfma` / `split_bf16`)")
+                         "(`fp32_mfma` / `split_f16`)")
     ap.add_argument("--split-bf16", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of the model forward from Python instead of replaying a HIP graph "
                                                              "per (stream, shape)")
@@ -621,7 +621,7 @@ def main():
                    "conv3x3_kernel": "pod_wino_conv3x3_split (fp32 Winograd; every product from 2-way f16 splits of the scaled operands on the f16 matrix cores, 3 partial "
                                      "products, fp32 accumulate; per shape at least as close to fp64 as the fp32-MFMA kernel: tests/test_wino_conv_gpu.py); "
                                      "the fp32-MFMA kernel's figure: `fp32_mfma`" if args.split_bf16 else
-                                     "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_bf16`",
+                                     "pod_wino_conv3x3 (fp32 matrix instructions); the split kernel's figure: `split_f16`",
                    "rng": "in-kernel Philox4x32-10, fresh key per image",
                    "backbone": ("channels-last from the frame on: pod_stem7x7_split + pod_maxpool3x3s2_cl, pod_conv1x1_split, pod_wino_conv3x3_split (p6 / p7: PyTorch-ROCm)"
                                 if (modeling.CL_BACKBONE and args.split_bf16) else "NCHW: 1x1 / strided convolutions on PyTorch-ROCm, 3x3 / stride-1 on the Winograd kernel"),
@@ -631,7 +631,7 @@ def main():
         "mean_detections": n_det_mean,
     }
     if second is not None:
-        out["split_bf16" if second["kernel"].endswith("_split") else "fp32_mfma"] = second
+        out["split_f16" if second["kernel"].endswith("_split") else "fp32_mfma"] = second
     if sparse_leg is not None:
         out["sparse_bbox_tower"] = sparse_leg
     out["config"]["bbox_tower"] = "sparse (--sparse-bbox)" if args.sparse_bbox else "dense (the reference's evaluation order; the sparse tower's figures: `sparse_bbox_tower`)"
@@ -818,7 +818,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
                                                          "remaining 3.5 us are one scoring round (10 Philox / Box-Muller samples per class), one barrier and the emission"}
         out["k1_hbm_frac"], out["k1_merge_and_score_hbm_frac"] = k1r["frac"], k1r["merge_and_score"]["frac"]
         out["roofline_head_conv"] = out["roofline"]
-        other = "split_bf16" if not args.split_bf16 else "fp32_mfma"
+        other = "split_f16" if not args.split_bf16 else "fp32_mfma"
         if other in out:          # the same launch on the other kernel, for the second leg's record
             from pod_compare_amd import wino as _w
             _w.SPLIT_BF16 = not args.split_bf16
@@ -880,7 +880,7 @@ def diagnostics(args, spec, out, model, frames, heads, hps, params, net_hw, dev,
             out["roofline_backbone"].update(class_roofline("3x3"))
 
         c1 = census.get("1x1_hip")
-        if c1:      # the bottlenecks' 1x1 convolutions, shortcuts and FPN laterals on pod_conv1x1_split (channels-last GEMM, 6 bf16 partial products)
+        if c1:      # the bottlenecks' 1x1 convolutions, shortcuts and FPN laterals on pod_conv1x1_split (channels-last GEMM, 3 f16 partial products)
             out["roofline_conv1x1"] = {"kernel": "pod_conv1x1_split on the backbone's 1x1 convolutions and the FPN laterals (%d calls per image, batch 1; "
                                                  "small maps cut over their input channels: + pod_reduce_partials)" % c1["calls"],
                                        "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TF, "achieved": c1["tflops"] * SPLIT_PRODUCTS,

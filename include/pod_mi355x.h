@@ -476,10 +476,7 @@ int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t 
  *                         global_anchor_ids[i] (= anchor_base_l + index inside the level). */
 int pod_dump_cls_normals(const PodConfig* cfg, const PodLevel* levels, int32_t level, float* eps_cls, pod_stream_t stream);
 int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids, int32_t n, float* eps_prop, pod_stream_t stream);
-/* test support for pod_wino_conv3x3_split's arithmetic contract: the three bf16 terms (bit patterns, terms dev uint16 [3][n]) the kernel
- * forms of each fp32 operand x[i] (dev, n even): x == t0 + t1 + t2 exactly (tests/test_wino_conv_gpu.py). */
-int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t stream);
-/* terms[2][n] f16 bit patterns: x[i] * scale = t0 + t1 to 2^-23 |x[i] scale| (scale a power of two; the round-5 split kernels' own code) */
+/* test support for the split kernels' arithmetic contract (tests/test_wino_conv_gpu.py): terms[2][n] f16 bit patterns (dev uint16, n even): x[i] * scale = t0 + t1 to 2^-23 |x[i] scale| (scale a power of two; the round-5 split kernels' own code) */
 int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, pod_stream_t stream);
 
 /* ---- K13 conv1x1_split (round 4): the 1x1 convolutions of the backbone / FPN as a channels-last GEMM ------------------------

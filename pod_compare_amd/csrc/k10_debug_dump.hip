@@ -79,24 +79,6 @@ extern "C" int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_
     return POD_OK;
 }
 
-// pod_debug_bf16_split3 -- test support: the exact 3-way bf16 split of pod_wino_conv3x3_split's operands (pod_wino.h: wino_bf16_split3, the
-// very functions the kernel's loop calls), written out: terms[3][n] bf16 bit patterns of x[n] (n even: values are split in pairs, as
-// v_cvt_pk_bf16_f32 converts them).
-namespace pod {
-__global__ void __launch_bounds__(256) k_debug_bf16_split3(const float* __restrict__ x, uint16_t* __restrict__ terms, int64_t n) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (i >= n) return;
-    uint32_t w[3];
-    const WinoSplitSel sel;
-    wino_bf16_split3(x[i], x[i + 1], w, sel);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        terms[t * n + i] = (uint16_t)(w[t] & 0xFFFFu);
-        terms[t * n + i + 1] = (uint16_t)(w[t] >> 16);
-    }
-}
-}  // namespace pod
-
 // pod_debug_f16_split2 -- test support: the 2-way f16 split of the power-of-two-scaled operands of the round-5 split kernels (pod_wino.h:
 // wino_f16_split2, the functions the kernels' loops call): terms[2][n] f16 bit patterns of x[n] * scale (n even).
 namespace pod {
@@ -117,15 +99,6 @@ extern "C" int pod_debug_f16_split2(const float* x, float scale, void* terms, in
     if (!x || !terms || n < 0 || (n & 1) != 0) return POD_E_INVALID;
     if (n == 0) return POD_OK;
     hipLaunchKernelGGL(pod::k_debug_f16_split2, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       reinterpret_cast<uint16_t*>(terms), n);
-    POD_CHECK_LAUNCH();
-    return POD_OK;
-}
-
-extern "C" int pod_debug_bf16_split3(const float* x, void* terms, int64_t n, pod_stream_t stream) {
-    if (!x || !terms || n < 0 || (n & 1) != 0) return POD_E_INVALID;
-    if (n == 0) return POD_OK;
-    hipLaunchKernelGGL(pod::k_debug_bf16_split3, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<uint16_t*>(terms), n);
     POD_CHECK_LAUNCH();
     return POD_OK;

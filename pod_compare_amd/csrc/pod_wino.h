@@ -132,44 +132,6 @@ __device__ __forceinline__ void wino_pin(T&... v) {
     (wino_pin_one(v), ...);
 }
 
-// ---- an fp32 value as the exact sum of three bf16 values (k12_wino_conv_split.hip; pod_debug_bf16_split3 exposes the same code to the tests)
-// x = x0 + x1 + x2:  x0 = bf16(x) (round to nearest even), r1 = x - x0 (exact: |r1| <= 2^-9 |x|, 16 significant bits), x1 = bf16(r1),
-// r2 = r1 - x1 (exact, 8 significant bits), x2 = bf16(r2) = r2.  Exact for every finite x whose residuals stay normal (|x| >= 2^-110);
-// below that the last terms are fp32 denormals, which v_cvt_pk_bf16_f32 / the subtraction keep or flush as the kernel's denormal mode
-// says -- either way the sum is within 2^-126 of x.  +-inf / nan give (x, nan, nan): the products are nan, as an fp32 product would be.
-typedef __bf16 wino_bf16x2 __attribute__((ext_vector_type(2)));
-#ifndef POD_SPLIT_DOT2C
-#define POD_SPLIT_DOT2C 1
-#endif
-__device__ __forceinline__ uint32_t wino_bf16_pair(float lo, float hi) {              // v_cvt_pk_bf16_f32: nearest even, lo in bits 15:0
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, wino_bf16x2));
-}
-struct WinoSplitSel {                     // the two operand selectors of the residual's v_dot2c_f32_bf16, made once per kernel
-    uint32_t lo, hi;
-    __device__ __forceinline__ WinoSplitSel() : lo(0x0000BF80u), hi(0xBF800000u) {
-        // scalar registers the compiler cannot see through: as an INLINE constant a 16-bit operand's -1.0 is the fp16 pattern 0xBC00,
-        // which read as bf16 is -2^-7
-        asm volatile("" : "+s"(lo), "+s"(hi));
-    }
-};
-__device__ __forceinline__ void wino_bf16_residual(uint32_t w, float& lo, float& hi, const WinoSplitSel& sel) {   // (lo, hi) -= the bf16 pair w, exactly
-#if POD_SPLIT_DOT2C
-    // v_dot2c_f32_bf16: D += A.lo B.lo + A.hi B.hi with B = (-1, 0) / (0, -1): ONE instruction per value instead of shift / mask + subtract
-    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, sel.lo), lo, false);
-    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wino_bf16x2, w), __builtin_bit_cast(wino_bf16x2, sel.hi), hi, false);
-#else
-    lo -= __builtin_bit_cast(float, w << 16);
-    hi -= __builtin_bit_cast(float, w & 0xFFFF0000u);
-#endif
-}
-__device__ __forceinline__ void wino_bf16_split3(float lo, float hi, uint32_t (&w)[3], const WinoSplitSel& sel) {
-    w[0] = wino_bf16_pair(lo, hi);
-    wino_bf16_residual(w[0], lo, hi, sel);
-    w[1] = wino_bf16_pair(lo, hi);
-    wino_bf16_residual(w[1], lo, hi, sel);
-    w[2] = wino_bf16_pair(lo, hi);
-}
-
 // ---- an fp32 value as the sum of two FP16 values (round 5: k12 / k13 / k14; pod_debug_f16_split2 exposes the same code to the tests)
 // The f16 matrix cores run at the bf16 rate, and two f16 terms carry 11 + 1 (the sign of the residual) + 11 = 23 of an fp32's 24
 // significand bits: x s = x0 + x1 + e, |e| <= 2^-23 |x s| in the worst case (exact whenever the residual has <= 11 significant bits), where

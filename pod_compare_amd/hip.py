@@ -28,7 +28,7 @@ EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_scor
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image", "pod_run_image_part",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_bf16_split3", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
+           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -145,7 +145,6 @@ def load() -> ctypes.CDLL:
     lib.pod_bias_act.argtypes = [P, P, P, P, c_int64, c_int32, c_int64, c_int32, c_float, c_uint64, c_uint64, P]
     lib.pod_dump_cls_normals.argtypes = [POINTER(PodConfig), POINTER(PodLevel), c_int32, P, P]
     lib.pod_dump_box_normals.argtypes = [POINTER(PodConfig), P, c_int32, P, P]
-    lib.pod_debug_bf16_split3.argtypes = [P, P, c_int64, P]
     lib.pod_run_image.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
     lib.pod_run_image_part.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,

@@ -1,4 +1,4 @@
-"""pod_conv1x1_split (csrc/k13_conv1x1_split.hip): the backbone's / FPN's 1x1 convolutions as a channels-last GEMM with exact 3 x bf16
+"""pod_conv1x1_split (csrc/k13_conv1x1_split.hip): the backbone's / FPN's 1x1 convolutions as a channels-last GEMM with split-operand (round 5: 2-way f16; rounds 3-4: 3 x bf16)
 split products.  Referees: torch's conv2d on the same tensors, and an fp64 convolution with the per-element bound of the 3x3 kernels."""
 import pytest
 import torch

@@ -36,7 +36,7 @@ def make(levels, copies, C, K, seed=0):
 ])
 @pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "f16x3"])
 def test_channels_last_output_equals_conv2d(levels, copies, C, K, split):
-    """split: pod_wino_conv3x3_split (3-way bf16 splits on the bf16 matrix cores; needs C % 16 == 0, else the fp32 kernel serves)."""
+    """split: pod_wino_conv3x3_split (2-way f16 splits on the f16 matrix cores; needs C % 16 == 0, else the fp32 kernel serves)."""
     w, b, xs = make(levels, copies, C, K)
     conv = WinoConv(w, b, split=split)
     assert conv.split == (split and C % 16 == 0)
@@ -105,7 +105,8 @@ def test_error_against_an_fp64_direct_convolution(K, planes):
     evaluation is written in (a length-n fp32 dot product guarantees c <= n = 2304).  Measured c (tools/wino_fp64_check.py, MI355X):
     pod_wino_conv3x3 11.6 / 10.8 / 13.6 (trunk / cls_score / bbox_pred), MIOpen's fp32 conv2d 2.5 - 2.8, mkldnn's fp32 conv2d on the
     CPU 2.9 - 5.2: fp32 Winograd costs a factor ~4 over a direct fp32 sum and stays two orders of magnitude inside the fp32 class.
-    pod_wino_conv3x3_split (every product from exact 3-way bf16 splits, 6 partial products, fp32 accumulate): 10.6 / 9.6 / 8.5.
+    pod_wino_conv3x3_split, rounds 3-4 (exact 3-way bf16 splits, 6 partial products, fp32 accumulate): 10.6 / 9.6 / 8.5; round 5 (2-way f16 splits of the
+    scaled operands, 3 partial products): printed by this test.
     THE CONTRACT OF THE SPLIT KERNEL, per shape: c(K12) <= c(K11) -- it is at least as close to the fp64 result as the fp32-MFMA
     kernel on every shape it replaces it on (same Winograd, same operation order: the two differ only in how a product is formed)."""
     c11 = _c_against_fp64(K, planes, False)
