@@ -56,6 +56,17 @@ def marginal_calibration_error(probs: np.ndarray, labels: np.ndarray, num_bins: 
     return float(max(total, 0.0) ** 0.5)
 
 
+def default_marginal_fn():
+    """The reference's own function when its dependency is installed (`calibration.get_calibration_error`, requirements.txt:16:
+    `uncertainty-calibration`; CE:117-136 calls it with the package's defaults), else the restatement above -- and which one it is, for the
+    table: the restatement is unpinned against the package (absent from this image), so a number produced with it says so."""
+    try:
+        import calibration as cal                                     # noqa: F401  (third-party: not in this image)
+        return (lambda probs, labels: float(cal.get_calibration_error(np.asarray(probs), np.asarray(labels)))), "calibration.get_calibration_error"
+    except Exception:
+        return marginal_calibration_error, "restated (package `uncertainty-calibration` not installed: unpinned)"
+
+
 def _min_uncertainty_error(entropy: torch.Tensor, is_tp: torch.Tensor) -> torch.Tensor:
     """CE:160-178 / CE:279-292: shuffle (ties), sort by entropy, 0.5 * (TP above the threshold / TP) + 0.5 * (non-TP below it / non-TP), min."""
     perm = torch.randperm(entropy.shape[0])
@@ -150,8 +161,11 @@ def main(argv=None):
     g = ev.eval_gt_preprocess(gt, device=args.device)
     matched = ev.match_predictions_to_groundtruth(pred["predicted_boxes"], pred["predicted_cls_probs"], pred["predicted_covar_mats"],
                                                   g["gt_boxes"], g["gt_cat_idxs"], args.iou_min, args.iou_correct, device=args.device)
-    res = calibration_errors(matched, BDD_DATASET_ID_TO_CONTIGUOUS)
+    fn, which = default_marginal_fn()
+    res = calibration_errors(matched, BDD_DATASET_ID_TO_CONTIGUOUS, marginal_fn=fn)
     print(format_table(res))
+    print("Cls Marginal Calibration Error computed by: " + which)       # (say it in the table's output, not only in a docstring)
+    res["cls_marginal_calibration_error_source"] = which
     return res
 
 
