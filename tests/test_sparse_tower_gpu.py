@@ -11,9 +11,10 @@ from pod_compare_amd.wino import block_table
 pytestmark = pytest.mark.gpu
 
 
-def build(**kw):
+def build(plain=False, **kw):
     torch.manual_seed(0)
-    m = modeling.ProbabilisticRetinaNet(cls_var_loss="loss_attenuation", cls_var_num_samples=10, bbox_cov_loss="negative_log_likelihood", **kw).cuda().eval()
+    heads = {} if plain else dict(cls_var_loss="loss_attenuation", cls_var_num_samples=10, bbox_cov_loss="negative_log_likelihood")
+    m = modeling.ProbabilisticRetinaNet(**heads, **kw).cuda().eval()
     modeling.fold_frozen_bn(m)
     for q in m.parameters():
         q.requires_grad_(False)
@@ -221,3 +222,26 @@ def test_stale_blocks_of_a_louder_image_cannot_overflow_the_next_images_scale():
     k = got.count()
     assert k == want.count() and k > 0 and torch.equal(got.classes[:k], want.classes[:k])
     assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
+
+
+def test_plain_model_without_variance_heads_takes_the_sparse_order_too():
+    """BASELINE configs[3]'s model (retinanet_R_50_FPN_1x: no cls_var / bbox_cov heads) under anchor_statistics: dense against sparse."""
+    m = build(plain=True)
+    frame = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+    pl = synthetic.planted_head_outputs((256, 384), 1, seed=13, num_boxes=6, with_cls_var=False, with_reg_var=False).to("cuda")
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=1, has_cls_var=False, cov_dims=0, device="cuda:0")
+    dense = m(frame)
+    assert dense.cls_var is None and dense.reg_var is None
+    want = hp.run_image("anchor_statistics", pl.cls, dense.delta, None, None, (256, 384), (256, 384), draw_id=2)
+
+    def hook(partial):
+        assert partial.cls_var is None
+        hp.select(pl.cls, None, draw_id=2)
+        return sparse.LiveBlocks(hp)
+
+    sp = m(frame, sparse_bbox=hook)
+    got = hp.finish("anchor_statistics", pl.cls, sp.delta, None, None, (256, 384), (256, 384))
+    k = got.count()
+    assert k == want.count() and k > 0 and torch.equal(got.classes[:k], want.classes[:k])
+    assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
+    assert float((got.cov[:k] - want.cov[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.cov[:k].abs().max()))
