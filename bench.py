@@ -85,7 +85,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per GPU, images round-robin (batch 1 per stream as in AN:35; SURVEY 8d); 0 = the config's default: 2 for the "
                          "MC-dropout config (its step is K12's head launches; a third image in flight only adds contention: 101.6 - 102.6 against "
-                         "99.6 - 99.7 images/s, profiles/r04_experiments.md), 3 otherwise")
+                         "99.6 - 99.7 images/s, profiles/r04_experiments.md), 4 for the single-model configs (profiles/r05_streams_sweep.txt: "
+                         "570 / 628 / 646 / 616 images/s with 2 / 3 / 4 / 6 streams on cfg2), 3 for the in-process ensemble")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
                     help="cfg5 only: one ensemble member per rank (needs --gpus >= 5), exchange pipelined over RCCL p2p")
     ap.add_argument("--fp32-mfma", action="store_true",
@@ -448,7 +449,7 @@ def main():
     D = 4 if spec["reg_var"] else 0
     # one workspace per stream: images are independent units (PI:86-111), so consecutive images go to different HIP streams
     # and the low-occupancy stretches of one image's backbone overlap the other image's head convs
-    n_streams = args.streams if args.streams > 0 else (2 if (N > 1 and spec.get("members", 1) == 1) else 3)
+    n_streams = args.streams if args.streams > 0 else (3 if spec.get("members", 1) > 1 else 2 if N > 1 else 4)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     hps = [hotpath.HotPath(heads[0].shapes, heads[0].anchors, params, n_runs=N, has_cls_var=spec["cls_var"], cov_dims=D, device=dev)
            for _ in range(n_streams)]

@@ -225,7 +225,7 @@ def main(argv=None):
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of a forward from Python instead of replaying a HIP graph per (stream, frame shape)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per GPU; consecutive images of a rank go to different streams (batch 1 per stream, AN:35); 0 = 2 with "
-                         "MC dropout (several runs per image), 3 otherwise")
+                         "MC dropout (several runs per image), 3 for an in-process ensemble, 4 otherwise (profiles/r05_streams_sweep.txt)")
     ap.add_argument("--flush-every", type=int, default=64,
                     help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
@@ -279,7 +279,8 @@ def main(argv=None):
                 m.graph_after_seen = 2                                      # (a frame size is captured once it has come back: data sets of many sizes stay eager)
     # images are independent units: keep a few in flight on separate HIP streams so one image's low-occupancy backbone
     # stretches overlap another image's head convs (+12 % images/s on one MI355X); the predictor keeps a workspace per stream
-    n_streams = args.streams if args.streams > 0 else (2 if (getattr(predictor, "mc_dropout_enabled", False) and getattr(predictor, "num_mc_dropout_runs", 1) > 1) else 3)
+    mc = getattr(predictor, "mc_dropout_enabled", False) and getattr(predictor, "num_mc_dropout_runs", 1) > 1
+    n_streams = args.streams if args.streams > 0 else (2 if mc else 3 if len(getattr(predictor, "model_list", [])) > 1 else 4)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
     width = record_width(K)
     dev = cfg.MODEL.DEVICE
