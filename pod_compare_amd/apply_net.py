@@ -13,6 +13,7 @@ image order and writes `coco_instances_results.json` (AN:100-102 format).
 import argparse
 import json
 import os
+import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -136,6 +137,54 @@ class CocoImages:
                 "file_name": rec["file_name"]}
 
 
+class Prefetched:
+    """The worker side of the reference's test loader (detectron2's build_detection_test_loader runs the mapper on
+    cfg.DATALOADER.NUM_WORKERS processes): entries `dataset[i]` for `indices`, read / decoded / resized up to `depth` entries ahead on
+    `workers` host threads (PIL drops the GIL while it decodes and resizes) and handed out IN ORDER; the uint8 frame is moved to pinned
+    memory so that `.to(device, non_blocking=True)` is an asynchronous copy on the image's stream.  One decode thread feeds ~60 frames of
+    1280x720 per second; a GPU takes 130 - 650.  workers = 0: the plain loop.  An exception of a worker surfaces at the entry it belongs to."""
+
+    def __init__(self, dataset, indices: Sequence[int], workers: int = 4, depth: int = 0, pin: bool = True):
+        self.dataset, self.indices, self.workers = dataset, list(indices), max(0, int(workers))
+        self.depth = int(depth) if depth > 0 else 2 * max(1, self.workers)
+        self.pin = bool(pin) and torch.cuda.is_available()
+
+    def _load(self, i: int) -> dict:
+        d = self.dataset[i]
+        if self.pin:
+            d["image"] = d["image"].pin_memory()
+        return d
+
+    def __len__(self) -> int:
+        return len(self.indices)
+
+    def __iter__(self):
+        if self.workers == 0:
+            for i in self.indices:
+                yield i, self._load(i)
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="pod-loader") as pool:
+            pending = deque()
+            it = iter(self.indices)
+            try:
+                for i in it:
+                    pending.append((i, pool.submit(self._load, i)))
+                    if len(pending) >= self.depth:
+                        break
+                while pending:
+                    i, fut = pending.popleft()
+                    entry = fut.result()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        pending.append((nxt, pool.submit(self._load, nxt)))
+                    yield i, entry
+            finally:
+                for _, fut in pending:
+                    fut.cancel()
+
+
 class EnsemblePerGpu:
     """Config 5 (`ensembles_pre_nms.yaml`) on one node: ensemble member s lives on rank s < M, every member rank runs the
     conv net on the SAME image, the dense pre-NMS head tensors meet on the image's merge rank (= the rank that owns the
@@ -226,6 +275,9 @@ def main(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per GPU; consecutive images of a rank go to different streams (batch 1 per stream, AN:35); 0 = 2 with "
                          "MC dropout (several runs per image), 3 for an in-process ensemble, 4 otherwise (profiles/r05_streams_sweep.txt)")
+    ap.add_argument("--loader-workers", type=int, default=-1,
+                    help="host threads that read / decode / resize the files of --coco-json ahead of the GPU (the reference's DATALOADER.NUM_WORKERS); "
+                         "-1 = the config's value, 0 = in the main loop")
     ap.add_argument("--flush-every", type=int, default=64,
                     help="images per rank between two gathers of the device-resident records (SURVEY 8e: ~0.74 MB per rank and flush)")
     ap.add_argument("--ensemble-per-gpu", action="store_true",
@@ -288,6 +340,7 @@ def main(argv=None):
     n_mine = len(shard_indices(args.num_images, 0, world))          # rank 0 owns the most images: every rank flushes as often
     all_ids: List[int] = []
     all_cnt, all_rec = [], []
+    flushed: List[Tuple[float, int]] = []
 
     def flush(chunk_ids, recs, cnts):
         """ONE collective: this chunk's records of every rank, image order restored (device memory stays bounded)."""
@@ -299,7 +352,10 @@ def main(argv=None):
         all_ids.extend(ids)
         all_cnt.append(cnt.cpu())
         all_rec.append(rec.cpu())
+        flushed.append((time.perf_counter(), len(all_ids)))       # (the host copies above waited for the records)
 
+    torch.cuda.synchronize()
+    t_loop = time.perf_counter()
     if args.ensemble_per_gpu:
         flush_ids = list(mine)
         for a in range(0, max(n_mine, 1), F):
@@ -307,13 +363,16 @@ def main(argv=None):
     else:
         chunk_ids: List[int] = []
         recs, cnts = [], []
+        workers = args.loader_workers if args.loader_workers >= 0 else int(cfg.DATALOADER.NUM_WORKERS)
+        loaded = iter(Prefetched(dataset, mine, workers=workers)) if dataset is not None else None
         with torch.no_grad():
             for j in range(n_mine):
                 if j < len(mine):
                     i = mine[j]
+                    if loaded is not None:
+                        _, d = next(loaded)                             # resized on the host exactly as detectron2's mapper does, a few entries ahead
                     with torch.cuda.stream(streams[j % len(streams)]):
                         if dataset is not None:
-                            d = dataset[i]                              # resized on the host exactly as detectron2's mapper does
                             input_im = [{"image": d["image"].to(dev, non_blocking=True), "height": d["height"], "width": d["width"],
                                          "image_id": i}]                # position in the list: the dataset's id is restored below
                         else:
@@ -329,6 +388,8 @@ def main(argv=None):
                 if (j + 1) % F == 0 or j + 1 == n_mine:
                     flush(chunk_ids, recs, cnts)
                     chunk_ids, recs, cnts = [], [], []
+    torch.cuda.synchronize()
+    t_loop = time.perf_counter() - t_loop
     ids = all_ids
     order = sorted(range(len(ids)), key=lambda q: ids[q])
     ids = [ids[q] for q in order]
@@ -343,6 +404,13 @@ def main(argv=None):
             from .inference_utils import write_binary_results
             write_binary_results(args.binary_output, ids, cnt, rec, K)
         print("wrote %s: %d images, %d detections" % (args.output, len(ids), int(cnt.sum())))
+        if not args.ensemble_per_gpu and t_loop > 0:           # (first images included: eager forwards, then the graph captures)
+            steady = ""
+            if len(flushed) >= 2 and flushed[-1][0] > flushed[0][0]:
+                steady = "; %.1f images/s after the first flush" % ((flushed[-1][1] - flushed[0][1]) / (flushed[-1][0] - flushed[0][0]))
+            print("inference loop: %d images on %d rank(s) in %.2f s = %.1f images/s%s (%d stream(s) per GPU%s)" % (
+                len(ids), world, t_loop, len(ids) / t_loop, steady, n_streams,
+                ", %d loader thread(s)" % workers if dataset is not None else ", synthetic frames made on the device"))
     if world > 1:
         dist.destroy_process_group()
 

@@ -295,6 +295,36 @@ def test_coco_image_list_is_mapped_like_detectron2s_test_loader(tmp_path):
     assert tuple(b["image"].shape) == (3, 80, 100) and (b["height"], b["width"], b["image_id"]) == (40, 50, 17)
 
 
+def test_prefetched_loader_keeps_order_contents_and_errors(tmp_path):
+    """apply_net.Prefetched (the reference's DATALOADER.NUM_WORKERS side of the test loader): entries come back in the order asked for,
+    equal to the plain loop's, for any number of threads and look-ahead; a worker's exception surfaces at its entry."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    images = []
+    for k in range(9):
+        h, w = 30 + 3 * k, 50 + 2 * k
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / ("f%d.png" % k))
+        images.append({"id": 100 - k, "file_name": "f%d.png" % k, "height": h, "width": w})
+    (tmp_path / "set.json").write_text(json.dumps({"images": images}))
+    ds = apply_net.CocoImages(str(tmp_path / "set.json"), str(tmp_path), min_size=40, max_size=80)
+    order = [7, 0, 3, 3, 8, 1]
+    plain = [(i, ds[i]) for i in order]
+    for workers, depth in ((0, 0), (1, 1), (3, 2), (4, 0), (8, 16)):
+        got = list(apply_net.Prefetched(ds, order, workers=workers, depth=depth, pin=False))
+        assert [i for i, _ in got] == order
+        for (_, a), (_, b) in zip(got, plain):
+            assert torch.equal(a["image"], b["image"]) and (a["height"], a["width"], a["image_id"]) == (b["height"], b["width"], b["image_id"])
+    assert list(apply_net.Prefetched(ds, [], workers=2)) == []
+    images.append({"id": 1, "file_name": "missing.png", "height": 1, "width": 1})
+    (tmp_path / "set.json").write_text(json.dumps({"images": images}))
+    ds = apply_net.CocoImages(str(tmp_path / "set.json"), str(tmp_path), min_size=40, max_size=80)
+    it = iter(apply_net.Prefetched(ds, [0, 9, 1], workers=2, pin=False))
+    assert next(it)[0] == 0
+    with pytest.raises(FileNotFoundError):
+        next(it)
+
+
 def test_wino_block_table_canvases():
     """Host side of pod_wino_conv3x3: level-major pixel offsets and the block records {first in pixel, first out pixel,
     grid_cols<<24 | H<<12 | W, n_images<<24 | by<<12 | bx} (include/pod_mi355x.h): the images of a level stand in a grid on one canvas,
