@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 12
+#define POD_ABI_VERSION 13
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -447,6 +447,12 @@ int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream)
 int pod_stem7x7_split(const void* x, int32_t x_is_u8, int32_t H_img, int32_t W_img, const float* mean, const float* stddev, float* y, const void* Ws,
                       const float* bias, int32_t H, int32_t W, int32_t relu, const float* in_amax, float* out_amax, pod_stream_t stream);
 int pod_maxpool3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, pod_stream_t stream);
+/* pod_im2col3x3s2_cl (ABI 13): the patch matrix of a 3x3 / stride 2 / padding 1 convolution on a channels-last map -- x (H * W, C) ->
+ * y (((H-1)/2+1) * ((W-1)/2+1), 9 C), row (oy, ox) = the C-vectors of the nine taps in (ty, tx) order, zeros where a tap falls outside
+ * the map; relu != 0: max(x, 0) on the way.  pod_conv1x1_split on y with the weight laid out (Cout, ty, tx, Cin) is then the convolution:
+ * detectron2's LastLevelP6P7 (p6 = conv(res5), p7 = conv(relu(p6)); the last two convolutions of `self.backbone(images.tensor)`,
+ * probabilistic_retinanet.py:96-100) without MIOpen, bit-reproducible run to run.  C % 4 == 0; an upper bound of |x| bounds |y|. */
+int pod_im2col3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, int32_t relu, pod_stream_t stream);
 
 /* ---- ground-truth matching (offline metrics, SURVEY f-1) ------------------------------------------
  * Replaces: match_predictions_to_groundtruth core/evaluation_tools/evaluation_utils.py:191-367 for a whole data set

@@ -125,6 +125,37 @@ class Stem7x7:
         return torch.add(c[1], amax.of(x), alpha=c[0])
 
 
+class Conv3x3S2:
+    """conv3x3(stride 2, padding 1) on a channels-last map as pod_im2col3x3s2_cl + pod_conv1x1_split: FPN's LastLevelP6P7 (p6 on res5, p7 on
+    relu(p6): 252 and 66 output pixels at the benchmark frame -- the long K of the patch matrix, 9 Cin, is cut over workgroup sets and
+    wavefronts by the 1x1 kernel's own policy).  Bit-reproducible run to run (fixed-order partial sums), unlike the MIOpen kernels it replaces."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+        self.K, self.C = int(weight.shape[0]), int(weight.shape[1])
+        w9 = weight.detach().permute(0, 2, 3, 1).reshape(self.K, 9 * self.C, 1, 1).contiguous()       # (Cout, ty, tx, Cin): the patch matrix's column order
+        self.gemm = Conv1x1(w9, bias, 1)
+
+    @staticmethod
+    def eligible(conv: Optional[torch.nn.Conv2d]) -> bool:
+        return (conv is not None and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (1, 1)
+                and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0)
+
+    @staticmethod
+    def out_hw(h: int, w: int):
+        return ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
+
+    def __call__(self, x: torch.Tensor, h: int, w: int, relu_input: bool = False, relu: bool = False):
+        """x: (h * w, Cin) channels-last of ONE image -> (y (ho * wo, Cout) channels-last = act(conv(act_in(x)) + bias), ho, wo)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
+        ho, wo = self.out_hw(h, w)
+        cols = torch.empty((ho * wo, 9 * self.C), dtype=torch.float32, device=x.device)
+        bound = amax.of(x)                                   # max |x| bounds the patch matrix too (its entries are x's, relu'd or not, and zeros)
+        hip.check(hip.load().pod_im2col3x3s2_cl(x.data_ptr(), cols.data_ptr(), h, w, self.C, 1 if relu_input else 0, hip.current_stream()), "pod_im2col3x3s2_cl")
+        amax.attach(cols, bound)
+        return self.gemm(cols, ho, wo, relu=relu), ho, wo
+
+
 def maxpool3x3s2_cl(x: torch.Tensor, h: int, w: int):
     """max_pool2d(kernel 3, stride 2, padding 1) of a channels-last map (h * w, C) -> (y (hp * wp, C), hp, wp)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == h * w and x.shape[1] % 4 == 0

@@ -201,6 +201,30 @@ __global__ void __launch_bounds__(256) k_maxpool3x3s2_cl(const float* __restrict
     }
 }
 
+// The patch matrix of a 3x3 / stride 2 / padding 1 convolution on a channels-last map: row (oy, ox) = the nine taps' C-vectors in (ty, tx)
+// order, zeros where a tap falls outside the map -- pod_conv1x1_split with Cin = 9 C then IS the convolution (FPN's LastLevelP6P7: 252 and
+// 66 output pixels at the benchmark frame, where an implicit-GEMM kernel of its own would be a few workgroups).  relu: max(x, 0) on the
+// way (p7 reads relu(p6)).  One thread per 16 bytes: whole 128-byte lines in, whole lines out.
+__global__ void __launch_bounds__(256) k_im2col3x3s2_cl(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo, int C4, int relu) {
+    const int64_t n = (int64_t)Ho * Wo * 9 * C4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t r = i / C4;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int ox = (int)(r % Wo), oy = (int)(r / Wo);
+        const int iy = 2 * oy - 1 + tap / 3, ix = 2 * ox - 1 + tap % 3;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+            v = *reinterpret_cast<const f32x4*>(x + (((int64_t)iy * Wi + ix) * C4 + c4) * 4);
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
 }  // namespace pod
 
 extern "C" int pod_stem7x7_filter_split(const float* weight, void* Ws, pod_stream_t stream) {
@@ -242,6 +266,18 @@ extern "C" int pod_maxpool3x3s2_cl(const float* x, float* y, int32_t H, int32_t 
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(pod::k_maxpool3x3s2_cl, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, Hp, Wp, C / 4);
+    POD_CHECK_LAUNCH();
+    return POD_OK;
+}
+
+extern "C" int pod_im2col3x3s2_cl(const float* x, float* y, int32_t H, int32_t W, int32_t C, int32_t relu, pod_stream_t stream) {
+    if (!x || !y || x == y || H < 1 || W < 1 || H > 16384 || W > 16384 || C < 4 || (C & 3) != 0) return POD_E_INVALID;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) != 0) return POD_E_INVALID;
+    const int32_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t n = (int64_t)Ho * Wo * 9 * (C / 4);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pod::k_im2col3x3s2_cl, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, Ho, Wo, C / 4, relu ? 1 : 0);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 12
+POD_ABI_VERSION = 13
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -28,7 +28,7 @@ EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_scor
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image", "pod_run_image_part",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl")
+           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl", "pod_im2col3x3s2_cl")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -138,6 +138,7 @@ def load() -> ctypes.CDLL:
     lib.pod_stem7x7_filter_split.argtypes = [P, P, P]
     lib.pod_stem7x7_split.argtypes = [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32, c_int32, c_int32, P, P, P]
     lib.pod_maxpool3x3s2_cl.argtypes = [P, P, c_int32, c_int32, c_int32, P]
+    lib.pod_im2col3x3s2_cl.argtypes = [P, P, c_int32, c_int32, c_int32, c_int32, P]
     lib.pod_conv1x1_filter_split.argtypes = [P, P, c_int32, c_int32, P]
     lib.pod_conv1x1_split.argtypes = [P, P, P, P, P] + [c_int32] * 9 + [P, c_int32, P, P, P]
     lib.pod_conv1x1_filter_split_bytes.argtypes = [c_int32, c_int32]

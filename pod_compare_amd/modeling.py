@@ -247,6 +247,7 @@ GROUPED_HEAD = __import__("os").environ.get("POD_GROUPED_HEAD", "1") != "0"     
 FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0"     # the first conv of an MC-dropout subnet stores its masked replicas itself
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
 FUSED_PREPROCESS = __import__("os").environ.get("POD_FUSED_PREPROCESS", "1") != "0"   # ... which then also normalises and pads the frame on load
+HIP_P6P7 = __import__("os").environ.get("POD_HIP_P6P7", "1") != "0"         # FPN's p6 / p7 (3x3 / stride 2) as pod_im2col3x3s2_cl + pod_conv1x1_split instead of MIOpen
 HIP_STEM = __import__("os").environ.get("POD_HIP_STEM", "1") != "0"         # the 7x7 stem + max-pool of the channels-last trunk on pod_stem7x7_split / pod_maxpool3x3s2_cl
 
 
@@ -271,6 +272,18 @@ def stem_of(conv: nn.Conv2d):
         cached = (key, Stem7x7(conv.weight, conv.bias))
         torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
         conv._pod_stem = cached
+    return cached[1]
+
+
+def s2_of(conv: nn.Conv2d):
+    """The conv's im2col + pod_conv1x1_split form (3x3 / stride 2: FPN's p6 / p7; weight re-laid and split once), refreshed when the parameters change."""
+    from .conv1x1 import Conv3x3S2
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else (conv.bias.data_ptr(), conv.bias._version))
+    cached = getattr(conv, "_pod_s2", None)
+    if cached is None or cached[0] != key:
+        cached = (key, Conv3x3S2(conv.weight, conv.bias))
+        torch.cuda.current_stream(conv.weight.device).synchronize()      # made once, then read from any stream
+        conv._pod_s2 = cached
     return cached[1]
 
 
@@ -438,7 +451,7 @@ class FPN(nn.Module):
 
     def forward_cl(self, feats):
         """feats: [(c3, h, w), (c4, h, w), (c5, h, w)] channels-last buffers.  Lateral 1x1 convs on pod_conv1x1_split, top-down sums on
-        channels-last views, output 3x3 convs on pod_wino_conv3x3[_split]; p6 / p7 (stride-2 3x3: MIOpen) read channels_last views.
+        channels-last views, output 3x3 convs on pod_wino_conv3x3[_split]; p6 / p7 (stride-2 3x3) as a patch matrix on pod_conv1x1_split (round 5; POD_HIP_P6P7=0: MIOpen on channels_last views).
         Returns (1, 256, h, w) tensors with channels_last strides: the head lays them out channels-last anyway."""
         (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = feats
         l5 = c1_of(self.lateral[2])(c5, h5, w5)
@@ -448,8 +461,14 @@ class FPN(nn.Module):
         p3 = cl_as_nchw(wino_cl(self.output[0], l3, h3, w3, relu=False), h3, w3)
         p4 = cl_as_nchw(wino_cl(self.output[1], l4, h4, w4, relu=False), h4, w4)
         p5 = cl_as_nchw(wino_cl(self.output[2], l5, h5, w5, relu=False), h5, w5)
-        p6 = self.p6(cl_as_nchw(c5, h5, w5))
-        p7 = self.p7(F.relu(p6))
+        from .conv1x1 import Conv3x3S2
+        if HIP_P6P7 and Conv3x3S2.eligible(self.p6) and Conv3x3S2.eligible(self.p7):
+            t6, h6, w6 = s2_of(self.p6)(c5, h5, w5)
+            t7, h7, w7 = s2_of(self.p7)(t6, h6, w6, relu_input=True)
+            p6, p7 = cl_as_nchw(t6, h6, w6), cl_as_nchw(t7, h7, w7)
+        else:
+            p6 = self.p6(cl_as_nchw(c5, h5, w5))
+            p7 = self.p7(F.relu(p6))
         return [p3, p4, p5, p6, p7]
 
 

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # the latter can never hide the former (round 4: one stray fixture stopped the run at test 86 of 387).
 GPU_ORDER = ("test_hip_parity", "test_nms_gpu", "test_topk_gpu", "test_nll_gpu", "test_predictor_gpu", "test_native_exact_gpu",
              "test_hip_edge_cases", "test_run_image_gpu", "test_sparse_tower_gpu", "test_eval_matching", "test_probabilistic_metrics", "test_torch_ops_gpu", "test_head_reference_gpu",
-             "test_wino_conv_gpu", "test_stem_gpu", "test_conv1x1_gpu", "test_graphs_gpu", "test_ensemble_dist_gpu",
+             "test_wino_conv_gpu", "test_stem_gpu", "test_conv1x1_gpu", "test_p6p7_gpu", "test_graphs_gpu", "test_ensemble_dist_gpu",
              "test_apply_net_gpu", "test_multi_gpu")
 # inside test_hip_parity: goldens and index sequences before everything else
 FUNC_ORDER = ("test_hip_matches_reference_golden", "test_hip_indices_bit_exact", "test_records_match_json_of_oracle",
