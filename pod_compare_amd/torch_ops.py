@@ -16,7 +16,7 @@ no second implementation and no CPU kernel (calling them with CPU tensors raises
     wino_filter_transform / wino_conv3x3
                  the head's `Conv2d(C, K, 3, padding=1) [+ ReLU + Dropout]` (PR:403-484) for all MC runs and FPN levels in one
                  launch: channels-last activations in, channels-last (trunk) or NCHW planes (predictors) out
-    conv1x1_filter_split / conv1x1_split, stem7x7_filter_split / stem7x7_split, maxpool3x3s2_cl
+    conv1x1_filter_split / conv1x1_split, stem7x7_filter_split / stem7x7_split, maxpool3x3s2_cl, im2col3x3s2_cl
                  the channels-last trunk (round 4): the backbone's / FPN's 1x1 convolutions with bias / residual / ReLU in the store, the
                  7x7 stem taking the frame as loaded (normalisation + padding on load) and its max-pool
 """
@@ -42,6 +42,7 @@ _LIB.define("conv1x1_split(Tensor x, Tensor Ws, Tensor? bias, Tensor? residual, 
 _LIB.define("stem7x7_filter_split(Tensor weight) -> Tensor")
 _LIB.define("stem7x7_split(Tensor frame, Tensor Ws, Tensor? bias, Tensor? mean, Tensor? std, int padded_h, int padded_w, bool relu=True) -> Tensor")
 _LIB.define("maxpool3x3s2_cl(Tensor x, int h, int w) -> Tensor")
+_LIB.define("im2col3x3s2_cl(Tensor x, int h, int w, bool relu=False) -> Tensor")
 
 _PATHS = {}            # key -> [HotPath, anchor identity, the anchor tensors]; insertion order = LRU order
 _MAX_PATHS = 16
@@ -274,7 +275,19 @@ def _maxpool3x3s2_cl(x, h, w) -> torch.Tensor:
     return y
 
 
+def _im2col3x3s2_cl(x, h, w, relu=False) -> torch.Tensor:
+    """The patch matrix of a 3x3 / stride 2 / padding 1 convolution (FPN's p6 / p7): conv1x1_split on it with the weight laid out
+    (Cout, ty, tx, Cin) is the convolution."""
+    torch._check(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[0] == h * w and x.shape[1] % 4 == 0 and x.shape[1] >= 4,
+                 lambda: "x: contiguous CUDA fp32 (h * w, C), C % 4 == 0")
+    y = torch.empty((((h - 1) // 2 + 1) * ((w - 1) // 2 + 1), 9 * x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        hip.check(hip.load().pod_im2col3x3s2_cl(hip.ptr(x), hip.ptr(y), int(h), int(w), int(x.shape[1]), 1 if relu else 0, hip.current_stream()), "pod_im2col3x3s2_cl")
+    return y
+
+
 _IMPL = torch.library.Library("pod_mi355x", "IMPL")
+_IMPL.impl("im2col3x3s2_cl", _im2col3x3s2_cl, "CUDA")
 _IMPL.impl("conv1x1_filter_split", _conv1x1_filter_split, "CUDA")
 _IMPL.impl("conv1x1_split", _conv1x1_split, "CUDA")
 _IMPL.impl("stem7x7_filter_split", _stem7x7_filter_split, "CUDA")

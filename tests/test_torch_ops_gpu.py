@@ -133,7 +133,12 @@ def test_trunk_operators_equal_conv2d_and_max_pool():
         z = ops.conv1x1_split(p, ws, b1, res, 24, 32, 2, 128, relu=True, n_splits=splits)
         wantz = (F.conv2d(p.view(1, 24, 32, 64).permute(0, 3, 1, 2), w1, b1, stride=2) + res.view(1, 12, 16, 128).permute(0, 3, 1, 2)).relu()
         assert float((z.view(1, 12, 16, 128).permute(0, 3, 1, 2) - wantz).abs().max()) <= 2e-5 * max(1.0, float(wantz.abs().max()))
-    for bad in (lambda: ops.conv1x1_split(p.cpu(), ws, b1, None, 24, 32, 1, 128), lambda: ops.conv1x1_split(p, ws[:-1], b1, None, 24, 32, 1, 128),
+    w3 = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05                     # FPN's p6 / p7 form: patch matrix + the 1x1 kernel
+    cols = ops.im2col3x3s2_cl(p, 24, 32, relu=True)
+    z3 = ops.conv1x1_split(cols, ops.conv1x1_filter_split(w3.permute(0, 2, 3, 1).reshape(64, 576, 1, 1).contiguous()), b7, None, 12, 16, 1, 64)
+    want3 = F.conv2d(p.view(1, 24, 32, 64).permute(0, 3, 1, 2).relu(), w3, b7, stride=2, padding=1)
+    assert float((z3.view(1, 12, 16, 64).permute(0, 3, 1, 2) - want3).abs().max()) <= 2e-5 * max(1.0, float(want3.abs().max()))
+    for bad in (lambda: ops.im2col3x3s2_cl(p, 24, 31), lambda: ops.conv1x1_split(p.cpu(), ws, b1, None, 24, 32, 1, 128), lambda: ops.conv1x1_split(p, ws[:-1], b1, None, 24, 32, 1, 128),
                 lambda: ops.conv1x1_split(p, ws, b1, None, 24, 32, 3, 128), lambda: ops.conv1x1_split(p, ws, b1, None, 24, 32, 1, 128, n_splits=3),
                 lambda: ops.stem7x7_split(frame, ops.stem7x7_filter_split(w7), b7, mean, None, 96, 128), lambda: ops.stem7x7_split(frame, ops.stem7x7_filter_split(w7), b7, None, None, 64, 128),
                 lambda: ops.maxpool3x3s2_cl(y, 48, 63)):
