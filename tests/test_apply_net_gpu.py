@@ -49,6 +49,18 @@ def test_one_rank_and_two_gloo_ranks_on_one_gpu(tmp_path):
     assert ids == list(range(5)) and k == 7                      # every image exactly once, in order, whichever rank ran it
 
 
+def test_two_sessions_write_the_same_bytes(tmp_path):
+    """--random-seed fixes the run: the MC-dropout masks are a function of (seed, stream, forward number) -- eager forwards and graph replays
+    alike -- and since FPN's p6 / p7 left MIOpen no kernel of the forward accumulates with atomics, so two sessions of the same topology
+    (two streams, graphs captured on the way) write identical files, byte for byte."""
+    outs = []
+    for name in ("a", "b"):
+        run(tmp_path, name, 1, ("--num-images", "9", "--random-seed", "7"))
+        outs.append((open(str(tmp_path / (name + ".json")), "rb").read(), open(str(tmp_path / (name + ".podr")), "rb").read()))
+    assert len(json.loads(outs[0][0])) > 0
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+
+
 def test_coco_image_list_end_to_end(tmp_path):
     """--coco-json / --image-root: files -> detectron2-style mapped inputs -> predictor -> results keyed by the DATASET's ids."""
     import numpy as np
