@@ -901,7 +901,7 @@ class ProbabilisticRetinaNet(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(PIXEL_STD).view(3, 1, 1), persistent=False)
         self._anchor_cache: Dict[Tuple[int, int], List[torch.Tensor]] = {}
         self.use_graphs = False
-        self.max_graphs = 12                                   # (stream, frame shape, flags) entries kept; each owns its activations
+        self.max_graphs = 16                                   # (stream, frame shape, flags) entries kept (four frame shapes on each of apply_net's four streams); each owns its activations
         self.graph_after_seen = 0                              # forwards of a (stream, shape, flags) run eagerly before it is captured
         self._graphs: Dict[tuple, tuple] = {}
         self._graph_seen: Dict[tuple, int] = {}
