@@ -59,11 +59,12 @@ class Conv1x1:
         return waves
 
     def __call__(self, x: torch.Tensor, h: int, w: int, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                 n_splits: Optional[int] = None, waves: int = 0) -> torch.Tensor:
+                 n_splits: Optional[int] = None, waves: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: (h * w, Cin) channels-last of ONE image -> (h_out * w_out, Cout) channels-last = act(conv(x) + bias [+ residual])."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
         ho, wo = self.out_hw(h, w)
-        y = torch.empty((ho * wo, self.K), dtype=torch.float32, device=x.device)
+        y = torch.empty((ho * wo, self.K), dtype=torch.float32, device=x.device) if out is None else out
+        assert y.is_contiguous() and tuple(y.shape) == (ho * wo, self.K) and y.dtype == torch.float32
         if residual is not None:
             assert residual.is_contiguous() and tuple(residual.shape) == tuple(y.shape) and residual.dtype == torch.float32
         s = self.splits_for(ho * wo) if n_splits is None else int(n_splits)
@@ -145,7 +146,7 @@ class Conv3x3S2:
     def out_hw(h: int, w: int):
         return ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
 
-    def __call__(self, x: torch.Tensor, h: int, w: int, relu_input: bool = False, relu: bool = False):
+    def __call__(self, x: torch.Tensor, h: int, w: int, relu_input: bool = False, relu: bool = False, out: Optional[torch.Tensor] = None):
         """x: (h * w, Cin) channels-last of ONE image -> (y (ho * wo, Cout) channels-last = act(conv(act_in(x)) + bias), ho, wo)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
         ho, wo = self.out_hw(h, w)
@@ -153,7 +154,7 @@ class Conv3x3S2:
         bound = amax.of(x)                                   # max |x| bounds the patch matrix too (its entries are x's, relu'd or not, and zeros)
         hip.check(hip.load().pod_im2col3x3s2_cl(x.data_ptr(), cols.data_ptr(), h, w, self.C, 1 if relu_input else 0, hip.current_stream()), "pod_im2col3x3s2_cl")
         amax.attach(cols, bound)
-        return self.gemm(cols, ho, wo, relu=relu), ho, wo
+        return self.gemm(cols, ho, wo, relu=relu, out=out), ho, wo
 
 
 def maxpool3x3s2_cl(x: torch.Tensor, h: int, w: int):

@@ -298,10 +298,24 @@ def _w3_ok(conv: Optional[nn.Conv2d]) -> bool:
             and conv.out_channels in (64, 128, 256, 512))
 
 
-def wino_cl(conv: nn.Conv2d, x: torch.Tensor, h: int, w: int, relu: bool) -> torch.Tensor:
+def wino_cl(conv: nn.Conv2d, x: torch.Tensor, h: int, w: int, relu: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(conv3x3(x) + bias) of one channels-last image (h * w, C) -> (h * w, K)."""
     from .wino import block_table
-    return wino_of(conv).channels_last_of_one_image(x, block_table([(h, w)], 1, x.device, channels=max(conv.in_channels, conv.out_channels)), relu=relu)
+    return wino_of(conv).channels_last_of_one_image(x, block_table([(h, w)], 1, x.device, channels=max(conv.in_channels, conv.out_channels)), relu=relu, out=out)
+
+
+def levels_channels_last(features: List[torch.Tensor]) -> torch.Tensor:
+    """The FPN levels as ONE channels-last buffer, level after level (what the head's grouped launches read): the buffer FPN.forward_cl wrote
+    them into when they still are its consecutive slices (no copy), else their concatenation."""
+    buf = getattr(features[0], "_pod_cl_levels", None)
+    if buf is not None and buf.shape[0] == sum(int(f.shape[2]) * int(f.shape[3]) for f in features) and buf._version == features[0]._pod_cl_version:
+        at, ok = buf.data_ptr(), True
+        for f in features:
+            ok = ok and f.shape[0] == 1 and f.shape[1] == buf.shape[1] and f.data_ptr() == at and f.stride(1) == 1
+            at += int(f.shape[2]) * int(f.shape[3]) * int(buf.shape[1]) * 4
+        if ok:
+            return buf
+    return torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])
 
 
 def cl_as_nchw(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
@@ -458,17 +472,34 @@ class FPN(nn.Module):
         up = lambda t, h, w, size: nchw_as_cl(F.interpolate(cl_as_nchw(t, h, w), size=size, mode="nearest"))
         l4 = c1_of(self.lateral[1])(c4, h4, w4, residual=up(l5, h5, w5, (h4, w4)))       # lateral + upsampled top-down map in one store
         l3 = c1_of(self.lateral[0])(c3, h3, w3, residual=up(l4, h4, w4, (h3, w3)))
+        from . import amax
+        from .conv1x1 import Conv3x3S2
+        if HIP_P6P7 and Conv3x3S2.eligible(self.p6) and Conv3x3S2.eligible(self.p7) and self.output[0].out_channels == self.p6.out_channels == self.p7.out_channels:
+            # the five levels go straight into ONE buffer, level after level -- the layout the head's grouped launches read (no concatenation
+            # in front of the head) -- and max their abs-max into one record (the head's `in_amax`)
+            (h6, w6) = Conv3x3S2.out_hw(h5, w5)
+            (h7, w7) = Conv3x3S2.out_hw(h6, w6)
+            hw = [(h3, w3), (h4, w4), (h5, w5), (h6, w6), (h7, w7)]
+            buf = torch.empty((sum(h * w for h, w in hw), self.p6.out_channels), dtype=torch.float32, device=c5.device)
+            rec, parts, at = amax.word(buf.device), [], 0
+            for h, w in hw:
+                parts.append(buf[at:at + h * w])
+                parts[-1]._pod_amax_persistent = rec             # (amax.produced: the launch that writes this slice max'es into the shared record)
+                at += h * w
+            wino_cl(self.output[0], l3, h3, w3, relu=False, out=parts[0])
+            wino_cl(self.output[1], l4, h4, w4, relu=False, out=parts[1])
+            wino_cl(self.output[2], l5, h5, w5, relu=False, out=parts[2])
+            s2_of(self.p6)(c5, h5, w5, out=parts[3])
+            s2_of(self.p7)(parts[3], h6, w6, relu_input=True, out=parts[4])
+            amax.attach(buf, rec)
+            outs = [cl_as_nchw(t, h, w) for t, (h, w) in zip(parts, hw)]
+            outs[0]._pod_cl_levels, outs[0]._pod_cl_version = buf, buf._version
+            return outs
         p3 = cl_as_nchw(wino_cl(self.output[0], l3, h3, w3, relu=False), h3, w3)
         p4 = cl_as_nchw(wino_cl(self.output[1], l4, h4, w4, relu=False), h4, w4)
         p5 = cl_as_nchw(wino_cl(self.output[2], l5, h5, w5, relu=False), h5, w5)
-        from .conv1x1 import Conv3x3S2
-        if HIP_P6P7 and Conv3x3S2.eligible(self.p6) and Conv3x3S2.eligible(self.p7):
-            t6, h6, w6 = s2_of(self.p6)(c5, h5, w5)
-            t7, h7, w7 = s2_of(self.p7)(t6, h6, w6, relu_input=True)
-            p6, p7 = cl_as_nchw(t6, h6, w6), cl_as_nchw(t7, h7, w7)
-        else:
-            p6 = self.p6(cl_as_nchw(c5, h5, w5))
-            p7 = self.p7(F.relu(p6))
+        p6 = self.p6(cl_as_nchw(c5, h5, w5))
+        p7 = self.p7(F.relu(p6))
         return [p3, p4, p5, p6, p7]
 
 
@@ -746,7 +777,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         if not ok:
             raise RuntimeError("the sparse bbox tower needs the split kernels on the GPU (POD_WINO_SPLIT=1, one fp32 image, grouped head)")
         levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
-        x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
+        x0 = levels_channels_last(features)                                                    # channels-last, level after level
         tc, nc = self._trunk_all_levels(self.cls_subnet, x0, levels, cls_copies, dropout)
         cj = [(self.cls_score, tc, nc, 0, m, n)] if dropout else [(self.cls_score, tc, 1, 0, 1, 1)]
         if self.compute_cls_var:
@@ -806,7 +837,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         if wino:
             # every conv of the head on pod_wino_conv3x3: one launch per layer over all levels and all runs
             levels = [(int(f.shape[2]), int(f.shape[3])) for f in features]
-            x0 = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in features])     # channels-last, level after level
+            x0 = levels_channels_last(features)                                                    # channels-last, level after level
             grouped = self._grouped_ok(cls_copies, box_copies)
             if sparse_bbox is not None:
                 st = self.forward_cls(features, num_runs, mc_dropout, skip_unused_last_run)

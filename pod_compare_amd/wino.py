@@ -245,12 +245,14 @@ class WinoConv:
         _launch_split([{"conv": self, "src": src, "dst": partials, "bias": False, "out_amax": False}], table, [0], self.C, self.Kpad, False, 0.0, 0, None,
                       n_splits=s, split_stride=hw * self.Kpad)
 
-    def channels_last_of_one_image(self, src: torch.Tensor, table: torch.Tensor, relu: bool = False, n_splits: Optional[int] = None) -> torch.Tensor:
+    def channels_last_of_one_image(self, src: torch.Tensor, table: torch.Tensor, relu: bool = False, n_splits: Optional[int] = None,
+                                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """conv + bias (+ ReLU) of ONE image, channels-last in and out ((H*W, C) -> (H*W, K); K % 64 == 0): the form a channels-last
         backbone chains (conv1x1.Conv1x1 before and after); small maps are cut over their input channels like `planes_of_one_image`."""
         assert self.K == self.Kpad, "channels-last output needs K % 64 == 0"
         hw = int(src.shape[0])
-        dst = torch.empty((hw, self.Kpad), dtype=torch.float32, device=src.device)
+        dst = torch.empty((hw, self.Kpad), dtype=torch.float32, device=src.device) if out is None else out
+        assert dst.is_contiguous() and tuple(dst.shape) == (hw, self.Kpad) and dst.dtype == torch.float32
         s = self.splits_for(int(table.shape[0])) if n_splits is None else int(n_splits)
         if s <= 1:
             return self(src, dst, table, relu=relu)

@@ -82,3 +82,26 @@ def test_fpn_top_levels_equal_the_miopen_path(monkeypatch):
         for ta, tb in zip(a[3:], b[3:]):
             assert ta.shape == tb.shape
             assert float((ta - tb).abs().max()) <= 2e-5 * max(1.0, float(tb.abs().max())), (h5, w5)
+
+
+def test_fpn_levels_land_in_one_buffer_the_head_reads_without_a_copy():
+    """FPN.forward_cl writes p3 .. p7 into consecutive slices of one channels-last buffer and maxes their abs-max into one record;
+    modeling.levels_channels_last hands the head that buffer (no concatenation) -- and falls back to the concatenation for any other list."""
+    from pod_compare_amd import amax
+    torch.manual_seed(4)
+    fpn = modeling.FPN().cuda().eval()
+    h5, w5 = 7, 11
+    feats = [(torch.randn(h5 * k * w5 * k, c, device="cuda").relu(), h5 * k, w5 * k) for c, k in ((512, 4), (1024, 2), (2048, 1))]
+    with torch.no_grad():
+        outs = fpn.forward_cl(feats)
+    buf = modeling.levels_channels_last(outs)
+    assert buf.data_ptr() == outs[0].data_ptr() and buf is outs[0]._pod_cl_levels
+    want = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]) for f in outs])
+    assert torch.equal(buf, want)
+    rec = amax.of(buf)                                             # the shared record bounds every level (and equals the maximum: 16 slots)
+    assert float(rec.max()) == float(want.abs().max())
+    other = [f.clone() for f in outs]                              # not the buffer's slices any more: concatenated
+    cat = modeling.levels_channels_last(other)
+    assert cat.data_ptr() != buf.data_ptr() and torch.equal(cat, want)
+    shuffled = [outs[0], outs[2], outs[1], outs[3], outs[4]]       # same objects, another order: not consecutive slices
+    assert modeling.levels_channels_last(shuffled).data_ptr() != buf.data_ptr()
