@@ -497,13 +497,18 @@ int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, po
  * n_splits > 1 (small maps): the input channels cut over workgroup sets, partial sums in `partials` (n_splits * H_out * W_out * Cout
  * floats), added in a fixed order with bias / residual / ReLU by a second launch.  waves (round 5): 1, 2 or 4 wavefronts of ONE workgroup
  * share a tile's K range and add their accumulators in LDS in a fixed order -- split-K without the partial sums' trip through HBM or a
- * second launch, to the bit the result of the same cut over workgroup sets; 0: chosen by the library (what the model uses). */
+ * second launch, to the bit the result of the same cut over workgroup sets; 0: chosen by the library (what the model uses).
+ * flags: POD_C1_RELU (1) = ReLU; POD_C1_RESIDUAL_UP2 (2, n_splits == 1 only) = `residual` is the HALF-resolution map, ((H_out + 1) / 2) x
+ * ((W_out + 1) / 2) pixels, and pixel (y, x) adds residual[(y >> 1) * ((W_out + 1) / 2) + (x >> 1)]: detectron2 FPN's top-down path,
+ * `lateral + F.interpolate(top_down, scale_factor=2, mode="nearest")`, without materialising the upsampled map. */
+#define POD_C1_RELU 1
+#define POD_C1_RESIDUAL_UP2 2
 int64_t pod_conv1x1_filter_split_bytes(int32_t Cout, int32_t Cin);
 int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t Cout, int32_t Cin, pod_stream_t stream);
 int pod_reduce_partials(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, const float* residual, float* y,
                         int64_t n, int32_t Cout, int32_t relu, float* out_amax, pod_stream_t stream);   /* y = act(sum_s partials[s] + bias + residual), channels-last */
 int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out,
-                      int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials,
+                      int32_t H_in, int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t flags, int32_t n_splits, float* partials,
                       int32_t waves, const float* in_amax, float* out_amax, pod_stream_t stream);
 
 /* ---- one image, one call --------------------------------------------------------------------

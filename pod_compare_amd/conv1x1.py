@@ -59,18 +59,28 @@ class Conv1x1:
         return waves
 
     def __call__(self, x: torch.Tensor, h: int, w: int, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                 n_splits: Optional[int] = None, waves: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: (h * w, Cin) channels-last of ONE image -> (h_out * w_out, Cout) channels-last = act(conv(x) + bias [+ residual])."""
+                 n_splits: Optional[int] = None, waves: int = 0, out: Optional[torch.Tensor] = None, residual_up2: bool = False) -> torch.Tensor:
+        """x: (h * w, Cin) channels-last of ONE image -> (h_out * w_out, Cout) channels-last = act(conv(x) + bias [+ residual]).
+        residual_up2: `residual` is the half-resolution map ((h_out + 1) // 2 x (w_out + 1) // 2 pixels), added nearest-neighbour upsampled
+        (FPN's top-down sum) without being materialised."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (h * w, self.C)
         ho, wo = self.out_hw(h, w)
         y = torch.empty((ho * wo, self.K), dtype=torch.float32, device=x.device) if out is None else out
         assert y.is_contiguous() and tuple(y.shape) == (ho * wo, self.K) and y.dtype == torch.float32
-        if residual is not None:
-            assert residual.is_contiguous() and tuple(residual.shape) == tuple(y.shape) and residual.dtype == torch.float32
         s = self.splits_for(ho * wo) if n_splits is None else int(n_splits)
+        if residual is not None and residual_up2:
+            hr, wr = (ho + 1) // 2, (wo + 1) // 2
+            assert residual.is_contiguous() and tuple(residual.shape) == (hr * wr, self.K) and residual.dtype == torch.float32
+            if s > 1:                                            # (the second launch of a split adds full-resolution residuals only)
+                residual = residual.view(hr, wr, self.K).repeat_interleave(2, 0).repeat_interleave(2, 1)[:ho, :wo].reshape(ho * wo, self.K).contiguous()
+                residual_up2 = False
+        else:
+            residual_up2 = False
+        if residual is not None and not residual_up2:
+            assert residual.is_contiguous() and tuple(residual.shape) == tuple(y.shape) and residual.dtype == torch.float32
         partials = torch.empty((s, ho * wo, self.K), dtype=torch.float32, device=x.device) if s > 1 else None
         hip.check(hip.load().pod_conv1x1_split(x.data_ptr(), y.data_ptr(), self.Ws.data_ptr(), hip.ptr(self.bias), hip.ptr(residual), ho, wo, h, w, self.stride,
-                                               self.C, self.K, 1 if relu else 0, s, hip.ptr(partials), int(waves), amax.of(x).data_ptr(), amax.produced(y).data_ptr(),
+                                               self.C, self.K, (1 if relu else 0) | (2 if residual_up2 else 0), s, hip.ptr(partials), int(waves), amax.of(x).data_ptr(), amax.produced(y).data_ptr(),
                                                hip.current_stream()), "pod_conv1x1_split")
         return y
 

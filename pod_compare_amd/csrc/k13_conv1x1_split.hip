@@ -59,6 +59,7 @@ struct C1Params {
     const float* bias;
     const float* residual;
     int32_t P_out, W_out, W_in, stride, Cin, Cout, relu;
+    int32_t res_up2, W_res;   // the residual is the half-resolution map (W_res columns): pixel (y, x) adds residual[(y >> 1) * W_res + (x >> 1)]
     int32_t n_pt, n_ct;       // pixel tiles (64), channel tiles (32 NCB)
     int32_t ks_per_split;     // k-steps (16 channels) a workgroup set accumulates; grid.y sets
     int64_t split_stride;     // floats between partial outputs; 0: no split (bias / residual / ReLU applied here)
@@ -224,11 +225,16 @@ __global__ void __launch_bounds__(64) k_conv1x1_split(const C1Params P) {
         const int64_t e0 = (int64_t)pout[pb] * P.Cout + k0;
         f32x4 r[NCB][4];
         if (final_pass && res) {
+            int64_t re0 = e0;
+            if (P.res_up2) {                                                     // FPN's top-down sum: the coarser map, nearest neighbour
+                const int oy = pout[pb] / P.W_out, ox = pout[pb] - oy * P.W_out;
+                re0 = ((int64_t)(oy >> 1) * P.W_res + (ox >> 1)) * P.Cout + k0;
+            }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    r[cb][q] = (k0 + 32 * cb + 8 * q < P.Cout) ? *reinterpret_cast<const f32x4*>(res + e0 + 32 * cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    r[cb][q] = (k0 + 32 * cb + 8 * q < P.Cout) ? *reinterpret_cast<const f32x4*>(res + re0 + 32 * cb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -272,7 +278,19 @@ __device__ __forceinline__ void c1_epilogue(const C1Params& P, float* const lds_
     const int gp0 = tp * 64 + op;
     const int64_t e0 = (int64_t)gp0 * P.Cout + tc * 64 + 4 * oc;    // + 4 j Cout
     f32x4 r[16];
-    if (final_pass && res) {
+    if (final_pass && res && P.res_up2) {                             // FPN's top-down sum: the coarser map, nearest neighbour -- pixel (y, x) adds (y >> 1, x >> 1)
+        int oy = gp0 / P.W_out, ox = gp0 - oy * P.W_out;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            r[j] = (gp0 + 4 * j < P.P_out) ? *reinterpret_cast<const f32x4*>(res + ((int64_t)(oy >> 1) * P.W_res + (ox >> 1)) * P.Cout + tc * 64 + 4 * oc)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            ox += 4;
+            while (ox >= P.W_out) {
+                ox -= P.W_out;
+                ++oy;
+            }
+        }
+    } else if (final_pass && res) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) r[j] = (gp0 + 4 * j < P.P_out) ? *reinterpret_cast<const f32x4*>(res + e0 + (int64_t)(4 * j) * P.Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -519,7 +537,7 @@ extern "C" int pod_conv1x1_filter_split(const float* weight, void* Ws, int32_t C
 }
 
 extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const float* bias, const float* residual, int32_t H_out, int32_t W_out, int32_t H_in,
-                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t relu, int32_t n_splits, float* partials, int32_t waves,
+                                 int32_t W_in, int32_t stride, int32_t Cin, int32_t Cout, int32_t flags, int32_t n_splits, float* partials, int32_t waves,
                                  const float* in_amax, float* out_amax, pod_stream_t stream) {
     if (!x || !y || !Ws || !in_amax || x == y || H_out < 1 || W_out < 1 || (stride != 1 && stride != 2) || Cin < 16 || (Cin & 15) != 0 || Cout < 64 || (Cout & 63) != 0)
         return POD_E_INVALID;
@@ -528,6 +546,8 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     if (P_out * (Cout > Cin ? Cout : Cin) >= ((int64_t)1 << 31) || (int64_t)H_in * W_in * Cin >= ((int64_t)1 << 31)) return POD_E_INVALID;
     const int nks = Cin / 16;
     if (n_splits < 1 || n_splits > 16 || nks % n_splits != 0 || (n_splits > 1 && !partials)) return POD_E_INVALID;
+    const int res_up2 = (flags & POD_C1_RESIDUAL_UP2) ? 1 : 0, relu = flags & POD_C1_RELU;
+    if (res_up2 && (!residual || n_splits > 1)) return POD_E_INVALID;     // (the second launch of a split adds full-resolution residuals only)
     // waves: wavefronts of a workgroup sharing a tile's K range (1, 2 or 4; each takes whole PAIRS of k-steps); 0 = choose here: as many as
     // keep the launch within ONE wavefront per SIMD and leave every wavefront at least 8 k-steps (measured per shape, splits x wavefronts: tools/conv1x1_splits.py, profiles/r05_conv1x1_splits.txt:
     // shorter chains or fuller launches lose more to the LDS meeting and the halved occupancy than the shorter chain wins)
@@ -549,6 +569,7 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     P.x = x; P.y = n_splits > 1 ? partials : y; P.Ws = reinterpret_cast<const uint16_t*>(Ws); P.bias = bias; P.residual = residual;
     P.in_amax = in_amax; P.out_amax = out_amax;
     P.P_out = (int32_t)P_out; P.W_out = W_out; P.W_in = W_in; P.stride = stride; P.Cin = Cin; P.Cout = Cout; P.relu = relu;
+    P.res_up2 = res_up2; P.W_res = (W_out + 1) / 2;
     // 64 pixels x 64 channels per wavefront (two wavefronts per SIMD: one's epilogue under the other's MFMAs; 128-channel tiles measured
     // 1.29 ms per image against 1.17)
     P.n_pt = (int32_t)((P_out + 63) / 64); P.n_ct = Cout / 64;

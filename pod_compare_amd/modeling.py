@@ -248,6 +248,7 @@ FUSED_REPLICAS = __import__("os").environ.get("POD_FUSED_REPLICAS", "1") != "0" 
 CL_BACKBONE = __import__("os").environ.get("POD_CL_BACKBONE", "1") != "0"
 FUSED_PREPROCESS = __import__("os").environ.get("POD_FUSED_PREPROCESS", "1") != "0"   # ... which then also normalises and pads the frame on load
 HIP_P6P7 = __import__("os").environ.get("POD_HIP_P6P7", "1") != "0"         # FPN's p6 / p7 (3x3 / stride 2) as pod_im2col3x3s2_cl + pod_conv1x1_split instead of MIOpen
+FUSED_TOPDOWN = __import__("os").environ.get("POD_FUSED_TOPDOWN", "1") != "0"   # FPN's top-down map read at half resolution by the lateral conv's store (POD_C1_RESIDUAL_UP2) instead of F.interpolate
 HIP_STEM = __import__("os").environ.get("POD_HIP_STEM", "1") != "0"         # the 7x7 stem + max-pool of the channels-last trunk on pod_stem7x7_split / pod_maxpool3x3s2_cl
 
 
@@ -469,9 +470,12 @@ class FPN(nn.Module):
         Returns (1, 256, h, w) tensors with channels_last strides: the head lays them out channels-last anyway."""
         (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = feats
         l5 = c1_of(self.lateral[2])(c5, h5, w5)
-        up = lambda t, h, w, size: nchw_as_cl(F.interpolate(cl_as_nchw(t, h, w), size=size, mode="nearest"))
-        l4 = c1_of(self.lateral[1])(c4, h4, w4, residual=up(l5, h5, w5, (h4, w4)))       # lateral + upsampled top-down map in one store
-        l3 = c1_of(self.lateral[0])(c3, h3, w3, residual=up(l4, h4, w4, (h3, w3)))
+        def lateral(conv, c, h, w, top, ht, wt):               # lateral + nearest-upsampled top-down map in one store
+            if FUSED_TOPDOWN and (ht, wt) == ((h + 1) // 2, (w + 1) // 2):      # a factor of two (every ResNet stage): read at (y >> 1, x >> 1), never materialised
+                return c1_of(conv)(c, h, w, residual=top, residual_up2=True)
+            return c1_of(conv)(c, h, w, residual=nchw_as_cl(F.interpolate(cl_as_nchw(top, ht, wt), size=(h, w), mode="nearest")))
+        l4 = lateral(self.lateral[1], c4, h4, w4, l5, h5, w5)
+        l3 = lateral(self.lateral[0], c3, h3, w3, l4, h4, w4)
         from . import amax
         from .conv1x1 import Conv3x3S2
         if HIP_P6P7 and Conv3x3S2.eligible(self.p6) and Conv3x3S2.eligible(self.p7) and self.output[0].out_channels == self.p6.out_channels == self.p7.out_channels:

@@ -139,3 +139,35 @@ def test_split_k_inside_the_workgroup_equals_the_cut_over_workgroup_sets_to_the_
     bad = lambda wv: lib.pod_conv1x1_split(xcl.data_ptr(), y.data_ptr(), conv.Ws.data_ptr(), None, None, ho, wo, h, w, stride, cin, cout, 0, 1, None, wv, am.data_ptr(), None,
                                           hip.current_stream())
     assert bad(3) == -1 and bad(5) == -1 and bad(-1) == -1
+
+
+@pytest.mark.parametrize("h,w,cin,cout", [(48, 84, 1024, 256), (47, 83, 512, 256), (5, 3, 48, 64), (1, 1, 16, 64), (96, 168, 512, 256), (7, 9, 32, 128)])
+def test_half_resolution_residual_equals_the_materialised_upsampling(h, w, cin, cout):
+    """POD_C1_RESIDUAL_UP2 (FPN's top-down sum): the residual read at (y >> 1, x >> 1) of the coarser map == the same launch with
+    F.interpolate(..., mode="nearest")'s output as a full-resolution residual, bit for bit -- both kernels (whole pairs of k-steps: LDS
+    form; an odd count: direct fragments), ragged tiles, odd sizes."""
+    import torch.nn.functional as F
+    from pod_compare_amd.conv1x1 import Conv1x1
+    g = torch.Generator(device="cuda").manual_seed(h * 17 + w + cin)
+    wt = torch.randn(cout, cin, 1, 1, device="cuda", generator=g) * 0.05
+    b = torch.randn(cout, device="cuda", generator=g)
+    x = torch.randn(h * w, cin, device="cuda", generator=g)
+    hr, wr = (h + 1) // 2, (w + 1) // 2
+    top = torch.randn(hr * wr, cout, device="cuda", generator=g)
+    up = F.interpolate(top.view(1, hr, wr, cout).permute(0, 3, 1, 2), size=(h, w), mode="nearest").permute(0, 2, 3, 1).reshape(h * w, cout).contiguous()
+    conv = Conv1x1(wt, b, 1)
+    for relu in (False, True):
+        want = conv(x, h, w, relu=relu, residual=up, n_splits=1)
+        got = conv(x, h, w, relu=relu, residual=top, residual_up2=True, n_splits=1)
+        assert torch.equal(got, want)
+    if (cin // 16) % 2 == 0:
+        assert torch.equal(conv(x, h, w, residual=top, residual_up2=True, n_splits=2), conv(x, h, w, residual=up, n_splits=2))     # (split: materialised on the host side)
+    lib, s = hip.load(), hip.current_stream()
+    y = torch.empty(h * w, cout, device="cuda")
+    am = torch.full((512,), 8.0, device="cuda")
+    args = lambda res, flags, splits, part: (x.data_ptr(), y.data_ptr(), conv.Ws.data_ptr(), conv.bias.data_ptr(), res, h, w, h, w, 1, cin, cout, flags, splits, part, 0,
+                                             am.data_ptr(), None, s)
+    assert lib.pod_conv1x1_split(*args(None, 2, 1, None)) == -1                        # the flag without a residual
+    if (cin // 16) % 2 == 0:
+        part = torch.empty(2, h * w, cout, device="cuda")
+        assert lib.pod_conv1x1_split(*args(top.data_ptr(), 2, 2, part.data_ptr())) == -1   # ... or with a split

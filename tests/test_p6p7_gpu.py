@@ -105,3 +105,20 @@ def test_fpn_levels_land_in_one_buffer_the_head_reads_without_a_copy():
     assert cat.data_ptr() != buf.data_ptr() and torch.equal(cat, want)
     shuffled = [outs[0], outs[2], outs[1], outs[3], outs[4]]       # same objects, another order: not consecutive slices
     assert modeling.levels_channels_last(shuffled).data_ptr() != buf.data_ptr()
+
+
+def test_channels_last_fpn_equals_the_nchw_fpn_on_odd_sizes():
+    """FPN.forward_cl (laterals with the top-down map read at half resolution, p6 / p7 as patch matrices, one output buffer) against
+    FPN.forward (torch's interpolate / conv2d on NCHW tensors) on maps whose sizes are odd at every level."""
+    torch.manual_seed(6)
+    fpn = modeling.FPN().cuda().eval()
+    for (h3, w3) in ((27, 45), (24, 42)):
+        sizes = [(h3, w3), ((h3 + 1) // 2, (w3 + 1) // 2)]
+        sizes.append(((sizes[1][0] + 1) // 2, (sizes[1][1] + 1) // 2))
+        nchw = [torch.randn(1, c, h, w, device="cuda").relu() for c, (h, w) in zip((512, 1024, 2048), sizes)]
+        with torch.no_grad():
+            want = fpn(nchw)
+            got = fpn.forward_cl([(t[0].permute(1, 2, 0).reshape(-1, t.shape[1]).contiguous(), t.shape[2], t.shape[3]) for t in nchw])
+        for a, b in zip(got, want):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (h3, w3, tuple(a.shape))
