@@ -74,6 +74,16 @@ CASES = {
                                     image=(750, 1333), out=(720, 1280), num_boxes=24),
     "full_cfg4_anchor_stats_plain": dict(mode="anchor_statistics", runs=1, cls_var=False, reg_var=False, seeds=[1002],
                                          image=(750, 1333), out=(720, 1280), num_boxes=24),
+    # round 6: the remaining BASELINE configs at full size, and configs[2] on the ADVERSARIAL distribution bench.py times as
+    # `hot_path_worst_ms` (every level truncated at 1000 by PI:300-308) -- the index sequences (topk_*, nms_keep_0, aw0_*) at R = 193374
+    "full_cfg1_standard_nms_plain": dict(mode="standard_nms", runs=1, cls_var=False, reg_var=False, seeds=[1003],
+                                         image=(750, 1333), out=(720, 1280), num_boxes=24),
+    "full_cfg2_bayes_od_regclsvar": dict(mode="bayes_od", runs=1, cls_var=True, reg_var=True, seeds=[1004],
+                                         image=(750, 1333), out=(720, 1280), num_boxes=24),
+    "full_cfg5_ensembles_pre_nms": dict(mode="ensembles", runs=5, ensemble=True, cls_var=True, reg_var=True, seeds=[1005],
+                                        image=(750, 1333), out=(720, 1280), num_boxes=24),
+    "full_worst_cfg3_bayes_od_mc10": dict(mode="bayes_od", runs=10, mc=True, cls_var=True, reg_var=True, seeds=[1006],
+                                          image=(750, 1333), out=(720, 1280), num_boxes=24, synth_mode="worst"),
 }
 SMALL_IMAGE, SMALL_OUT = (180, 250), (173, 240)
 

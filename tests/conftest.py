@@ -32,7 +32,7 @@ def gpu_order_key(item):
     f = FUNC_ORDER.index(fn) if fn in FUNC_ORDER else len(FUNC_ORDER)
     # BASELINE-config goldens (cfg1..cfg5, then the full-size ones) ahead of the side-mode goldens
     name = item.name
-    g = 0 if "[cfg" in name else 1 if "[full_cfg" in name else 2
+    g = 0 if "[cfg" in name else 1 if "[full_cfg" in name or "[full_worst_cfg" in name else 2
     return (m, f, g)
 
 

@@ -70,9 +70,11 @@ def test_hip_matches_reference_golden(path):
     assert_close(det.cov[:m].cpu(), g.t("pred_boxes_covariance"), "cov")
 
 
-@pytest.mark.parametrize("path", SMALL, ids=fixture_id)
+@pytest.mark.parametrize("path", PRE_NMS, ids=fixture_id)
 def test_hip_indices_bit_exact(path):
-    """top-k anchor index sequence per level and the NMS keep list equal the reference's."""
+    """top-k anchor index sequence per level and the NMS keep list equal the reference's (PI:300-311, PI:554-566, IU:78-92) -- on the
+    small frames AND at BASELINE's own size (R = 193 374: the five configs planted, configs[2] also on the adversarial distribution
+    where every level is truncated at 1000: n = 4 594, the radix-select path of K2)."""
     g = Golden(path)
     hp, det = run_hip(g)
     n = int(hp.n_total.item())

@@ -60,7 +60,7 @@ def test_oracle_reproduces_reference(path):
         assert_close(a["bbox_covar"], b["bbox_covar"], "json cov", 1e-5, 1e-6)
 
 
-@pytest.mark.parametrize("path", [p for p in SMALL if "post_nms" not in p], ids=fixture_id)
+@pytest.mark.parametrize("path", [p for p in ALL if "post_nms" not in p], ids=fixture_id)
 def test_oracle_indices_match_reference(path):
     """top-k anchor index sequences, candidate lists and NMS keep lists: exact."""
     g = Golden(path)

@@ -66,7 +66,7 @@ def test_fixture_names_written_into_test_sources_exist_and_load():
 
 def test_predictor_fixture_selection_is_by_content():
     paths = fixture_paths()
-    assert len(paths) == 23, [os.path.basename(p) for p in paths]
+    assert len(paths) == 27, [os.path.basename(p) for p in paths]
     for p in paths:
         g = Golden(p)
         assert g.meta["input_sha"] and "runs" in g.spec
@@ -74,7 +74,7 @@ def test_predictor_fixture_selection_is_by_content():
     assert all(not is_predictor_fixture(os.path.join(GOLDEN, o)) for o in others if o.endswith(".npz"))
     for k in range(1, 6):      # every BASELINE config has its two small goldens
         assert len(fixture_paths("cfg%d_" % k)) == 2, k
-    assert len(fixture_paths("full_cfg")) == 2
+    assert len(fixture_paths("full_cfg")) == 5 and len(fixture_paths("full_worst_cfg3")) == 1      # every BASELINE config at R = 193 374
 
 
 def test_gpu_run_order_puts_the_contract_first(gpu_ids):
@@ -88,4 +88,4 @@ def test_gpu_run_order_puts_the_contract_first(gpu_ids):
     assert known == [m for m in GPU_ORDER if m in known], mods
     assert set(mods) <= set(GPU_ORDER), sorted(set(mods) - set(GPU_ORDER))      # a new GPU test module must be given a place
     first = [i for i in gpu_ids if "test_hip_parity" in i][:12]
-    assert all("test_hip_matches_reference_golden[cfg" in i or "[full_cfg" in i for i in first), first
+    assert all("test_hip_matches_reference_golden[cfg" in i or "[full_cfg" in i or "[full_worst_cfg" in i for i in first), first
