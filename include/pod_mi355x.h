@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POD_ABI_VERSION 13
+#define POD_ABI_VERSION 14
 #define POD_MAX_LEVELS 8
 #define POD_MAX_CLASSES 16       /* K: BDD = 7 (Base-BDD-RetinaNet.yaml:11-12) */
 #define POD_MAX_RUNS 64          /* MC-dropout runs / ensemble members */
@@ -408,7 +408,8 @@ typedef struct PodWinoConv {
     int32_t n_splits;       /* <= 1: off */
     int32_t reserved;
     int64_t split_stride;
-    const int32_t* live_blocks; /* NULL, or pod_sparse_live_blocks' device list {count, record indices ...}: only those records are computed */
+    const int32_t* live_blocks; /* NULL, or pod_sparse_live_blocks' device list {count, ..., entries {record, need bits}}: only those records are
+                                   computed, and the patch pixels whose need bit is clear are read as 0.0 */
     PodConvSet sets[4];
 } PodWinoConv;
 int64_t pod_wino_filter_split_bytes(int32_t K, int32_t C);
@@ -421,12 +422,19 @@ int pod_wino_conv3x3_split(const PodWinoConv* conv, pod_stream_t stream);
  * first: pod_sparse_reach turns pod_level_topk's selection into a per-cell map (one byte per cell of every level, level after level;
  * `scratch` as large) of how many convolution layers below the predictors a cell is still needed (0: a candidate's own cell .. 5; 255:
  * never -- Winograd tiles taken into account); pod_sparse_live_blocks lists the records of a pod_wino_conv3x3 table that hold a cell of
- * reach <= max_reach (rec_level[r] = FPN level of record r) as {count, indices ...} for PodWinoConv.live_blocks.  Needed cells depend on
- * needed cells only: the detections equal the dense tower's (to the last bits where an abs-max record differs in its binade). */
+ * reach <= max_reach (rec_level[r] = FPN level of record r) for PodWinoConv.live_blocks: int32 word 0 = the count, then from word
+ * POD_SPARSE_LIVE_HEAD one entry of POD_SPARSE_LIVE_STRIDE words per live record (order unspecified): {record index, 11 words of NEED
+ * bits: bit 18 py + px <=> pixel (py, px) of the record's 18 x 18 input patch is an image cell of reach <= in_reach}.  The convolution
+ * reads a patch pixel whose bit is clear as 0.0: with in_reach = max_reach + 1 (the reach the layer below was launched with; 255 for a
+ * dense input) a launch never reads what an earlier image left in a buffer, every abs-max record is per image, and the tower's outputs
+ * are a function of the image alone (ABI 14).  Needed cells depend on needed cells only: the detections equal the dense tower's (to the
+ * last bits where an abs-max record differs in its binade). */
+#define POD_SPARSE_LIVE_HEAD 4
+#define POD_SPARSE_LIVE_STRIDE 12
 int pod_sparse_reach(const PodConfig* cfg, const PodLevel* levels, const uint64_t* cat_keys, const int32_t* cat_level, const int32_t* n_total,
                      uint8_t* reach, uint8_t* scratch, pod_stream_t stream);
 int pod_sparse_live_blocks(const PodConfig* cfg, const PodLevel* levels, const int32_t* records, const int32_t* rec_level, int32_t n_records,
-                           const uint8_t* reach, int32_t max_reach, int32_t* live, pod_stream_t stream);
+                           const uint8_t* reach, int32_t max_reach, int32_t in_reach, int32_t* live, pod_stream_t stream);
 /* pod_wino_reduce: the partial sums of an n_splits launch -> bias (K values, zero-padded) + ReLU -> the k_real planes of ONE NCHW image (HW =
  * out_pixels).  Replaces the same reference lines as pod_wino_conv3x3 (detectron2 BottleneckBlock.conv2, FPN.output_convs). */
 int pod_wino_reduce(const float* partials, int32_t n_splits, int64_t split_stride, const float* bias, float* planes, int64_t HW,

@@ -42,20 +42,15 @@ def attach(t: torch.Tensor, w: Optional[torch.Tensor]) -> torch.Tensor:
 
 
 def produced(t: torch.Tensor) -> torch.Tensor:
-    """The record a launch about to write t max'es into (its out_amax), attached to t: a fresh zeroed one -- or, for a PERSISTENT buffer that
-    is only partly rewritten per image (the sparse bbox tower's activations: dead blocks keep an earlier image's values, and they may stand
-    in a live block's patch), the buffer's own never-zeroed record: the maximum over everything ever stored there bounds what is there."""
-    w = getattr(t, "_pod_amax_persistent", None)
+    """The record a launch about to write t max'es into (its out_amax), attached to t: a fresh zeroed one -- or, when t is one slice of a
+    buffer several launches fill (FPN's five levels in one buffer), the record those launches share (`_pod_amax_shared`, itself taken fresh
+    from the pool for every forward).  No record outlives an image: the scale of a split is a function of the image alone (round 6; round
+    5's sparse tower kept a never-zeroed record per buffer, which made an image's roundings depend on the images before it)."""
+    w = getattr(t, "_pod_amax_shared", None)
     if w is None:
         w = word(t.device)
     attach(t, w)
     return w
-
-
-def persistent(t: torch.Tensor) -> torch.Tensor:
-    """Marks t as a persistent, partly rewritten buffer (see `produced`); t must be zero-filled now."""
-    t._pod_amax_persistent = torch.zeros(RECORD, dtype=torch.float32, device=t.device)
-    return t
 
 
 def forget(t: torch.Tensor) -> None:

@@ -267,8 +267,12 @@ def main(argv=None):
     ap.add_argument("--image-root", default="", help="directory of the files named in --coco-json")
     ap.add_argument("--train-dataset", default="bdd_train", help="cfg.DATASETS.TRAIN[0] of the model (AN:53): with --test-dataset it fixes the category map (AN:52-80)")
     ap.add_argument("--test-dataset", default="bdd_val", help="the data set the detections are written for (AN:55, args.test_dataset)")
-    ap.add_argument("--sparse-bbox", action="store_true", help="evaluate the bbox side of the head only over the blocks that can reach a candidate "
-                                                                "(pod_compare_amd/sparse.py; same detections, single-model modes)")
+    ap.add_argument("--dense-bbox", action="store_true",
+                    help="evaluate bbox_subnet / bbox_pred / bbox_cov on every cell, in the reference's order (PR:518-537).  Default since round 6: the "
+                         "SPARSE order -- cls side first, candidates selected (PI:283-308), bbox side only over the blocks that can reach a candidate "
+                         "(PI:310-331 reads nothing else; pod_compare_amd/sparse.py): the same detections, a function of the image alone "
+                         "(tests/test_sparse_tower_gpu.py), 1.3 x the images/s with MC dropout.  --ensemble-per-gpu (one member per GPU) is always dense")
+    ap.add_argument("--sparse-bbox", action="store_true", help="(the default; kept for round-5 command lines)")
     ap.add_argument("--random-seed", type=int, default=0)
     ap.add_argument("--output", default="coco_instances_results.json")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch of a forward from Python instead of replaying a HIP graph per (stream, frame shape)")
@@ -324,7 +328,8 @@ def main(argv=None):
     predictor = build_predictor(cfg) if not args.ensemble_per_gpu else None
     if predictor is not None:
         predictor.return_device = True      # no per-image host sync: records and counts stay in HBM until the gather
-        predictor.sparse_bbox_tower = predictor.sparse_bbox_tower or bool(getattr(args, "sparse_bbox", False))
+        # every image is evaluated on ONE GPU here (image sharding): the sparse order is the default; POD_SPARSE_BBOX=0 / --dense-bbox give the dense one
+        predictor.sparse_bbox_tower = not bool(getattr(args, "dense_bbox", False)) and os.environ.get("POD_SPARSE_BBOX", "1") != "0"
         for m in [predictor.model] + list(predictor.model_list):
             if isinstance(m, modeling.ProbabilisticRetinaNet):
                 m.enable_graphs(not getattr(args, "no_graphs", False))      # one host call per forward instead of ~200 launches

@@ -82,9 +82,15 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     int ks, tb;
     wino_schedule(P.KS, P.n_blocks, ks, tb);
     if (tb >= P.n_blocks) return;
-    if (P.live) {                                                         // sparse launch: slot -> live record (uniform: scalar loads)
+    uint32_t need[2] = {~0u, ~0u};                                        // need bits of this thread's patch pixels (tid, tid + 256): all, unless sparse
+    if (P.live) {                                                         // sparse launch: slot -> live entry {record, need bits} (uniform: scalar loads)
         if (tb >= P.live[0]) return;
-        tb = P.live[1 + tb];
+        const int32_t* const ent = P.live + POD_SPARSE_LIVE_HEAD + (int64_t)POD_SPARSE_LIVE_STRIDE * tb;
+        tb = ent[0];
+        // a patch pixel the layer below did not have to compute for this image reads as 0.0 (k15_sparse_blocks.hip): nothing an earlier
+        // image left in the buffer is ever read, so the launch -- its abs-max record included -- is a function of this image alone
+        need[0] = (uint32_t)ent[1 + (tid >> 5)];
+        need[1] = (uint32_t)ent[9 + (tid >> 5 < 3 ? tid >> 5 : 2)];
     }
     // block record: the images of a (level, launch) stand in a GRID on a virtual canvas, image i at grid cell (i / gcols, i % gcols),
     // top-left canvas pixel (row (H + 1), col (W + 1)): one zero row / column between neighbours is the convolution's padding for
@@ -199,11 +205,13 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // instead of two per lane and piece.
     int* pix_tab = reinterpret_cast<int*>(lds + 2 * WINO_SB_FLOATS + 2 * 3072);       // 324 ints behind the mini stages
 #pragma unroll
-    for (int t = tid; t < 325; t += 256) {
+    for (int it = 0; it < 2; ++it) {
+        const int t = tid + 256 * it;
+        if (t >= 325) break;
         const int py = t / 18, px = t - py * 18, vy = y0 - 1 + py, vx = x0 - 1 + px;
         int m, n;
         const int gy = cell(vy < 0 ? 0 : vy, Hv, rHv, m), gx = cell(vx < 0 ? 0 : vx, Wv, rWv, n), img = m * gcols + n;
-        const bool ok = (t < 324) & (vy >= 0) & (gy < H) & (vx >= 0) & (gx < W) & (n < gcols) & (img < n_img);
+        const bool ok = (t < 324) & (vy >= 0) & (gy < H) & (vx >= 0) & (gx < W) & (n < gcols) & (img < n_img) & (((need[it] >> (t & 31)) & 1u) != 0);
         pix_tab[t] = ok ? img * HWi + gy * W + gx : -1;              // entry 324 = -1: the "no pixel" slots of the fills point here
     }
     __syncthreads();

@@ -10,8 +10,10 @@
 // cells of rows [c.y - 2, c.y + 2] and columns [c.x - 4, c.x + 4] (tile alignment + halo), whatever the tile phase.  Layer by layer,
 // from the predictors (needed: the candidate cells, reach 0) down to the first conv of the subnet (reach 4):
 //     needed(reach j) = candidates (+) box(2 j rows, 4 j columns)
-// and needed cells only ever depend on needed cells of the layer below, so whatever stands in the rest of a live block's patch (stale
-// activations of an earlier image: the buffers are persistent and were zeroed once) influences only outputs nobody reads.
+// and needed cells only ever depend on needed cells of the layer below.  What stands in the REST of a live block's patch influences only
+// outputs nobody reads -- but it would influence the launch's abs-max record (the f16 split's operand scale), so since round 6 a launch
+// reads every input cell the layer below did not have to compute for THIS image as 0.0 (the need bits of k_sparse_live): nothing an
+// earlier image left in a buffer is ever read, the records are per image, and the tower's results are a function of the image alone.
 // reach[cell] = the smallest j with cell in needed(j) (0..POD_SPARSE_MAX_REACH, 255: none), by a separable pass over the candidate mask;
 // a table record (block) is LIVE for reach j iff one of its 256 canvas pixels is an image cell with reach <= j.
 #include "pod_device.h"
@@ -73,18 +75,48 @@ __global__ void __launch_bounds__(256) k_sparse_reach_y(const uint8_t* __restric
     reach[cell] = (uint8_t)best;
 }
 
-// one workgroup per table record: live iff a canvas pixel of the block is an image cell within `max_reach`; live[0] counts, live[1..] lists
+// one workgroup per table record: live iff a canvas pixel of the block is an image cell within `max_reach`.  live[0] counts; entry e (int32
+// words POD_SPARSE_LIVE_HEAD + POD_SPARSE_LIVE_STRIDE e ..) = {record, 11 words of NEED bits}: bit (18 py + px) says that patch pixel (py, px)
+// of the block's 18 x 18 INPUT patch is an image cell the layer below had to compute (reach <= in_reach; >= 255: every cell).  The convolution
+// reads every other patch pixel as 0.0, so a launch never reads what an earlier image left in a block (round 6: the tower's results are
+// a function of the image alone).  Entries are appended in the order the workgroups arrive: the ORDER of the list is unspecified (blocks
+// are independent; nothing downstream depends on it).
 __global__ void __launch_bounds__(256) k_sparse_live(const int4* __restrict__ records, const int32_t* __restrict__ rec_level, SparseGeom G,
-                                                     const uint8_t* __restrict__ reach, int32_t max_reach, int32_t* __restrict__ live) {
+                                                     const uint8_t* __restrict__ reach, int32_t max_reach, int32_t in_reach, int32_t* __restrict__ live) {
+    __shared__ int32_t s_slot;
     const int r = blockIdx.x, t = threadIdx.x;
     const int4 d = records[r];
     const int l = rec_level[r];
     const int gcols = (d.z >> 24) & 0xFF, H = (d.z >> 12) & 0xFFF, W = d.z & 0xFFF, n_img = (d.w >> 24) & 0xFF;
-    const int vy = ((d.w >> 12) & 0xFFF) * 16 + (t >> 4), vx = (d.w & 0xFFF) * 16 + (t & 15);
-    const int m = vy / (H + 1), gy = vy - m * (H + 1), n = vx / (W + 1), gx = vx - n * (W + 1);
-    bool hit = false;
-    if (gy < H && gx < W && n < gcols && m * gcols + n < n_img) hit = reach[G.cell_base[l] + gy * W + gx] <= max_reach;
-    if (__syncthreads_or(hit) && t == 0) live[1 + atomicAdd(&live[0], 1)] = r;
+    const int y0 = ((d.w >> 12) & 0xFFF) * 16, x0 = (d.w & 0xFFF) * 16;
+    const uint8_t* const lr = reach + G.cell_base[l];
+    auto cell_reach = [&](int vy, int vx) {                       // canvas pixel -> reach of its image cell (256: not a cell of any image)
+        if (vy < 0 || vx < 0) return 256;
+        const int m = vy / (H + 1), gy = vy - m * (H + 1), n = vx / (W + 1), gx = vx - n * (W + 1);
+        return (gy < H && gx < W && n < gcols && m * gcols + n < n_img) ? (int)lr[gy * W + gx] : 256;
+    };
+    const bool hit = cell_reach(y0 + (t >> 4), x0 + (t & 15)) <= max_reach;
+    if (!__syncthreads_or(hit)) return;
+    if (t == 0) s_slot = atomicAdd(&live[0], 1);
+    // need bits of the 18 x 18 patch (canvas rows y0 - 1 .. y0 + 16): thread t -> patch pixels t and t + 256
+    const int all = in_reach >= 255;
+    uint64_t b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pp = t + 256 * i, py = pp / 18, px = pp - py * 18;
+        const int rc = pp < 324 ? cell_reach(y0 - 1 + py, x0 - 1 + px) : 256;
+        b[i] = __ballot(rc < 256 && (all || rc <= in_reach));
+    }
+    __syncthreads();
+    int32_t* e = live + POD_SPARSE_LIVE_HEAD + (int64_t)POD_SPARSE_LIVE_STRIDE * s_slot;
+    const int wave = t >> 6;
+    if ((t & 63) == 0) {
+        e[1 + 2 * wave] = (int32_t)(uint32_t)b[0];
+        e[2 + 2 * wave] = (int32_t)(uint32_t)(b[0] >> 32);
+        if (wave == 0) { e[9] = (int32_t)(uint32_t)b[1]; e[10] = (int32_t)(uint32_t)(b[1] >> 32); }
+        if (wave == 1) e[11] = (int32_t)(uint32_t)b[1];
+    }
+    if (t == 0) e[0] = r;
 }
 
 }  // namespace pod
@@ -105,26 +137,28 @@ extern "C" int pod_sparse_reach(const PodConfig* cfg, const PodLevel* levels, co
     }
     G.cell_base[L] = base; G.n_levels = L; G.A = cfg->num_anchors;
     const hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0xFF, (size_t)base, st) != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemsetAsync(reach, 0xFF, (size_t)base, st) != hipSuccess) return POD_E_LAUNCH;
     const int cap = L * cfg->topk;
-    hipLaunchKernelGGL(pod::k_sparse_mark, dim3((cap + 255) / 256), dim3(256), 0, st, cat_keys, cat_level, n_total, cap, G, scratch);
+    hipLaunchKernelGGL(pod::k_sparse_mark, dim3((cap + 255) / 256), dim3(256), 0, st, cat_keys, cat_level, n_total, cap, G, reach);
     POD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pod::k_sparse_reach_x, dim3((base + 255) / 256), dim3(256), 0, st, scratch, reach, G);
+    // x pass: scratch (mask) -> reach (as hx); y pass would race in place, so the mask is first moved out of the way: mask lives in `reach`,
+    // the x pass writes `scratch`, the y pass reads it and writes `reach`
+    hipLaunchKernelGGL(pod::k_sparse_reach_x, dim3((base + 255) / 256), dim3(256), 0, st, reach, scratch, G);
     POD_CHECK_LAUNCH();
-    // (in place would race: x pass -> reach, y pass -> scratch, copy back is avoided by handing the roles round: the caller reads `scratch`?
-    //  no -- keep the contract simple: y pass reads reach (as hx) and writes scratch, then scratch -> reach)
-    hipLaunchKernelGGL(pod::k_sparse_reach_y, dim3((base + 255) / 256), dim3(256), 0, st, reach, scratch, G);
+    hipLaunchKernelGGL(pod::k_sparse_reach_y, dim3((base + 255) / 256), dim3(256), 0, st, scratch, reach, G);
     POD_CHECK_LAUNCH();
-    if (hipMemcpyAsync(reach, scratch, (size_t)base, hipMemcpyDeviceToDevice, st) != hipSuccess) return POD_E_LAUNCH;
     return POD_OK;
 }
 
-// live (device, 1 + n_records int32): [0] <- number of live records, [1 ..] <- their indices (any order), for the blocks of a
-// pod_wino_conv3x3 table (`records`: n_records int32x4) whose record r belongs to level rec_level[r]; max_reach 0 .. 5 (see above).
+// live (device, POD_SPARSE_LIVE_HEAD + POD_SPARSE_LIVE_STRIDE n_records int32): [0] <- number of live records, then one entry per live
+// record (any order): {record index, 11 words of need bits of its 18 x 18 input patch} -- for the blocks of a pod_wino_conv3x3 table
+// (`records`: n_records int32x4) whose record r belongs to level rec_level[r].  max_reach 0 .. 5: reach of the launch's OUTPUT (see above);
+// in_reach: cells of the launch's INPUT with a larger reach are read as 0.0 (normally max_reach + 1: what the layer below computed for
+// this image; 255: the input is dense, e.g. the FPN features in front of the subnet's first convolution).
 extern "C" int pod_sparse_live_blocks(const PodConfig* cfg, const PodLevel* levels, const int32_t* records, const int32_t* rec_level, int32_t n_records,
-                                      const uint8_t* reach, int32_t max_reach, int32_t* live, pod_stream_t stream) {
+                                      const uint8_t* reach, int32_t max_reach, int32_t in_reach, int32_t* live, pod_stream_t stream) {
     if (!cfg || !levels || !records || !rec_level || !reach || !live || n_records < 0 || max_reach < 0 || max_reach > pod::SPARSE_MAX_REACH ||
-        (reinterpret_cast<uintptr_t>(records) & 15u) != 0)
+        in_reach < max_reach || in_reach > 255 || (reinterpret_cast<uintptr_t>(records) & 15u) != 0 || (reinterpret_cast<uintptr_t>(live) & 15u) != 0)
         return POD_E_INVALID;
     const int L = cfg->n_levels;
     if (L < 1 || L > POD_MAX_LEVELS) return POD_E_INVALID;
@@ -136,9 +170,10 @@ extern "C" int pod_sparse_live_blocks(const PodConfig* cfg, const PodLevel* leve
     }
     G.cell_base[L] = base; G.n_levels = L; G.A = cfg->num_anchors;
     const hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(live, 0, 4, st) != hipSuccess) return POD_E_LAUNCH;
+    if (hipMemsetAsync(live, 0, 4 * POD_SPARSE_LIVE_HEAD, st) != hipSuccess) return POD_E_LAUNCH;
     if (n_records == 0) return POD_OK;
-    hipLaunchKernelGGL(pod::k_sparse_live, dim3((unsigned)n_records), dim3(256), 0, st, reinterpret_cast<const int4*>(records), rec_level, G, reach, max_reach, live);
+    hipLaunchKernelGGL(pod::k_sparse_live, dim3((unsigned)n_records), dim3(256), 0, st, reinterpret_cast<const int4*>(records), rec_level, G, reach, max_reach,
+                       in_reach, live);
     POD_CHECK_LAUNCH();
     return POD_OK;
 }

@@ -14,7 +14,7 @@ import torch
 
 from .build import LIB
 
-POD_ABI_VERSION = 13
+POD_ABI_VERSION = 14
 POD_MAX_LEVELS = 8
 POD_MAX_CLASSES = 16
 POD_MAX_RUNS = 64
@@ -131,7 +131,7 @@ def load() -> ctypes.CDLL:
     lib.pod_wino_conv3x3_split.argtypes = [POINTER(PodWinoConv), P]
     lib.pod_absmax.argtypes = [P, c_int64, P, P]
     lib.pod_sparse_reach.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, P, P, P, P]
-    lib.pod_sparse_live_blocks.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, c_int32, P, c_int32, P, P]
+    lib.pod_sparse_live_blocks.argtypes = [POINTER(PodConfig), POINTER(PodLevel), P, P, c_int32, P, c_int32, c_int32, P, P]
     lib.pod_debug_f16_split2.argtypes = [P, c_float, P, c_int64, P]
     lib.pod_wino_reduce.argtypes = [P, c_int32, c_int64, P, P, c_int64, c_int32, c_int32, c_int32, P, P]
     lib.pod_reduce_partials.argtypes = [P, c_int32, c_int64, P, P, P, c_int64, c_int32, c_int32, P, P]

@@ -71,8 +71,12 @@ _MAGIC = b"PODR"
 def write_binary_results(path: str, image_ids, counts: torch.Tensor, records: torch.Tensor, num_classes: int) -> None:
     import numpy as np
     n = len(image_ids)
-    rec = records.detach().cpu().to(torch.float32).contiguous().numpy()
+    rec = records.detach().cpu().to(torch.float32).contiguous().numpy().copy()
     assert rec.shape[0] == n and rec.shape[2] == record_width(num_classes)
+    # rows behind an image's count were never written by K7 (the buffers are torch.empty): zero them, so that the file is a function of the
+    # detections alone (round 6: two topologies of the same run wrote different garbage there)
+    cnt = counts.detach().cpu().to(torch.int64).reshape(-1).numpy()
+    rec[np.arange(rec.shape[1])[None, :] >= cnt[:, None]] = 0.0
     with open(path, "wb") as f:
         f.write(_MAGIC + struct.pack("<IIII", 1, n, int(num_classes), int(rec.shape[1])))
         f.write(np.asarray(list(image_ids), dtype="<i8").tobytes())

@@ -71,9 +71,29 @@ def fold_frozen_bn(module: nn.Module) -> int:
             n += 1
         else:
             n += fold_frozen_bn(child)
-    if n and hasattr(module, "_param_generation"):              # (a model serving HIP graphs: they were captured against the unfolded filters)
-        module._param_generation += 1
+    if n:                                                       # (a model serving HIP graphs: they were captured against the unfolded filters)
+        bump_param_generation()
     return n
+
+
+# Anything that replaces or moves parameter STORAGE without bumping a tensor's version counter -- nn.Module._apply on the model or on ANY of
+# its submodules (model.head.to(...), model.bottom_up.float()), load_state_dict, fold_frozen_bn on a part of the model -- moves this
+# process-wide counter on; every model's graph fingerprint contains it, so graphs captured against the old storage are dropped (ADVICE r5:
+# a counter on the root module alone missed the submodule cases).
+_PARAM_GENERATION = [0]
+
+
+def bump_param_generation() -> None:
+    _PARAM_GENERATION[0] += 1
+
+
+class _TracksStorage(nn.Module):
+    """nn.Module whose `_apply` (to / cuda / float / ...) is seen by the graph fingerprints."""
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        bump_param_generation()
+        return out
 
 
 def _plain_conv(m) -> Optional[nn.Conv2d]:
@@ -335,7 +355,7 @@ def _conv_bn(cin, cout, k, stride=1, padding=0):
     return nn.Sequential(conv, FrozenBatchNorm2d(cout))
 
 
-class Bottleneck(nn.Module):
+class Bottleneck(_TracksStorage):
     def __init__(self, cin, cout, mid, stride):
         super().__init__()
         self.shortcut = _conv_bn(cin, cout, 1, stride) if cin != cout else None
@@ -377,7 +397,7 @@ class Bottleneck(nn.Module):
         return c3(b, h1, w1, relu=True, residual=r), h1, w1
 
 
-class ResNet50(nn.Module):
+class ResNet50(_TracksStorage):
     """res2..res5 of ResNet-50; returns res3, res4, res5 (strides 8, 16, 32)."""
 
     def __init__(self):
@@ -435,7 +455,7 @@ class ResNet50(nn.Module):
         return outs[1:]
 
 
-class FPN(nn.Module):
+class FPN(_TracksStorage):
     """detectron2 FPN (sum fusion, no norm) on res3..res5 + LastLevelP6P7(in_feature='res5')."""
 
     def __init__(self, in_channels=(512, 1024, 2048), out_channels=256):
@@ -488,7 +508,7 @@ class FPN(nn.Module):
             rec, parts, at = amax.word(buf.device), [], 0
             for h, w in hw:
                 parts.append(buf[at:at + h * w])
-                parts[-1]._pod_amax_persistent = rec             # (amax.produced: the launch that writes this slice max'es into the shared record)
+                parts[-1]._pod_amax_shared = rec             # (amax.produced: the launch that writes this slice max'es into the shared record)
                 at += h * w
             wino_cl(self.output[0], l3, h3, w3, relu=False, out=parts[0])
             wino_cl(self.output[1], l4, h4, w4, relu=False, out=parts[1])
@@ -507,7 +527,7 @@ class FPN(nn.Module):
         return [p3, p4, p5, p6, p7]
 
 
-class ProbabilisticRetinaNetHead(nn.Module):
+class ProbabilisticRetinaNetHead(_TracksStorage):
     """PR:365-537."""
 
     def __init__(self, in_channels=256, num_anchors=9, num_classes=7, num_convs=4, prior_prob=0.01,
@@ -600,17 +620,18 @@ class ProbabilisticRetinaNetHead(nn.Module):
         activation as (pixels of all levels x images, C) channels-last, level after level -- `copies` images per level with
         dropout, one without (every copy would be identical).
         live (sparse bbox tower, pod_compare_amd/sparse.py): a LiveBlocks -- layer j is launched over the blocks of reach L - j only;
-        bufs: `new(key, shape)` handing out PERSISTENT zero-initialised buffers (what a dead block holds must be finite: it may stand in
-        a live block's patch)."""
+        bufs: `new(key, shape)` handing out the tower's re-used buffers (only live blocks are written; what dead blocks hold is never read)."""
         from . import hip
-        from .sparse import reach_of_subnet_layer
+        from .sparse import DENSE_INPUT, reach_of_subnet_layer
         from .wino import block_table, level_pixel_offsets
         lib, C, L = hip.load(), x0.shape[1], len(convs)
         t1 = block_table(levels, 1, x0.device)
         off1 = level_pixel_offsets(levels, 1)
         first = self._wino(convs[0])
         # (keyword only when sparse: the convolution objects of the dense path -- a test's fp64 double among them -- need not know it)
-        lv = (lambda table, layer: {}) if live is None else (lambda table, layer: {"live": live(table, reach_of_subnet_layer(layer, L))})
+        # (layer 0 reads the FPN features, which are dense; layer j > 0 reads what layer j - 1 computed for THIS image and nothing else)
+        lv = (lambda table, layer: {}) if live is None else (
+            lambda table, layer: {"live": live(table, reach_of_subnet_layer(layer, L), DENSE_INPUT if layer == 0 else -1)})
         new = (lambda key, shape: torch.empty(shape, dtype=x0.dtype, device=x0.device)) if bufs is None else bufs
         if not dropout:
             y = first(x0, new("t0", tuple(x0.shape)), t1, relu=True, **lv(t1, 0))
@@ -755,15 +776,16 @@ class ProbabilisticRetinaNetHead(nn.Module):
         return x
 
     def sparse_buffers(self, key):
-        """Persistent zero-initialised activation buffers of the sparse bbox tower, per (stream, geometry): new(name, shape)."""
+        """Re-used activation buffers of the sparse bbox tower, per (stream, geometry): new(name, shape)."""
         pool = self._sparse_pool.setdefault(key, {})
 
         def new(name, shape):
             t = pool.get(name)
             if t is None or tuple(t.shape) != tuple(shape):
-                from . import amax
-                # zeroed once; its abs-max record is never zeroed either: it bounds the stale values dead blocks keep (amax.produced)
-                t = pool[name] = amax.persistent(torch.zeros(shape, dtype=torch.float32, device=self.cls_score.weight.device))
+                # zeroed once (a reader of the DENSE tensors finds finite numbers outside the live blocks).  The tower itself never reads
+                # what an earlier image left here: a sparse launch reads the cells the layer below did not compute for this image as 0.0
+                # (the need bits of sparse.LiveBlocks), and every launch gets a fresh abs-max record -- results depend on the image alone
+                t = pool[name] = torch.zeros(shape, dtype=torch.float32, device=self.cls_score.weight.device)
             return t
         return new
 
@@ -908,7 +930,7 @@ class ProbabilisticRetinaNetHead(nn.Module):
         return logits, deltas, (logit_vars if self.compute_cls_var else None), (delta_covs if self.compute_bbox_cov else None)
 
 
-class ProbabilisticRetinaNet(nn.Module):
+class ProbabilisticRetinaNet(_TracksStorage):
     """PR:20-166 (inference side only; `losses` PR:168-333 is training and out of scope)."""
 
     def __init__(self, num_classes=7, dropout_rate=0.0, cls_var_loss="none", cls_var_num_samples=3,
@@ -941,10 +963,9 @@ class ProbabilisticRetinaNet(nn.Module):
         self._graphs: Dict[tuple, tuple] = {}
         self._graph_seen: Dict[tuple, int] = {}
         self._graph_serial = 0
-        self._param_generation = 0
         self._fingerprint_tensors = None
         self._graphs_fingerprint = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_param_generation", module._param_generation + 1))
+        self.register_load_state_dict_post_hook(lambda module, incompatible: bump_param_generation())
 
     @property
     def device(self):
@@ -990,13 +1011,8 @@ class ProbabilisticRetinaNet(nn.Module):
     # (.to(), .cuda(), load_state_dict(assign=True), fold_frozen_bn: all go through _apply / the load hook / module surgery -> the
     # generation counter) and an in-place write (load_state_dict, copy_: bumps the tensors' `_version`).  Both are in the fingerprint;
     # when it moves, every graph is dropped and the next forward re-captures against re-transformed filters.
-    def _apply(self, fn, *a, **kw):
-        out = super()._apply(fn, *a, **kw)
-        self._param_generation = getattr(self, "_param_generation", 0) + 1
-        return out
-
     def _param_fingerprint(self):
-        gen = self._param_generation
+        gen = _PARAM_GENERATION[0]
         ts = self._fingerprint_tensors
         if ts is None or ts[0] != gen:
             ts = self._fingerprint_tensors = (gen, [t for t in list(self.parameters()) + list(self.buffers()) if t is not self.head._epoch])
@@ -1077,6 +1093,9 @@ class ProbabilisticRetinaNet(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: only this thread's calls are policed during the capture (an RCCL watchdog thread polling its events
                 # must not abort it)
+                # (the warm-up forwards attached an abs-max record to a float frame: it is the FIRST frame's, and a capture that found it
+                #  would record no pod_absmax -- every replay would scale the stem's split by that frame's range.  ADVICE r5)
+                amax.forget(static_in)
                 amax.reset()                               # the operand abs-max words of the captured launches come from pools zeroed INSIDE the
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):      # capture: every replay starts from zeroed words
                     if dropout:
@@ -1115,13 +1134,12 @@ class ProbabilisticRetinaNet(nn.Module):
         mc_dropout: dropout active in the head subnets -- the reference's `model.train()` (PI:53-56), which it sets
         whenever MC_DROPOUT.ENABLE is true, also for a single run; default: active iff several runs are requested.
         sparse_bbox: callable (partial HeadOutputs: cls / cls_var set, delta = reg_var = None) -> sparse.LiveBlocks: the bbox side of the
-        head is evaluated only where it can reach a candidate (ProbabilisticRetinaNetHead.forward); not captured into HIP graphs yet."""
+        head is evaluated only where it can reach a candidate (ProbabilisticRetinaNetHead.forward).  The trunk + cls half is replayed as a HIP
+        graph (`cls_part`), the bbox half is enqueued eagerly (its live lists are made per image)."""
         n = num_mc_dropout_runs if num_mc_dropout_runs > 1 else 1
         if mc_dropout is None:
             mc_dropout = n > 1
         dropout = bool(mc_dropout) and self.use_dropout
-        graphs = (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None
-                  and (not dropout or self.head.takes_wino_path()))
         if sparse_bbox is not None:
             return self._bbox_eager(self.cls_part(image, num_mc_dropout_runs, skip_unused_last_run, mc_dropout), sparse_bbox)
         if (self.use_graphs and image.is_cuda and self.device.type == "cuda" and self.head.dropout_replay is None

@@ -12,6 +12,8 @@ from . import hip
 
 # reach of a launch = how many convolution layers its OUTPUT lies below the predictors' output: predictors 0, subnet conv 4 .. conv 1: 1 .. 4
 REACH_PREDICTOR = 0
+DENSE_INPUT = 255                 # in_reach of a launch whose input is dense (the FPN features in front of a subnet's first convolution)
+LIVE_HEAD, LIVE_STRIDE = 4, 12    # include/pod_mi355x.h: POD_SPARSE_LIVE_HEAD / _STRIDE -- {count, -, -, -}, then {record, 11 words of need bits} per live record
 
 
 def reach_of_subnet_layer(layer: int, num_convs: int = 4) -> int:
@@ -27,6 +29,7 @@ class LiveBlocks:
         self.cells = sum(h * w for h, w in hp.shapes)
         self.reach = torch.empty(self.cells, dtype=torch.uint8, device=hp.device)
         scratch = torch.empty_like(self.reach)
+        self._scratch = scratch                                       # (kept until the launches that use it have been enqueued AND this object dies)
         lv = hp._levels_t()
         for l, (h, w) in enumerate(hp.shapes):
             lv[l].H, lv[l].W, lv[l].anchor_base = h, w, hp.anchor_base[l]
@@ -35,16 +38,24 @@ class LiveBlocks:
                                           hip.ptr(scratch), hip.current_stream()), "pod_sparse_reach")
         self._lists: Dict[Tuple[int, int], torch.Tensor] = {}
 
-    def __call__(self, table: torch.Tensor, reach: int) -> torch.Tensor:
-        key = (table.data_ptr(), int(reach))
+    def __call__(self, table: torch.Tensor, reach: int, in_reach: int = -1) -> torch.Tensor:
+        """The device list of `table`'s live records for a launch whose OUTPUT has reach `reach`; cells of its INPUT with a reach above
+        `in_reach` are read as 0.0 (default reach + 1: what the layer below computed for this image; DENSE_INPUT: all of it)."""
+        in_reach = int(reach) + 1 if in_reach < 0 else int(in_reach)
+        key = (table.data_ptr(), int(reach), in_reach)
         live = self._lists.get(key)
         if live is None:
             n = int(table.shape[0])
-            live = torch.empty(1 + n, dtype=torch.int32, device=table.device)
+            live = torch.empty(LIVE_HEAD + LIVE_STRIDE * n, dtype=torch.int32, device=table.device)
             hip.check(self.hp.lib.pod_sparse_live_blocks(self.hp.cfg, self._lv, table.data_ptr(), table.pod_rec_level.data_ptr(), n, hip.ptr(self.reach),
-                                                         int(reach), hip.ptr(live), hip.current_stream()), "pod_sparse_live_blocks")
+                                                         int(reach), in_reach, hip.ptr(live), hip.current_stream()), "pod_sparse_live_blocks")
             self._lists[key] = live
         return live
+
+    def records(self, table: torch.Tensor, reach: int, in_reach: int = -1) -> torch.Tensor:
+        """The live record indices (host sync: tests / diagnostics)."""
+        lst = self(table, reach, in_reach)
+        return lst[LIVE_HEAD:LIVE_HEAD + LIVE_STRIDE * int(lst[0].item())].view(-1, LIVE_STRIDE)[:, 0]
 
     def fraction(self, table: torch.Tensor, reach: int) -> float:
         """Live share of a table (host sync: diagnostics only)."""

@@ -137,9 +137,42 @@ def test_graphs_are_dropped_when_the_parameters_change():
     L = len(m(f).cls)                                                   # tensors(): cls levels, then delta levels, ...
     assert float((c[L] - b[L]).abs().min()) > 0.4
     close([c[0]], [b[0]])
+    gen = modeling._PARAM_GENERATION[0]
     m.float()                                                           # _apply: generation counter
-    assert m._param_generation >= 2
+    assert modeling._PARAM_GENERATION[0] > gen
     close([t.clone() for t in tensors(m(f))], c)
+    # ... and on a SUBMODULE (a counter on the root alone missed it): the head's storage moves, the graph must not replay
+    # against the freed filters
+    fp = m._param_fingerprint()
+    m.head.cuda()                                                       # (what model.head.to(...) calls: nn.Module._apply on the SUBMODULE)
+    m.head._apply(lambda t: t.clone())                                  # new storage for every parameter of the head, versions untouched
+    assert m._param_fingerprint() != fp
+    with torch.no_grad():
+        m.head.cls_score.weight.data = m.head.cls_score.weight.data * 2.0          # (.data: no version bump either)
+        modeling.bump_param_generation()
+    d = [t.clone() for t in tensors(m(f))]
+    m.enable_graphs(False)
+    close(d, tensors(m(f)))
+    assert float((d[0] - c[0]).abs().max()) > 1e-4
+
+
+def test_float_frames_of_different_range_replay_with_their_own_abs_max():
+    """the warm-up forwards of a capture attach an abs-max record to the static input; a capture that re-used it would record no
+    pod_absmax, and every replay would scale the stem's f16 split by the FIRST frame's range -- a later, louder float frame overflows f16.
+    Float32 frames whose ranges differ by 40 x, replayed through one graph, must equal their eager forwards bit for bit."""
+    m = build()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randint(0, 256, (3, 160, 224), dtype=torch.uint8, device="cuda", generator=g).float()
+    frames = [base * 0.05, base, base * 2.0, base * 0.05]
+    eager = [[t.clone() for t in tensors(m(f))] for f in frames]
+    assert all(bool(torch.isfinite(t).all()) for e in eager for t in e)
+    m.enable_graphs()
+    for rep in range(2):
+        for f, e in zip(frames, eager):
+            out = m(f)
+            assert all(bool(torch.isfinite(t).all()) for t in tensors(out))
+            close(out, e)
+    assert len(m._graphs) == 1
 
 
 def test_a_shape_is_captured_only_after_it_came_back():

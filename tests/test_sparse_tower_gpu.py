@@ -64,22 +64,32 @@ def test_reach_map_and_live_lists_equal_a_brute_force_evaluation(mode, runs):
     got = live.reach.cpu().numpy().astype(np.int64)
     assert np.array_equal(got, want)
     levels = [tuple(s) for s in hp.shapes]
-    for copies, reach in ((1, 4), (5, 2), (5, 0)):
+    for copies, reach, in_reach in ((1, 4, 255), (5, 2, 3), (5, 0, 1)):
         table = block_table(levels, copies, "cuda")
-        lst = live(table, reach).cpu().numpy()
+        lst = live(table, reach, in_reach).cpu().numpy()
+        ents = lst[sparse.LIVE_HEAD:sparse.LIVE_HEAD + sparse.LIVE_STRIDE * lst[0]].reshape(-1, sparse.LIVE_STRIDE)
         recs, rl = table.cpu().numpy(), table.pod_rec_level.cpu().numpy()
         base = np.cumsum([0] + [h * w for h, w in levels])
-        expect = set()
+        expect = {}
         for r, (d, l) in enumerate(zip(recs, rl)):
             gcols, H, W, n_img = (d[2] >> 24) & 0xFF, (d[2] >> 12) & 0xFFF, d[2] & 0xFFF, (d[3] >> 24) & 0xFF
             by, bx = (d[3] >> 12) & 0xFFF, d[3] & 0xFFF
-            vy, vx = np.meshgrid(16 * by + np.arange(16), 16 * bx + np.arange(16), indexing="ij")
-            m_, gy, n_, gx = vy // (H + 1), vy % (H + 1), vx // (W + 1), vx % (W + 1)
-            ok = (gy < H) & (gx < W) & (n_ < gcols) & (m_ * gcols + n_ < n_img)
-            cells = base[l] + np.where(ok, gy * W + gx, 0)
+
+            def cells_of(vy, vx):
+                m_, gy, n_, gx = vy // (H + 1), vy % (H + 1), vx // (W + 1), vx % (W + 1)
+                ok = (vy >= 0) & (vx >= 0) & (gy < H) & (gx < W) & (n_ < gcols) & (m_ * gcols + n_ < n_img)
+                return ok, base[l] + np.where(ok, gy * W + gx, 0)
+            ok, cells = cells_of(*np.meshgrid(16 * by + np.arange(16), 16 * bx + np.arange(16), indexing="ij"))
             if bool((ok & (want[cells] <= reach)).any()):
-                expect.add(r)
-        assert set(lst[1:1 + lst[0]].tolist()) == expect and lst[0] == len(expect)
+                # need bits: the 18 x 18 input patch of the block (canvas rows / columns -1 .. 16), row-major
+                okp, cp = cells_of(*np.meshgrid(16 * by - 1 + np.arange(18), 16 * bx - 1 + np.arange(18), indexing="ij"))
+                expect[r] = (okp & (want[cp] <= in_reach)).reshape(-1)
+        assert lst[0] == len(expect) and set(ents[:, 0].tolist()) == set(expect)
+        assert set(live.records(table, reach, in_reach).cpu().tolist()) == set(expect)
+        for e in ents:
+            words = e[1:].astype(np.uint32)
+            bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:324].astype(bool)
+            assert np.array_equal(bits, expect[int(e[0])]), int(e[0])
         if mode == "planted" and reach == 0:
             assert lst[0] < 0.6 * len(recs)                    # a handful of objects: most blocks are dead
 
@@ -192,36 +202,88 @@ def test_ensemble_members_share_one_set_of_live_blocks():
     assert float((a.pred_boxes_covariance - b.pred_boxes_covariance).abs().max()) <= 1e-4 * max(1.0, float(a.pred_boxes_covariance.abs().max()))
 
 
-def test_stale_blocks_of_a_louder_image_cannot_overflow_the_next_images_scale():
-    """The sparse tower's activation buffers are persistent and only their live blocks are rewritten per image.  A frame whose activations
-    are 50 x larger leaves such values in the blocks that are dead for the NEXT frame -- inside live blocks' patches.  The buffers' abs-max
-    records are never zeroed (they bound everything ever stored), so the quiet frame's detections are finite and equal its dense ones."""
-    m = build(dropout_rate=0.0)
-    pl = planted((256, 384), 1, seed=9)
-    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=1, has_cls_var=True, cov_dims=4, device="cuda:0")
+@pytest.mark.parametrize("dropout,runs", [(0.0, 1), (0.2, 4)])
+def test_sparse_results_do_not_depend_on_the_images_before(dropout, runs):
+    """Round 6: the sparse tower is a function of the image alone.  A frame whose activations are 50 x larger, with its
+    candidates elsewhere, runs first -- it leaves loud values in the blocks that are dead for the NEXT frame, inside live blocks' patches,
+    in the tower's re-used buffers.  The quiet frame after it must give, BIT FOR BIT, what it gives in a session that never saw the loud
+    one: box deltas / variances at the candidates, boxes, covariances, keep list, detections.  (A sparse launch reads the cells the layer
+    below did not compute for this image as 0.0 and every launch max'es into a fresh abs-max record; round 5 read the stale values and kept
+    one never-zeroed record per buffer.)  And it still equals the dense tower's detections to the parity bar."""
+    m = build(dropout_rate=dropout)
+    mc = dropout > 0
+    kw = dict(num_mc_dropout_runs=runs if mc else -1, mc_dropout=mc, skip_unused_last_run=mc)
+    n_runs = runs if mc else 1
+    pl = planted((256, 384), n_runs, seed=9)
+    other = planted((256, 384), n_runs, seed=21)         # the loud frame's candidates lie elsewhere: its live blocks are the quiet frame's dead ones
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=n_runs, has_cls_var=True, cov_dims=4, device="cuda:0")
     g = torch.Generator(device="cuda").manual_seed(3)
     quiet = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=g).float()
     loud = quiet * 50.0
-    outs = {}
 
     def run(frame, sparse_on, who):
+        m.head._drop_calls = 0                            # the same dropout masks for every evaluation of the frame
+        if m.head._epoch is not None:
+            m.head._epoch.zero_()
+
         def hook(partial):
             hp.select(who.cls, who.cls_var, draw_id=5)
             return sparse.LiveBlocks(hp)
         if sparse_on:
-            ho = m(frame, sparse_bbox=hook)
-            return hp.finish("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384)), ho
-        ho = m(frame)
-        return hp.run_image("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384), draw_id=5), ho
+            ho = m(frame, sparse_bbox=hook, **kw)
+            det = hp.finish("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384))
+        else:
+            ho = m(frame, **kw)
+            det = hp.run_image("bayes_od", who.cls, ho.delta, who.cls_var, ho.reg_var, (256, 384), (256, 384), draw_id=5)
+        n, k = int(hp.n_total.item()), det.count()
+        nk = int(hp.n_keep.item())
+        return {"n": n, "k": k, "cand_delta": hp.cand_delta[:n].clone(), "cand_reg_var": hp.cand_reg_var[:n].clone(), "cand_boxes": hp.boxes[:n].clone(),
+                "cand_cov": hp.cov[:n].clone(), "keep": hp.keep[:nk].clone(), "boxes": det.boxes[:k].clone(), "cov": det.cov[:k].clone(),
+                "classes": det.classes[:k].clone(), "scores": det.scores[:k].clone(), "finite": all(bool(torch.isfinite(t).all()) for t in ho.delta + ho.reg_var)}
 
-    other = planted((256, 384), 1, seed=21)              # the loud frame's candidates lie elsewhere: its live blocks are the quiet frame's dead ones
+    alone = run(quiet, True, pl)                          # a fresh model: the quiet frame is the first image the tower ever sees
     run(loud, True, other)
-    got, ho = run(quiet, True, pl)
-    want, _ = run(quiet, False, pl)
-    assert all(bool(torch.isfinite(t).all()) for t in ho.delta + ho.reg_var)
-    k = got.count()
-    assert k == want.count() and k > 0 and torch.equal(got.classes[:k], want.classes[:k])
-    assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
+    after = run(quiet, True, pl)
+    assert after["finite"] and alone["n"] == after["n"] > 20 and alone["k"] == after["k"] > 0
+    for name in ("cand_delta", "cand_reg_var", "cand_boxes", "cand_cov", "keep", "boxes", "cov", "classes", "scores"):
+        assert torch.equal(alone[name], after[name]), name
+    # ... twice more, the other way round (quiet, quiet): still the same bits
+    again = run(quiet, True, pl)
+    for name in ("cand_delta", "cand_reg_var", "boxes", "cov", "keep"):
+        assert torch.equal(alone[name], again[name]), name
+    want = run(quiet, False, pl)
+    assert want["k"] == after["k"] and torch.equal(want["classes"], after["classes"]) and torch.equal(want["keep"], after["keep"])
+    assert float((after["boxes"] - want["boxes"]).abs().max()) <= 1e-4 * max(1.0, float(want["boxes"].abs().max()))
+    assert float((after["cov"] - want["cov"]).abs().max()) <= 1e-4 * max(1.0, float(want["cov"].abs().max()))
+
+
+def test_no_sparse_launch_reads_what_an_earlier_image_left():
+    """The same property at the source: poison the tower's re-used buffers with NaN between two evaluations of a frame -- every value the
+    second evaluation's candidates read is computed from this image (needed cells) or read as 0.0 (need bits), so nothing changes."""
+    m = build(dropout_rate=0.0)
+    pl = planted((256, 384), 1, seed=9)
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=1, has_cls_var=True, cov_dims=4, device="cuda:0")
+    frame = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+
+    def run():
+        def hook(partial):
+            hp.select(pl.cls, pl.cls_var, draw_id=5)
+            return sparse.LiveBlocks(hp)
+        ho = m(frame, sparse_bbox=hook)
+        det = hp.finish("bayes_od", pl.cls, ho.delta, pl.cls_var, ho.reg_var, (256, 384), (256, 384))
+        n, k = int(hp.n_total.item()), det.count()
+        return hp.cand_delta[:n].clone(), hp.cand_reg_var[:n].clone(), det.boxes[:k].clone(), det.cov[:k].clone()
+
+    first = run()
+    pools = list(m.head._sparse_pool.values())
+    assert pools and all(len(p) > 0 for p in pools)
+    for pool in pools:
+        for t in pool.values():
+            t.fill_(float("nan"))
+    second = run()
+    assert len(first[2]) > 0
+    for a, b in zip(first, second):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
 
 
 def test_plain_model_without_variance_heads_takes_the_sparse_order_too():
