@@ -385,6 +385,12 @@ int pod_absmax(const float* x, int64_t n, float* amax, pod_stream_t stream);
  *     are cut into n_splits ranges of whole 32-channel super-chunks, one workgroup set each (grid.y): sets[0].out receives n_splits
  *     channels-last (out_pixels, K) arrays of partial sums (no bias / ReLU / dropout), split_stride floats apart; pod_wino_reduce /
  *     pod_reduce_partials add them in a fixed order. */
+/* PodWinoConv.form: 0 or POD_WINO_FORM_4 = the shipped kernel (csrc/k12_wino_conv_split.hip: four wavefronts, one per SIMD, six Winograd
+ * positions each).  POD_WINO_FORM_8 exists in round 6's EXPERIMENT builds only (tools/experiments/k16_wino_conv_split8.hip: eight wavefronts,
+ * two per SIMD sharing a row of the position grid; bit-identical results, measured 5 - 8 % slower on every launch shape:
+ * profiles/r06_k16_two_wavefronts_per_simd.md); the shipped library answers POD_E_INVALID for it. */
+#define POD_WINO_FORM_4 4
+#define POD_WINO_FORM_8 8
 typedef struct PodConvSet {
     const float* in;        /* channels-last activations [pixel][C] */
     float* out;             /* channels-last [pixel][K], NCHW planes (k_planes > 0) or partial sums (n_splits > 1) */
@@ -406,7 +412,7 @@ typedef struct PodWinoConv {
     uint64_t seed;
     const uint64_t* epoch;  /* NULL or the device word folded into the Philox key (pod_expand_dropout) */
     int32_t n_splits;       /* <= 1: off */
-    int32_t reserved;
+    int32_t form;           /* 0 (or POD_WINO_FORM_4): the shipped kernel; POD_WINO_FORM_8: experiment builds only (see above) */
     int64_t split_stride;
     const int32_t* live_blocks; /* NULL, or pod_sparse_live_blocks' device list {count, ..., entries {record, need bits}}: only those records are
                                    computed, and the patch pixels whose need bit is clear are read as 0.0 */

@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 # per-source extras.  k12: its transform arithmetic is slotted behind bf16 MFMAs, where a packed fp32 instruction (what the SLP vectoriser
 # makes of neighbouring scalar operations) costs ~40 cycles and a scalar one nothing (tools/mfma_bf16_split.hip)
-SOURCE_FLAGS = {"k12_wino_conv_split.hip": ["-fno-slp-vectorize"], "k13_conv1x1_split.hip": ["-fno-slp-vectorize"], "k14_stem_conv.hip": ["-fno-slp-vectorize"]}
+SOURCE_FLAGS = {"k12_wino_conv_split.hip": ["-fno-slp-vectorize"], "k16_wino_conv_split8.hip": ["-fno-slp-vectorize"], "k13_conv1x1_split.hip": ["-fno-slp-vectorize"], "k14_stem_conv.hip": ["-fno-slp-vectorize"]}
 
 
 def _flags(tagged: bool):
@@ -65,14 +65,19 @@ def build_library(force: bool = False, verbose: bool = False, tag: str = "") -> 
     if only:
         build_library(verbose=verbose, tag="__shipped__")
     objs = []
-    for src in SOURCES:
+    sources = list(SOURCES)
+    k16 = bool(tag) and os.environ.get("POD_WITH_K16") == "1"
+    if k16:      # round 6's experiment (tools/experiments/k16_wino_conv_split8.hip: the eight-wavefront form of pod_wino_conv3x3_split; measured, not shipped)
+        sources.append(os.path.join("..", "..", "tools", "experiments", "k16_wino_conv_split8.hip"))
+    for src in sources:
         s = os.path.join(CSRC, src)
+        src = os.path.basename(src)
         o = os.path.join(libdir if (not only or src in only) else LIBDIR, src.replace(".hip", ".o"))
         if only and src not in only:
             objs.append(o)
             continue
         if force or _stale(o, [s] + HEADERS):
-            cmd = [_hipcc()] + _flags(bool(tag)) + SOURCE_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [_hipcc()] + _flags(bool(tag)) + (["-DPOD_WITH_K16", "-I" + CSRC] if k16 else []) + SOURCE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -778,7 +778,8 @@ static int wino_split_prepare() {        // the kernel's dynamic LDS size, once 
 // convolution cut over its input channels into partial sums.  See include/pod_mi355x.h: PodWinoConv.
 extern "C" int pod_wino_conv3x3_split(const PodWinoConv* d, pod_stream_t stream) {
     if (!d || d->n_sets < 1 || d->n_sets > 4 || !d->blocks || d->n_blocks < 0 || d->C < 16 || (d->C & 15) != 0 || d->K < 64 || (d->K & 63) != 0 ||
-        !(d->p >= 0.0f && d->p < 1.0f) || d->sets[0].first_block != 0 || (reinterpret_cast<uintptr_t>(d->blocks) & 15u) != 0)
+        !(d->p >= 0.0f && d->p < 1.0f) || d->sets[0].first_block != 0 || (reinterpret_cast<uintptr_t>(d->blocks) & 15u) != 0 ||
+        (d->form != 0 && d->form != POD_WINO_FORM_4 && d->form != POD_WINO_FORM_8))
         return POD_E_INVALID;
     const int32_t C = d->C, K = d->K, KS = K / 64;
     if (KS != 1 && KS != 2 && KS != 4 && KS != 8) return POD_E_INVALID;
@@ -817,6 +818,13 @@ extern "C" int pod_wino_conv3x3_split(const PodWinoConv* d, pod_stream_t stream)
     P.live = d->live_blocks;
     const int64_t grid = pod::wino_grid(KS, d->n_blocks);
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
+    if (d->form == POD_WINO_FORM_8) {                   // round 6's experiment build only (tools/experiments/k16_wino_conv_split8.hip: measured 5 - 8 % slower)
+#ifdef POD_WITH_K16
+        return pod::wino_split8_launch(P, grid, partial ? (unsigned)d->n_splits : 1u, (hipStream_t)stream);
+#else
+        return POD_E_INVALID;
+#endif
+    }
     hipLaunchKernelGGL(pod::k_wino_conv3x3_split, dim3((unsigned)grid, partial ? (unsigned)d->n_splits : 1u), dim3(256), pod::WINO_LDS_BYTES, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     return POD_OK;

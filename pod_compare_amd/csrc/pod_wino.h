@@ -221,6 +221,9 @@ __device__ __forceinline__ float wino_reduce_amax(float v) {                    
 }
 __device__ __forceinline__ float wino_read_amax(const float* rec) { return wino_reduce_amax(wino_load_amax(rec)); }
 
+// the eight-wavefront form of pod_wino_conv3x3_split (tools/experiments/k16_wino_conv_split8.hip, -DPOD_WITH_K16 builds); P as k12's entry validated and filled it
+int wino_split8_launch(const WinoParams& P, int64_t grid, unsigned grid_y, hipStream_t stream);
+
 template <typename F, int... Js>
 __device__ __forceinline__ void wino_static_for(F&& f, std::integer_sequence<int, Js...>) {
     (f(std::integral_constant<int, Js>{}), ...);

@@ -69,7 +69,7 @@ class PodConvSet(Structure):
 class PodWinoConv(Structure):
     """include/pod_mi355x.h: PodWinoConv."""
     _fields_ = [("blocks", c_void_p), ("n_blocks", c_int32), ("n_sets", c_int32), ("C", c_int32), ("K", c_int32), ("relu", c_int32), ("p", c_float),
-                ("seed", c_uint64), ("epoch", c_void_p), ("n_splits", c_int32), ("reserved", c_int32), ("split_stride", c_int64), ("live_blocks", c_void_p),
+                ("seed", c_uint64), ("epoch", c_void_p), ("n_splits", c_int32), ("form", c_int32), ("split_stride", c_int64), ("live_blocks", c_void_p),
                 ("sets", PodConvSet * 4)]
 
 

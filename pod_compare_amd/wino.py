@@ -107,6 +107,8 @@ def block_table(levels: Sequence[Tuple[int, int]], copies: int, device, in_copie
 # Its contract is tested, not assumed (tests/test_wino_conv_gpu.py): x s == x0 + x1 to 2^-23 |x s|, and on every benchmark shape its error
 # against an fp64 convolution is no larger than the fp32-MFMA kernel's.  POD_WINO_SPLIT=0: pod_wino_conv3x3 (fp32 matrix instructions) everywhere.
 SPLIT_BF16 = os.environ.get("POD_WINO_SPLIT", "1") != "0"      # (the name is rounds 3-4's; the switch selects the split kernel, whatever its terms)
+# Workgroup form of the split kernel (include/pod_mi355x.h: POD_WINO_FORM_4 / _8; bit-identical results): 0 = the library's default
+FORM = int(os.environ.get("POD_WINO_FORM", "0"))
 
 
 def _launch_split(sets, table: torch.Tensor, firsts, C: int, Kpad: int, relu: bool, dropout_p: float, seed: int, epoch, n_splits: int = 0,
@@ -116,7 +118,7 @@ def _launch_split(sets, table: torch.Tensor, firsts, C: int, Kpad: int, relu: bo
     d = hip.PodWinoConv()
     d.blocks, d.n_blocks, d.n_sets = table.data_ptr(), int(table.shape[0]), len(sets)
     d.C, d.K, d.relu, d.p, d.seed, d.epoch = C, Kpad, 1 if relu else 0, float(dropout_p), int(seed), hip.ptr(epoch)
-    d.n_splits, d.split_stride, d.live_blocks = int(n_splits), int(split_stride), hip.ptr(live)
+    d.n_splits, d.split_stride, d.live_blocks, d.form = int(n_splits), int(split_stride), hip.ptr(live), FORM
     for i, s in enumerate(sets):
         q, conv = d.sets[i], s["conv"]
         planes = bool(s.get("planes", False))

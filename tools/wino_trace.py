@@ -28,7 +28,9 @@ torch.cuda.synchronize()
 n_wg = tab.shape[0] * 4
 lib = ctypes.CDLL(hip.library_path())
 host = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
-dump = lib.pod_wino_trace_dump_split if conv.split else lib.pod_wino_trace_dump
+import os  # noqa: E402
+form8 = os.environ.get("POD_WINO_FORM") == "8"      # the eight-wavefront form keeps its own stamps (k16_wino_conv_split8.hip)
+dump = (lib.pod_wino_trace_dump_split8 if form8 else lib.pod_wino_trace_dump_split) if conv.split else lib.pod_wino_trace_dump
 dump.argtypes = [ctypes.c_void_p, ctypes.c_int32]
 assert dump(host.ctypes.data, host.shape[0]) == 0
 t = host[:, :6]
