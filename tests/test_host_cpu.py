@@ -262,7 +262,9 @@ def test_binary_sidecar_round_trip_equals_the_json_records(tmp_path):
     path = str(tmp_path / "results.podr")
     inference_utils.write_binary_results(path, ids, counts, rec, K)
     ids2, counts2, rec2, k2 = inference_utils.read_binary_results(path)
-    assert ids2 == ids and k2 == K and torch.equal(counts2, counts) and torch.equal(rec2, rec)
+    assert ids2 == ids and k2 == K and torch.equal(counts2, counts)
+    for i, c in enumerate(counts.tolist()):          # the rows K7 wrote travel unchanged; rows behind the count (never written: torch.empty) are zeroed,
+        assert torch.equal(rec2[i, :c], rec[i, :c]) and float(rec2[i, c:].abs().sum()) == 0.0      # so the file is a function of the detections alone
     want = apply_net.results_json(ids, counts, rec, K, apply_net.BDD_CAT_MAP)
     got = inference_utils.binary_results_to_json(path, apply_net.BDD_CAT_MAP)
     assert got == want and len(got) == 103
