@@ -376,6 +376,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the rank's host threads next to its GPU (enqueue thread, torch's intra-op threads of the CPU baseline): pod_compare_amd/hostbind.py;
+    # with several ranks on a node only -- a single rank keeps the whole machine (its CPU-baseline leg uses 32 threads, AN:33-40)
+    from pod_compare_amd import hostbind
+    host_binding = hostbind.bind_rank_to_gpu_numa(local_rank, enable=None if world > 1 else False)
     dist = None
     # POD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group on device_id, device check, flush all_gather, barriers)
     # even with one rank -- under `torch.distributed.run --nproc-per-node 1` this is RCCL's first contact on a one-GPU box
@@ -617,7 +621,7 @@ def main():
                                                 "the head does not compute those 3 of its 4N subnet evaluations",
                    "members_on_this_gpu": len(members),
                    "images_per_gpu_step": 1, "streams_per_gpu": n_streams, "parallelism": "image-sharded dp%d" % world,
-                   "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices,
+                   "rccl_ranks": world, "collective_backend": backend if multi else None, "rank_devices": rank_devices, "host_binding": host_binding,
                    "ranks_share_one_gpu": bool(share and world > 1),
                    "conv3x3_kernel": "pod_wino_conv3x3_split (fp32 Winograd; every product from 2-way f16 splits of the scaled operands on the f16 matrix cores, 3 partial "
                                      "products, fp32 accumulate; per shape at least as close to fp64 as the fp32-MFMA kernel: tests/test_wino_conv_gpu.py); "

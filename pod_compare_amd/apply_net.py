@@ -307,6 +307,10 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
+    if world > 1:                 # enqueue + loader threads of this rank on its GPU's NUMA node (hostbind.py; POD_BIND_NUMA=0: off)
+        from . import hostbind
+        b = hostbind.bind_rank_to_gpu_numa(local_rank)
+        print("rank %d: cuda:%d pci %s numa node %s -> %s" % (rank, local_rank, b["pci"], b["numa_node"], b["cpus"] if b["bound"] else "not bound (%s)" % b.get("why_not", "off")))
     cfg = setup_config(args.config_file, args.inference_config, args.random_seed, data_dir=args.data_dir, is_testing=bool(args.data_dir))
     if args.weights is not None:
         cfg.MODEL.WEIGHTS = args.weights

@@ -396,3 +396,20 @@ def test_category_mapping_follows_the_reference_tables():
     rec[:, 5] = torch.tensor([0.0, 1.0, 3.0])                                   # car, bus, person
     out = records_to_json(rec, 3, 5, 7, category_mapping("bdd_train", "kitti_val"))
     assert [d["category_id"] for d in out] == [1, 2]
+
+
+def test_host_binding_reads_the_numa_node_from_sysfs(tmp_path):
+    """hostbind: the GPU's NUMA node and that node's CPU list come from sysfs; a box without the entries is left alone (and says so)."""
+    from pod_compare_amd import hostbind
+    sysfs = tmp_path / "sys"
+    (sysfs / "bus/pci/devices/0000:c1:00.0").mkdir(parents=True)
+    (sysfs / "bus/pci/devices/0000:c1:00.0/numa_node").write_text("1\n")
+    (sysfs / "devices/system/node/node1").mkdir(parents=True)
+    (sysfs / "devices/system/node/node1/cpulist").write_text("2-3,66-67\n")
+    assert hostbind.numa_node_of("0000:c1:00.0", str(sysfs)) == 1
+    assert hostbind.cpus_of_node(1, str(sysfs)) == [2, 3, 66, 67]
+    assert hostbind.numa_node_of("0000:c2:00.0", str(sysfs)) is None and hostbind.numa_node_of(None, str(sysfs)) is None
+    (sysfs / "bus/pci/devices/0000:c3:00.0").mkdir(parents=True)
+    (sysfs / "bus/pci/devices/0000:c3:00.0/numa_node").write_text("-1\n")
+    assert hostbind.numa_node_of("0000:c3:00.0", str(sysfs)) is None          # single-node host: the kernel reports -1
+    assert hostbind._parse_cpulist("0-2,8,10-11") == [0, 1, 2, 8, 10, 11]
