@@ -486,18 +486,8 @@ int pod_match_groundtruth(const float* det_boxes, const float* det_probs, const 
  * (-MVN(mean, cov + 1e-2 I).log_prob(gt), the "NLL parity" half of the metric). */
 int pod_reg_nll(const float* means, const float* covs, const float* gt, int32_t n, float* nll, pod_stream_t stream);
 
-/* ---- test support: the native-RNG draws, written out ---------------------------------------------
- * The in-kernel Philox draws that replace Normal(...).rsample((cls_samples,)) PI:291-294 and
- * MultivariateNormal(...).rsample((1000,)) PI:351-356 are never stored by the product path.  These two entry points
- * evaluate the same counter -> normal maps for the Philox key in cfg->philox_seed and write them in the reference's
- * tensor layouts, so a test can feed the CPU oracle exactly the draws pod_run_image used:
- *   pod_dump_cls_normals: eps_cls dev (cls_samples, H_l*W_l*A, K) of level `level`;
- *   pod_dump_box_normals: eps_prop dev (prop_samples, n, 4), row i = the draws of global anchor id
- *                         global_anchor_ids[i] (= anchor_base_l + index inside the level). */
-int pod_dump_cls_normals(const PodConfig* cfg, const PodLevel* levels, int32_t level, float* eps_cls, pod_stream_t stream);
-int pod_dump_box_normals(const PodConfig* cfg, const int32_t* global_anchor_ids, int32_t n, float* eps_prop, pod_stream_t stream);
-/* test support for the split kernels' arithmetic contract (tests/test_wino_conv_gpu.py): terms[2][n] f16 bit patterns (dev uint16, n even): x[i] * scale = t0 + t1 to 2^-23 |x[i] scale| (scale a power of two; the round-5 split kernels' own code) */
-int pod_debug_f16_split2(const float* x, float scale, void* terms, int64_t n, pod_stream_t stream);
+/* (test support -- the dumps of the in-kernel Philox draws and of the f16 split -- is declared in include/pod_mi355x_test.h: the library
+ * exports those three entry points for tests/ and tools/, they are not part of the drop-in boundary.) */
 
 /* ---- K13 conv1x1_split (round 4): the 1x1 convolutions of the backbone / FPN as a channels-last GEMM ------------------------
  * Replaces: detectron2 BottleneckBlock.conv1 / conv3 / shortcut (1x1, stride 1 or 2, FrozenBN folded, ReLU, residual add) and

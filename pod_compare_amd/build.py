@@ -13,7 +13,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpod_mi355x.so")
 SOURCES = ["k1_mc_merge_score.hip", "k1f_merge_score_fused.hip", "k2_topk_gather.hip", "k3_decode_cov.hip", "k4_nms.hip", "k5_cluster_merge.hip",
            "k8_model_ops.hip", "k9_eval_match.hip", "k10_debug_dump.hip", "k11_wino_conv.hip", "k12_wino_conv_split.hip", "k13_conv1x1_split.hip", "k14_stem_conv.hip", "k15_sparse_blocks.hip", "pod_run.hip"]
-HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(CSRC, "pod_candidate.h"), os.path.join(CSRC, "pod_wino.h"), os.path.join(os.path.dirname(HERE), "include", "pod_mi355x.h")]
+HEADERS = [os.path.join(CSRC, "pod_device.h"), os.path.join(CSRC, "pod_candidate.h"), os.path.join(CSRC, "pod_wino.h"), os.path.join(os.path.dirname(HERE), "include", "pod_mi355x.h"),
+           os.path.join(os.path.dirname(HERE), "include", "pod_mi355x_test.h"), os.path.join(CSRC, "pod_experiments.h")]
 # -ffp-contract=off: the CPU reference rounds after every op; index parity needs the same fp32 values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -8,6 +8,7 @@
 // so that a test can hand the oracle exactly the draws the product kernels used and compare the two end to end
 // (tests/test_native_exact_gpu.py).  Not on the inference path; nothing else calls them.
 #include "pod_device.h"
+#include "../../include/pod_mi355x_test.h"
 #include "pod_wino.h"
 
 namespace pod {

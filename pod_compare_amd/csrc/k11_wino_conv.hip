@@ -178,8 +178,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     }
     __syncthreads();
     auto byte_offset = [&](int pix, int part4) {
-        int o = pix >= 0 ? (pix * P.in_stride + part4) * 4 : ((POD_WINO_VAR & 4) ? part4 * 4 : 0x7FFFFF00);
-        if (POD_WINO_VAR & 8) o &= 0x3FFFF;          // (experiment: every piece from the same 256 KB)
+        const int o = pix >= 0 ? (pix * P.in_stride + part4) * 4 : 0x7FFFFF00;
         return o;
     };
     // The first two chunks come from two MINI stages (8 channels each, 324 pixels x 32 B, 3 LDS-DMA instructions per wave each), so the
@@ -211,12 +210,12 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     f32x16 acc[12];                                                      // [p][kb]; never cleared: chunk 0's first k-step multiplies into a zero C
 
     f32x4 x[12], uB[12], vA[6], vB[6], t[6], w6[4];                      // x[row][c], u[p][kb] (uA: above), v[p]: 4 channels each
-#if POD_WINO_ELIM
+    if (POD_WINO_ELIM) {                                                  // (elimination builds: operands that were never loaded still need values)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = uA[i] = uB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
+        for (int i = 0; i < 12; ++i) x[i] = uA[i] = uB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane + i);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) vA[i] = vB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane - i);
-#endif
+        for (int i = 0; i < 6; ++i) vA[i] = vB[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f} * (float)(lane - i);
+    }
     // 12 pieces: one ds_read_b128 each, stage par, chunk c of its super-chunk.  Issued as asm: hipcc orders every LDS read it can
     // see behind ALL pending LDS-DMA (vmcnt(0): it cannot tell the two stages apart), which would drain the pieces flying into the
     // other stage; so the reads are hidden from it and their completion is counted by hand (WINO_WAIT_LGKM0 before the transform).
@@ -305,13 +304,6 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     WINO_READ_MINI(0, 6); WINO_READ_MINI(0, 7); WINO_READ_MINI(0, 8); WINO_READ_MINI(0, 9); WINO_READ_MINI(0, 10); WINO_READ_MINI(0, 11);
     __builtin_amdgcn_s_waitcnt(WINO_WAIT_LGKM0);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef POD_WINO_DEBUG_X
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(P.out + (tid * 12 + i) * 4) = x[i];
-    }
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < 10; ++i) transform_piece(vA, i);
     // the transform's packed instructions are asm: hipcc neither pads the VALU-write -> MFMA-operand hazard behind them nor keeps the
@@ -343,7 +335,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         }, std::make_integer_sequence<int, 48>{});
         if (!(POD_WINO_ELIM & 16)) {
             // the filters of the next chunk and every patch piece issued before this chunk have landed; this chunk's 4 pieces may fly on
-            __builtin_amdgcn_s_waitcnt((POD_WINO_VAR & 16) ? WINO_WAIT_VM16 : c != 2 && !(POD_WINO_VAR & 2) ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
+            __builtin_amdgcn_s_waitcnt(c != 2 ? WINO_WAIT_VM4 : WINO_WAIT_VM0);
             __builtin_amdgcn_s_barrier();
         }
     };
@@ -365,11 +357,11 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
     // Every wave applies At4 to its row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS
     // (130 KB); the store pass combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],
     // Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
-#if POD_WINO_ELIM & 128
+    if (POD_WINO_ELIM & 128) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
-    return;
-#endif
+        for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
+        return;
+    }
     // The MFMAs run with the FILTER as the row operand: a lane's accumulator register reg of block (p, kb) is channel
     // 32 kb + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of tile lane & 31 -- four consecutive channels per register quad, so the
     // transform runs on packed pairs and a 16-byte store parks 4 channels.  Staging: Z[a][tile][column e][64 channels], a tile's 4 x 64
@@ -391,9 +383,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3(const WinoParams P) {
         }
     __syncthreads();
     WINO_STAMP(4);
-#if POD_WINO_ELIM & 32
-    return;
-#endif
+    if (POD_WINO_ELIM & 32) return;
     constexpr int ZA = 32 * TS;                // floats per position row a
     if (P.k_planes > 0) {
         // NCHW planes: thread -> (channel, row of the block, 4 pixels along x = one tile's columns); 64-byte runs per (channel, row)

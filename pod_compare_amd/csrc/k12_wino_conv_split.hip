@@ -129,16 +129,14 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(set_U) + ((int64_t)ks * nchunk_all + chunk0) * WINO_US_BYTES), 0,
                                                           nchunk * WINO_US_BYTES, 0x00020000);
     const int u_off = (a * 6 * 4 * 64 + h * 32 + i32) * 16;              // + ((p*2 + kb)*2 + term) KB, + chunk * 96 KB
-#ifndef POD_WINO_U_LEAD
-#define POD_WINO_U_LEAD 3      // positions the filter loads run ahead of their MFMAs (a position's 6 MFMAs last 192 cycles, an L2 round trip under load ~3x that)
-#endif
+    constexpr int WINO_U_LEAD = 3;   // positions the filter loads run ahead of their MFMAs (a position's 6 MFMAs last 192 cycles, an L2 round trip under load ~3x that)
     vu32x4 uP[6][4];                                                       // the filter terms of position p live in uP[p % 3]: [kb][term]; loaded TWO positions ahead (a position's
                                                                           // 6 MFMAs last 192 cycles, an L2 round trip under load longer)
     auto filter_piece = [&](int q16, int p, vu32x4(&u)[4], int i) {       // i = kb*2 + term: one buffer_load_dwordx4 (8 f16) each
         u[i] = __builtin_bit_cast(vu32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off, q16 * WINO_US_BYTES + (p * 4 + i) * 1024, 0));
     };
 #pragma unroll
-    for (int pp = 0; pp < POD_WINO_U_LEAD; ++pp)
+    for (int pp = 0; pp < WINO_U_LEAD; ++pp)
 #pragma unroll
         for (int i = 0; i < 4; ++i) filter_piece(0, pp, uP[pp], i);
     const int4 desc = P.blocks[tb];
@@ -216,9 +214,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     }
     __syncthreads();
     auto byte_offset = [&](int pix, int part4) {
-        int o = pix >= 0 ? (pix * P.in_stride + part4) * 4 : ((POD_WINO_VAR & 4) ? part4 * 4 : 0x7FFFFF00);
-        if (POD_WINO_VAR & 8) o &= 0x3FFFF;          // (experiment: every piece from the same 256 KB)
-        return o;
+        return pix >= 0 ? (pix * P.in_stride + part4) * 4 : 0x7FFFFF00;
     };
     // The first two chunks come from two MINI stages (8 channels each, 324 pixels x 32 B, 3 LDS-DMA instructions per wave each), so the
     // matrix cores start after 20 KB have landed instead of a 48 KB super-chunk; super-chunk 0 lands behind the first chunk's MFMAs.
@@ -262,7 +258,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     f32x4 x[12];                                                         // raw patch, one 4-channel half at a time: x[row][c]
     vu32x4 Vb[6][2];                                                      // the transformed patch as f16 operands: [position][term], 8 channels (regs 0-1: channels 0-3, 2-3: 4-7)
     float tN[6][4], vN[2][6][4];                                         // the NEXT chunk's transform in flight: row-combined columns; transformed values [half][position] (fp32, split later)
-#if POD_WINO_ELIM
+    if (POD_WINO_ELIM) {                                                  // (elimination builds: operands that were never loaded still need values)
 #pragma unroll
     for (int i = 0; i < 12; ++i) Vb[i / 2][i % 2] = vu32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + lane};
 #pragma unroll
@@ -271,7 +267,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     for (int i = 0; i < 48; ++i) vN[i / 24][(i / 4) % 6][i % 4] = x[i / 4][i % 4];
 #pragma unroll
     for (int i = 0; i < 24; ++i) tN[i / 4][i % 4] = x[i / 4][i % 4];
-#endif
+    }
     // (reads as asm with hand-counted completion: see k11_wino_conv.hip)
 #define WINO_READ(par, c16, hf, i)                                                                                                  \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[i]) : "v"(areg[(i) / 6][((i) % 6) >> 2][c16][hf]), "i"((par) * WINO_SB_FLOATS * 4 + ((i) % 6) * 256))
@@ -291,78 +287,52 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // make the dropped partial products one-signed: a bias the Winograd cancellation amplifies -- measured) and packed pairwise.
     //
     // The pieces of that work, so that they can be slotted behind MFMAs one small unit at a time (`unit` below) or run back to back
-    // (`make_v`: the first two chunks).  A unit PINS its inputs when it starts and its results when it ends (empty volatile asm): pure
-    // arithmetic otherwise floats to wherever instruction selection likes it, i.e. away from the MFMA it was meant to hide behind.
-#ifndef POD_WINO_XFORM_PINS
-#define POD_WINO_XFORM_PINS 0      // (the same: the slots keep their units through sched_barrier alone)
-#endif
-#if POD_WINO_XFORM_PINS
-#define WINO_XFORM_PIN(...) wino_pin(__VA_ARGS__)
-#else
-#define WINO_XFORM_PIN(...)
-#endif
+    // (`make_v`: the first two chunks).  The units keep their slots through the sched_barrier behind every MFMA (round 4 also pinned their
+    // inputs and results with empty volatile asm: measured in round 5 to change nothing but +65 s_nop per chunk, deleted in round 6).
     auto rows_combine = [&](int c0, int c1) __attribute__((always_inline)) {              // tN[c] = x0[c] + s x1[c]
 #pragma unroll
         for (int c = c0; c < c1; ++c) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) tN[c][e] = __builtin_fmaf(sgn, x[6 + c][e], x[c][e]);
-            WINO_XFORM_PIN(tN[c][0], tN[c][1], tN[c][2], tN[c][3]);
         }
     };
     float w0s[4], w1s[4], evs[4], ods[4], fs[4], gs[4];                                   // column transform, first level (per channel e)
     auto columns_level1 = [&](int e) __attribute__((always_inline)) {
-        WINO_XFORM_PIN(tN[1][e], tN[2][e], tN[3][e], tN[4][e], tN[5][e]);
         w0s[e] = __builtin_fmaf(-5.0f, tN[2][e], tN[4][e]);
         w1s[e] = __builtin_fmaf(-5.0f, tN[3][e], tN[5][e]);
         evs[e] = __builtin_fmaf(-4.0f, tN[2][e], tN[4][e]);
         ods[e] = __builtin_fmaf(-4.0f, tN[1][e], tN[3][e]);
         fs[e] = tN[4][e] - tN[2][e];
         gs[e] = tN[3][e] - tN[1][e];
-        WINO_XFORM_PIN(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e]);
     };
     auto columns_level2 = [&](int hf, int e) __attribute__((always_inline)) {
-        WINO_XFORM_PIN(w0s[e], w1s[e], evs[e], ods[e], fs[e], gs[e], tN[0][e], tN[1][e]);
         vN[hf][0][e] = __builtin_fmaf(4.0f, tN[0][e], w0s[e]);
         vN[hf][5][e] = __builtin_fmaf(4.0f, tN[1][e], w1s[e]);
         vN[hf][1][e] = evs[e] + ods[e];
         vN[hf][2][e] = evs[e] - ods[e];
         vN[hf][3][e] = __builtin_fmaf(2.0f, gs[e], fs[e]);
         vN[hf][4][e] = __builtin_fmaf(-2.0f, gs[e], fs[e]);
-        WINO_XFORM_PIN(vN[hf][0][e], vN[hf][1][e], vN[hf][2][e], vN[hf][3][e], vN[hf][4][e], vN[hf][5][e]);
     };
     // The two f16 terms of position p's 8 values (4 channel pairs: pair i = half i >> 1, channels 2 (i & 1) ..), in three steps whose
     // operations are independent of each other inside a step (a pair's own chain is convert -> residual -> convert):
     // w = nearest-even f16 pair of (v s) (v_fma_mixlo/hi_f16), residual r = v s - w exactly (v_fma_mix_f32, in place: vN is dead
     // afterwards), second term = nearest-even f16 pair of r (v_cvt_pk_f16_f32).
-#ifndef POD_WINO_SPLIT_PINS
-#define POD_WINO_SPLIT_PINS 0      // (each pin next to a dst-sel producer costs an s_nop: 85 -> 20 per chunk without them, placement unchanged)
-#endif
-#if POD_WINO_SPLIT_PINS
-#define WINO_SPLIT_PIN(...) wino_pin(__VA_ARGS__)
-#else
-#define WINO_SPLIT_PIN(...)
-#endif
     const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wino_pow2_scale(wino_reduce_amax(in_amax_slot), WINO_V_TOP))));
     auto split_convert = [&](int p, int term) __attribute__((always_inline)) {
         vu32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                                      // i = 2 hf + pair: regs 0-1 channels 0-3, 2-3 channels 4-7
-            WINO_SPLIT_PIN(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
             w[i] = term == 0 ? wino_f16_pair_scaled(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1], sv)
                              : wino_f16_pair(vN[i >> 1][p][2 * (i & 1)], vN[i >> 1][p][2 * (i & 1) + 1]);
         }
         Vb[p][term] = w;
-        WINO_SPLIT_PIN(Vb[p][term]);
     };
     auto split_residual = [&](int p, int i0, int i1) __attribute__((always_inline)) {      // v <- v s - the first term, exactly
-        WINO_SPLIT_PIN(Vb[p][0]);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             float& lo = vN[i >> 1][p][2 * (i & 1)];
             float& hi = vN[i >> 1][p][2 * (i & 1) + 1];
-            WINO_SPLIT_PIN(lo, hi);
             wino_f16_residual_scaled(Vb[p][0][i], lo, hi, sv);
-            WINO_SPLIT_PIN(lo, hi);
         }
     };
     auto split_position = [&](int p) __attribute__((always_inline)) {                      // all three steps back to back
@@ -489,7 +459,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
                 acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), zero16, 0, 0, 0);
             else
                 acc[p * 2 + kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wino_f16x8, uP[p][kb * 2 + sa]), __builtin_bit_cast(wino_f16x8, Vb[p][sb]), acc[p * 2 + kb], 0, 0, 0);
-            if constexpr (m < 4) { if (!(POD_WINO_ELIM & 2)) filter_piece(p + POD_WINO_U_LEAD >= 6 ? qn : q, (p + POD_WINO_U_LEAD) % 6, uP[(p + POD_WINO_U_LEAD) % 6], m); }
+            if constexpr (m < 4) { if (!(POD_WINO_ELIM & 2)) filter_piece(p + WINO_U_LEAD >= 6 ? qn : q, (p + WINO_U_LEAD) % 6, uP[(p + WINO_U_LEAD) % 6], m); }
             else if constexpr (m == 4) { if (!(POD_WINO_ELIM & 4)) stage_write(c16 == 0 ? par ^ 1 : par, p, c16 == 0 ? 6 + p : p); }
             if constexpr (p == 5 && m >= 4) {                    // the 6 stage loads (HBM) sit BEHIND the chunk's last filter loads: loads return in
                 if (!(POD_WINO_ELIM & 4)) {                      // order, and every filter term ahead is needed soon
@@ -546,11 +516,11 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
     // Every wave applies At4 to its row of 6 positions in registers (4 output columns) and parks Z[a][tile][column][channel] in LDS
     // (130 KB); the store pass combines the four rows in a fixed order:  Y[0][x] = (Z[0][x] + Z[1][x]) + Z[2][x],
     // Y[1][x] = (Z[1][x] - Z[2][x]) - Z[3][x]
-#if POD_WINO_ELIM & 128
+    if (POD_WINO_ELIM & 128) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
-    return;
-#endif
+        for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(acc[i]));
+        return;
+    }
     // The MFMAs run with the FILTER as the row operand: a lane's accumulator register reg of block (p, kb) is channel
     // 32 kb + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of tile lane & 31 -- four consecutive channels per register quad, so the
     // transform runs on packed pairs and a 16-byte store parks 4 channels.  Staging: Z[a][tile][column e][64 channels], a tile's 4 x 64
@@ -572,9 +542,7 @@ __global__ void __launch_bounds__(256, 1) k_wino_conv3x3_split(const WinoParams 
         }
     __syncthreads();
     WINO_STAMP(4);
-#if POD_WINO_ELIM & 32
-    return;
-#endif
+    if (POD_WINO_ELIM & 32) return;
     constexpr int ZA = 32 * TS;                // floats per position row a
     float* const out_base = set_out + (int64_t)blockIdx.y * P.split_out_stride;
     // the accumulators hold (s_u U) (s_v V) sums: the two powers of two come off again in the store pass -- exactly, inside the

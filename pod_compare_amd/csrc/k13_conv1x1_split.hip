@@ -25,10 +25,6 @@
 // even that leaves the chip idle the input channels are cut over grid.y (partial sums, finished by pod_conv1x1_reduce in a fixed order).
 #include "pod_wino.h"
 
-#ifndef POD_C1_ELIM
-#define POD_C1_ELIM 0        // experiment builds: 1 no activation loads, 2 no filter loads, 4 no split arithmetic, 8 no stores (time only)
-#endif
-
 #ifdef POD_C1_TRACE       // experiment builds: 10-ns time stamps of every wavefront (start | first k-step done | loop done | end), pod_c1_trace_dump()
 static __device__ long long g_c1_trace[8192 * 4];
 static __device__ long long g_c1_cycles[8192 * 4];      // s_memtime beside the constant 100-MHz clock: the shader clock the wavefront ran at
@@ -577,18 +573,15 @@ extern "C" int pod_conv1x1_split(const float* x, float* y, const void* Ws, const
     P.split_stride = n_splits > 1 ? P_out * Cout : 0;
     const int64_t grid = 8LL * ((P.n_pt + 7) / 8) * P.n_ct;
     if (grid > 0x7FFFFFFFLL) return POD_E_INVALID;
-#ifndef POD_C1_RING
-#define POD_C1_RING 3
-#endif
-#ifndef POD_C1_DIRECT       // (experiment builds: the direct-fragment kernel everywhere, tools/conv1x1_ab.py, tools/conv1x1_elim.py)
-    if ((P.ks_per_split & 1) == 0 && waves == 4)
+    if (POD_C1_DIRECT)          // (experiment builds: the direct-fragment kernel everywhere, pod_experiments.h)
+        hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
+    else if ((P.ks_per_split & 1) == 0 && waves == 4)
         hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 4>), dim3((unsigned)grid, (unsigned)n_splits), dim3(256), 0, (hipStream_t)stream, P);
     else if ((P.ks_per_split & 1) == 0 && waves == 2)
         hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 2>), dim3((unsigned)grid, (unsigned)n_splits), dim3(128), 0, (hipStream_t)stream, P);
     else if ((P.ks_per_split & 1) == 0)
         hipLaunchKernelGGL((pod::k_conv1x1_split_lds<2, 1>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
     else
-#endif
         hipLaunchKernelGGL((pod::k_conv1x1_split<2, POD_C1_RING>), dim3((unsigned)grid, (unsigned)n_splits), dim3(64), 0, (hipStream_t)stream, P);
     POD_CHECK_LAUNCH();
     if (n_splits > 1) {

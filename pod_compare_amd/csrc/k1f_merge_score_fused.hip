@@ -25,22 +25,9 @@
 #include <mutex>
 
 #include "pod_device.h"
+#include "pod_experiments.h"
 
-#ifndef POD_K1F_WAVES
-#define POD_K1F_WAVES 4      // wavefronts per workgroup (each streams its own, distant, chunk; all of them score the parked cells)
-#endif
-#ifndef POD_K1F_WPE
-#define POD_K1F_WPE 3        // wavefronts per SIMD the register allocation aims at: 12 per CU = all 3 060 wavefronts of a BASELINE launch resident
-#endif
-#ifndef POD_K1F_BATCH
-#define POD_K1F_BATCH 2      // runs whose loads are in flight together (CPL < 4): 2 x 2K loads per lane
-#endif
-#ifndef POD_K1F_NT
-#define POD_K1F_NT 1         // non-temporal loads (the runs are read exactly once)
-#endif
-#ifndef POD_K1F_CELLS
-#define POD_K1F_CELLS 1      // consecutive cells of a plane per lane (1, 2 or 4: 4-, 8- or 16-byte loads)
-#endif
+// launch geometry: POD_K1F_WAVES / _WPE / _BATCH / _NT / _CELLS (pod_experiments.h; profiles/r05_k1f_variants.txt: the defaults are the fastest of twelve)
 
 namespace pod {
 
@@ -206,14 +193,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
 
     // ---- stream: wavefront w of workgroup b takes wave-unit b + w * gridDim.x (units of one workgroup lie far apart) -----------------
-#ifdef POD_K1F_ADJ
-    const int u = (int)blockIdx.x * WAVES + wave;            // (experiment: the wavefronts of a workgroup stream ADJACENT chunks)
-#else
     // (rotating the quarters against each other so that the four units of a workgroup lie in different parts of the IMAGE as well:
     //  measured, no difference -- the 4 us this kernel takes beyond its streaming part are the barrier, one scoring round and the
     //  emission, not a cluster that piled up in one workgroup)
-    const int u = (int)blockIdx.x + wave * (int)gridDim.x;
-#endif
+    const int u = POD_K1F_ADJ ? (int)blockIdx.x * WAVES + wave : (int)blockIdx.x + wave * (int)gridDim.x;
     if (u < P.unit_begin[L]) {
         int l = 0;
         while (l + 1 < L && u >= P.unit_begin[l + 1]) ++l;
@@ -255,9 +238,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int j = 0; j < CPL; ++j)
                 if (hw0 + j >= HW) flags &= ~(1u << j);
-#ifdef POD_K1F_NOSCORE
-            flags = 0;                                       // (experiment: the streaming part alone)
-#endif
+            if (POD_K1F_NOSCORE) flags = 0;                  // (experiment builds: the streaming part alone)
             // park the flagged cells with their 2K merged values
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {

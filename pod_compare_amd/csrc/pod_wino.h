@@ -7,6 +7,7 @@
 #include <utility>
 
 #include "pod_device.h"
+#include "pod_experiments.h"
 
 namespace pod {
 
@@ -36,15 +37,6 @@ static __device__ long long g_wino_trace[8192 * 16];
 #define WINO_STAMP_WALL(k)
 #endif
 
-// -DPOD_WINO_ELIM=<bits> (tagged experiment builds only, tools/wino_elim.sh): parts of the kernel compiled out to price them --
-// results are then wrong, only the time is of interest.  1 patch reads, 2 filter loads, 4 patch DMA, 8 input transform,
-// 16 chunk barrier, 32 store pass, 64 dropout mask, 128 accumulator dump + store pass.
-#ifndef POD_WINO_ELIM
-#define POD_WINO_ELIM 0
-#endif
-#ifndef POD_WINO_VAR
-#define POD_WINO_VAR 0
-#endif
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14): lgkmcnt(0) with vmcnt(4) / vmcnt(0)
 constexpr int WINO_WAIT_VM4 = 0x0074, WINO_WAIT_VM0 = 0x0070, WINO_WAIT_VM16 = 0x4070, WINO_WAIT_LGKM0 = 0xC07F;
 

@@ -28,7 +28,9 @@ EXPORTS = ("pod_abi_version", "pod_mc_merge_score", "pod_maybe_words", "pod_scor
            "pod_decode_cov", "pod_nms_scratch_bytes", "pod_nms_cluster", "pod_bayes_fuse", "pod_anchor_stats_merge",
            "pod_ensemble_append", "pod_ensemble_merge",
            "pod_finalize", "pod_reg_nll", "pod_relu_dropout", "pod_bias_act", "pod_bias_act_to_nchw", "pod_bias_act_to_nhwc", "pod_expand_dropout", "pod_match_groundtruth", "pod_run_image", "pod_run_image_part",
-           "pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_f16_split2", "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl", "pod_im2col3x3s2_cl")
+           "pod_absmax", "pod_wino_filter_transform", "pod_wino_conv3x3", "pod_wino_filter_split_bytes", "pod_wino_filter_transform_split", "pod_wino_conv3x3_split", "pod_sparse_reach", "pod_sparse_live_blocks", "pod_wino_reduce", "pod_conv1x1_filter_split_bytes", "pod_conv1x1_filter_split", "pod_conv1x1_split", "pod_reduce_partials", "pod_stem7x7_filter_split", "pod_stem7x7_split", "pod_maxpool3x3s2_cl", "pod_im2col3x3s2_cl")
+# include/pod_mi355x_test.h: test support (the dumps of the in-kernel draws and of the f16 split) -- exported for tests/ and tools/, not part of the boundary
+TEST_EXPORTS = ("pod_dump_cls_normals", "pod_dump_box_normals", "pod_debug_f16_split2")
 POD_MODE_STANDARD_NMS, POD_MODE_BAYES_OD, POD_MODE_ANCHOR_STATISTICS = 0, 1, 2
 
 
@@ -94,7 +96,7 @@ def load() -> ctypes.CDLL:
         raise PodError("HIP library {} not found: run `python -m pod_compare_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the hot path.".format(path))
     lib = ctypes.CDLL(path)
-    for name in EXPORTS:
+    for name in EXPORTS + TEST_EXPORTS:
         if not hasattr(lib, name):
             raise PodError("{} does not export {}".format(path, name))
     P = c_void_p
@@ -150,7 +152,7 @@ def load() -> ctypes.CDLL:
                                   c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), P]
     lib.pod_run_image_part.argtypes = [POINTER(PodConfig), POINTER(PodLevel), POINTER(PodWorkspace), c_int32, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, POINTER(PodDetections), c_int32, P]
-    for name in EXPORTS:
+    for name in EXPORTS + TEST_EXPORTS:
         if name not in ("pod_abi_version", "pod_nms_scratch_bytes", "pod_maybe_words", "pod_wino_filter_split_bytes", "pod_conv1x1_filter_split_bytes"):
             getattr(lib, name).restype = ctypes.c_int
     if lib.pod_abi_version() != POD_ABI_VERSION:

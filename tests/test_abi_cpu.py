@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pod_mi355x.h")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+TEST_HEADER = os.path.join(ROOT, "include", "pod_mi355x_test.h")
+
+
+def declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(?:int|int64_t|size_t)\s+(pod_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,11 +29,13 @@ def lib_path():
 
 def test_header_and_binding_agree():
     assert declared_symbols() == sorted(hip.EXPORTS)
+    assert declared_symbols(TEST_HEADER) == sorted(hip.TEST_EXPORTS)          # test support lives in its own header (round 6)
+    assert not set(hip.TEST_EXPORTS) & set(declared_symbols())
 
 
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
-    for name in declared_symbols():
+    for name in declared_symbols() + declared_symbols(TEST_HEADER):
         assert hasattr(lib, name), name
     assert lib.pod_abi_version() == hip.POD_ABI_VERSION
 
