@@ -307,3 +307,27 @@ def test_plain_model_without_variance_heads_takes_the_sparse_order_too():
     assert k == want.count() and k > 0 and torch.equal(got.classes[:k], want.classes[:k])
     assert float((got.boxes[:k] - want.boxes[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.boxes[:k].abs().max()))
     assert float((got.cov[:k] - want.cov[:k]).abs().max()) <= 1e-4 * max(1.0, float(want.cov[:k].abs().max()))
+
+
+def test_an_image_without_candidates_runs_no_block_and_gives_no_detections():
+    """The default order of apply_net must survive an empty image: no candidate (PI:300-308 selects nothing) -> every live list is empty, every
+    launch of the bbox side exits at once, the path finishes with zero detections -- as the dense order does."""
+    m = build(dropout_rate=0.0)
+    frame = torch.randint(0, 256, (3, 256, 384), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12))
+    pl = synthetic.planted_head_outputs((256, 384), 1, seed=31, num_boxes=0).to("cuda")
+    hp = hotpath.HotPath(pl.shapes, pl.anchors, hotpath.PathParams(), n_runs=1, has_cls_var=True, cov_dims=4, device="cuda:0")
+    seen = {}
+
+    def hook(partial):
+        hp.select(pl.cls, pl.cls_var, draw_id=4)
+        seen["lb"] = sparse.LiveBlocks(hp)
+        return seen["lb"]
+
+    sp = m(frame, sparse_bbox=hook)
+    got = hp.finish("bayes_od", pl.cls, sp.delta, pl.cls_var, sp.reg_var, (256, 384), (256, 384))
+    assert int(hp.n_total.item()) == 0 and got.count() == 0
+    lv = [tuple(s) for s in pl.shapes]
+    assert seen["lb"].fraction(block_table(lv, 1, "cuda"), 0) == 0.0 and seen["lb"].fraction(block_table(lv, 1, "cuda"), 4) == 0.0
+    dense = m(frame)
+    want = hp.run_image("bayes_od", pl.cls, dense.delta, pl.cls_var, dense.reg_var, (256, 384), (256, 384), draw_id=4)
+    assert want.count() == 0
